@@ -1,0 +1,483 @@
+"""CPU oracle for the s2_emit SRF + polynomial-regression path.  TEST INFRASTRUCTURE ONLY.
+
+This module is a NumPy restatement of the reference algorithm, written to follow the
+reference's operation order literally so that it agrees with it to the last bits.  It is the
+*checker*, never the product: only ``tests/``, ``__graft_entry__.smoke()`` and the
+``cpu_baseline`` leg of ``bench.py`` may import it.  The shipped package
+(``hyperspectral_super-resolution_amd/s2_emit``) never imports anything from ``oracle/``.
+
+Pinning: the reference ships no tests or golden vectors, so the oracle is
+pinned against outputs of the reference functions themselves, imported by path in the build
+container by ``oracle/ref_loader.py`` and frozen into ``tests/golden/*.npz`` by
+``tests/golden/gen_golden.py``.  ``tests/test_oracle_golden.py`` re-checks the oracle against
+those fixtures on every run.  Two sub-steps stay **parity unpinned** because their third-party
+implementation is absent from the container and from the reference tree:
+  * the Sinkhorn transport plan (POT ``ot.dist`` / ``ot.sinkhorn``, unpinned dependency), and
+  * the GDAL ``reproject`` resamplers between the phases (rasterio absent).
+They are restated from the published algorithm and checked by invariants only.
+
+Each function cites the reference lines it follows (paths relative to the reference root).
+NumPy's own ``interp`` / ``percentile`` / ``polyfit`` / ``polyval`` are the reference's
+third-party arithmetic (requirements.txt:3) and are called directly, exactly as it calls them.
+"""
+from __future__ import annotations
+
+from itertools import combinations_with_replacement
+from typing import Dict, Optional, Sequence, Tuple
+
+import numpy as np
+
+S2_BANDS_13 = ["B1", "B2", "B3", "B4", "B5", "B6", "B7", "B8", "B8A", "B9", "B10", "B11", "B12"]  # s2_emit/srf.py:11
+
+
+# ---------------------------------------------------------------------------------------------
+# a2: SRF band integration  (s2_emit/synth.py:9-45)
+# ---------------------------------------------------------------------------------------------
+def _trapezoid_last_axis(y: np.ndarray, x: np.ndarray) -> np.ndarray:
+    """numpy.trapz(y, x=x, axis=-1) as NumPy computes it: sum(d * (y[1:] + y[:-1]) / 2)."""
+    d = np.diff(x)
+    return (d * (y[..., 1:] + y[..., :-1]) / 2.0).sum(axis=-1)
+
+
+def band_response_on_emit(emit_w, lam_srf, rsp_srf, good_mask=None) -> np.ndarray:
+    """SRF of one band resampled on the EMIT wavelength grid (synth.py:25,33-35)."""
+    w = np.asarray(emit_w).astype(float)
+    r = np.interp(w, lam_srf, rsp_srf, left=0.0, right=0.0)
+    if good_mask is not None:
+        r = r * np.asarray(good_mask).astype(float)
+    return r
+
+
+def pseudo_s2_srf_integral(R, emit_w, srf_dict, good_mask=None) -> Dict[str, Optional[np.ndarray]]:
+    """Literal restatement of synth.py:9-45 (float64 temporaries, one full-cube pass per band)."""
+    out: Dict[str, Optional[np.ndarray]] = {}
+    emit_w = np.asarray(emit_w).astype(float)                                  # synth.py:25
+    if R.ndim != 3:                                                            # synth.py:27-28
+        raise ValueError(f"R must be (H,W,B). Got shape {R.shape}")
+    if emit_w.ndim != 1 or emit_w.shape[0] != R.shape[-1]:                     # synth.py:29-30
+        raise ValueError(f"emit_w must be (B,) matching R bands. Got {emit_w.shape} vs {R.shape[-1]}")
+    for band, (lam_srf, rsp_srf) in srf_dict.items():                          # synth.py:32
+        r = band_response_on_emit(emit_w, lam_srf, rsp_srf, good_mask)         # synth.py:33-35
+        if np.all(r == 0):                                                     # synth.py:37-39
+            out[band] = None
+            continue
+        with np.errstate(invalid="ignore", over="ignore"):
+            num = _trapezoid_last_axis(R * r[None, None, :], emit_w)           # synth.py:41
+        den = _trapezoid_last_axis(r, emit_w)                                  # synth.py:42
+        out[band] = num / (den + 1e-32)                                        # synth.py:43
+    return out
+
+
+def srf_weight_matrix(emit_w, srf_dict, good_mask=None) -> Tuple[np.ndarray, list]:
+    """Weight-matrix form of the same integral: out_b = sum_k R_k * Wn[b,k].
+
+    Returns (Wn (nb_supported, B) float64, names of supported bands in dict order).
+    Used by tests to check the algebraic identity the device kernel relies on.
+    """
+    w = np.asarray(emit_w).astype(float)
+    d = np.diff(w)
+    half = (np.concatenate([[0.0], d]) + np.concatenate([d, [0.0]])) / 2.0
+    rows, names = [], []
+    for band, (lam, rsp) in srf_dict.items():
+        r = band_response_on_emit(w, lam, rsp, good_mask)
+        if np.all(r == 0):
+            continue
+        c = r * half
+        rows.append(c / (_trapezoid_last_axis(r, w) + 1e-32))
+        names.append(band)
+    return np.asarray(rows, dtype=np.float64).reshape(len(rows), w.shape[0]), names
+
+
+def pseudo_s2_rgb(pseudo_s2, order=("B4", "B3", "B2")) -> np.ndarray:
+    """synth.py:47-58."""
+    chans = []
+    for b in order:
+        x = pseudo_s2.get(b, None)
+        if x is None:
+            raise ValueError(f"Band {b} is None/missing in pseudo_s2.")
+        chans.append(x)
+    return np.stack(chans, axis=-1)
+
+
+# ---------------------------------------------------------------------------------------------
+# a4 / a10: percentile stretches and histogram matching  (s2_emit/color.py)
+# ---------------------------------------------------------------------------------------------
+def robust_norm(x, pmin=2, pmax=98):
+    """color.py:6-8."""
+    lo, hi = np.nanpercentile(x, [pmin, pmax])
+    return np.clip((x - lo) / (hi - lo + 1e-12), 0, 1)
+
+
+def robust_norm_rgb(img, mask, pmin=2, pmax=98):
+    """color.py:10-23 (unmasked pixels become NaN)."""
+    y = np.zeros_like(img, dtype=float)
+    for c in range(3):
+        lo, hi = np.percentile(img[..., c][mask], [pmin, pmax])
+        cc = (img[..., c] - lo) / (hi - lo + 1e-12)
+        cc[~mask] = np.nan
+        y[..., c] = np.clip(cc, 0, 1)
+    return y
+
+
+def apply_shared_percentile_stretch(img, mask, pmin=2, pmax=98, channels: Optional[int] = None):
+    """color.py:25-34; ``channels`` generalises the hard-coded 3 to nb planes (SURVEY.md 8 intro)."""
+    out = np.zeros_like(img, dtype=np.float32)
+    for c in range(3 if channels is None else channels):
+        lo, hi = np.percentile(img[..., c][mask], [pmin, pmax])
+        out[..., c] = np.clip((img[..., c] - lo) / (hi - lo + 1e-12), 0, 1)
+    return out
+
+
+def percentile_limits(plane, mask, pmin=2, pmax=98):
+    """The (lo, hi) pair of color.py:31-32 for one channel, float64."""
+    lo, hi = np.percentile(plane[mask], [pmin, pmax])
+    return float(lo), float(hi)
+
+
+def _hist_match_channel(src, ref, mask):
+    """color.py:36-53."""
+    src_vals = src[mask].ravel()
+    ref_vals = ref[mask].ravel()
+    s_values, s_idx, s_counts = np.unique(src_vals, return_inverse=True, return_counts=True)
+    r_values, r_counts = np.unique(ref_vals, return_counts=True)
+    s_q = np.cumsum(s_counts).astype(np.float64)
+    s_q /= (s_q[-1] + 1e-32)
+    r_q = np.cumsum(r_counts).astype(np.float64)
+    r_q /= (r_q[-1] + 1e-32)
+    matched = np.interp(s_q, r_q, r_values)[s_idx].reshape(src_vals.shape)
+    out = src.copy()
+    out[mask] = matched
+    return out
+
+
+def histogram_match_rgb(src_rgb, ref_rgb, mask):
+    """color.py:55-63."""
+    out = src_rgb.copy()
+    for c in range(3):
+        out[..., c] = _hist_match_channel(out[..., c], ref_rgb[..., c], mask)
+    return np.clip(out, 0, 1)
+
+
+# ---------------------------------------------------------------------------------------------
+# Sinkhorn (POT restated; PARITY UNPINNED - POT is not installed and not pinned by the reference)
+# ---------------------------------------------------------------------------------------------
+def sqeuclidean_cost(X, Y):
+    """ot.dist(X, Y, metric='sqeuclidean'): ||x||^2 + ||y||^2 - 2 x.y, clipped at 0 (POT docs)."""
+    a2 = np.einsum("ij,ij->i", X, X)[:, None]
+    b2 = np.einsum("ij,ij->i", Y, Y)[None, :]
+    return np.maximum(a2 + b2 - 2.0 * X.dot(Y.T), 0.0)
+
+
+def sinkhorn_knopp(a, b, M, reg, numItermax=1000, stopThr=1e-9):
+    """POT ``sinkhorn_knopp`` as documented: K = exp(-M/reg); v <- b/(K^T u); u <- a/(K v);
+    every 10th iteration err = ||v * (K^T u) - b||_2, stop when err < stopThr; on a numerical
+    breakdown keep the previous (u, v).  Returns u[:,None] * K * v[None,:].
+    """
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    K = np.exp(M / (-reg))
+    u = np.full(a.shape[0], 1.0 / a.shape[0])
+    v = np.full(b.shape[0], 1.0 / b.shape[0])
+    for ii in range(numItermax):
+        uprev, vprev = u, v
+        KtU = K.T.dot(u)
+        v = b / KtU
+        u = a / K.dot(v)
+        if (np.any(KtU == 0) or np.any(np.isnan(u)) or np.any(np.isnan(v))
+                or np.any(np.isinf(u)) or np.any(np.isinf(v))):
+            u, v = uprev, vprev
+            break
+        if ii % 10 == 0:
+            tmp2 = np.einsum("i,ij,j->j", u, K, v)
+            err = np.linalg.norm(tmp2 - b)
+            if err < stopThr:
+                break
+    return u[:, None] * K * v[None, :]
+
+
+def _ot_samples(src_rgb, ref_rgb, mask, n_samples, seed, min_rows):
+    """Shared head of fit_ot_poly_rgb / ot_match_rgb_sinkhorn_pot (poly_regression.py:31-47)."""
+    rng = np.random.default_rng(seed)
+    X_all = src_rgb[mask].reshape(-1, 3).astype(np.float64)
+    Y_all = ref_rgb[mask].reshape(-1, 3).astype(np.float64)
+    X_all = X_all[np.isfinite(X_all).all(axis=1)]
+    Y_all = Y_all[np.isfinite(Y_all).all(axis=1)]
+    if X_all.shape[0] < min_rows or Y_all.shape[0] < min_rows:
+        return None
+    ns = min(n_samples, X_all.shape[0])
+    nt = min(n_samples, Y_all.shape[0])
+    X = X_all[rng.choice(X_all.shape[0], size=ns, replace=False)]
+    Y = Y_all[rng.choice(Y_all.shape[0], size=nt, replace=False)]
+    return X, Y
+
+
+def ot_barycentric_targets(X, Y, reg=0.05, numItermax=300, stopThr=1e-6):
+    """poly_regression.py:49-56."""
+    ns, nt = X.shape[0], Y.shape[0]
+    a = np.full(ns, 1.0 / ns, dtype=np.float64)
+    b = np.full(nt, 1.0 / nt, dtype=np.float64)
+    P = sinkhorn_knopp(a, b, sqeuclidean_cost(X, Y), reg, numItermax=numItermax, stopThr=stopThr)
+    return (P @ Y) / (P.sum(axis=1, keepdims=True) + 1e-32)
+
+
+# ---------------------------------------------------------------------------------------------
+# a5 / a6: polynomial fit and apply  (s2_emit/poly_regression.py:16-84)
+# ---------------------------------------------------------------------------------------------
+def fit_ot_poly_rgb(src_rgb, ref_rgb, mask, deg=2, n_samples=5000, reg=0.05, numItermax=300,
+                    stopThr=1e-6, seed=0):
+    """poly_regression.py:16-62 (Sinkhorn sub-step parity unpinned, see module docstring)."""
+    s = _ot_samples(src_rgb, ref_rgb, mask, n_samples, seed, 200)
+    coeffs = np.zeros((3, deg + 1), dtype=np.float64)
+    if s is None:                                                              # :38-41
+        coeffs[:, -2] = 1.0
+        return coeffs
+    X, Y = s
+    Ybar = ot_barycentric_targets(X, Y, reg, numItermax, stopThr)
+    for c in range(3):                                                         # :59-60
+        coeffs[c] = np.polyfit(X[:, c], Ybar[:, c], deg=deg)
+    return coeffs
+
+
+def polyfit_channels(X, Ybar, deg):
+    """The step (vi) of a5 on explicit (x, ybar) columns: one np.polyfit per channel."""
+    return np.stack([np.polyfit(X[:, c], Ybar[:, c], deg=deg) for c in range(X.shape[1])])
+
+
+def apply_poly_rgb(rgb, coeffs, mask=None):
+    """poly_regression.py:65-84; channel count taken from coeffs (reference hard-codes 3)."""
+    out = rgb.copy().astype(np.float32)
+    nch = len(coeffs)
+    if mask is None:
+        for c in range(nch):
+            out[..., c] = np.polyval(coeffs[c], out[..., c])
+        return np.clip(out, 0.0, 1.0)
+    for c in range(nch):
+        x = out[..., c]
+        y = np.polyval(coeffs[c], x)
+        x2 = x.copy()
+        x2[mask] = y[mask]
+        out[..., c] = x2
+    return np.clip(out, 0.0, 1.0)
+
+
+# ---------------------------------------------------------------------------------------------
+# a8: per-band least squares over all valid pixels
+#     (Pairs_EMIT_S2_demo-2.ipynb cell 72, raw lines 4484-4510), degree generalised.
+# ---------------------------------------------------------------------------------------------
+def per_band_valid(x, y, valid_mask, min_valid=0.0):
+    return valid_mask & np.isfinite(x) & np.isfinite(y) & (x > min_valid) & (y > min_valid)
+
+
+def fit_per_band_poly(pseudo_stack, real_stack, valid_mask, deg=1, min_valid=0.0, min_count=50):
+    """Per band k: polyfit over every valid pixel; fewer than ``min_count`` -> identity."""
+    nb = pseudo_stack.shape[0]
+    coeffs = np.zeros((nb, deg + 1), dtype=np.float64)
+    counts = np.zeros(nb, dtype=np.int64)
+    for k in range(nb):
+        x, y = pseudo_stack[k], real_stack[k]
+        with np.errstate(invalid="ignore"):
+            vk = per_band_valid(x, y, valid_mask, min_valid)
+        x1 = x[vk].astype(np.float64)
+        y1 = y[vk].astype(np.float64)
+        counts[k] = x1.size
+        if x1.size < min_count:
+            coeffs[k, -2] = 1.0
+        else:
+            coeffs[k] = np.polyfit(x1, y1, deg=deg)
+    return coeffs, counts
+
+
+def calibrate_pseudo_to_real_linear(pseudo_stack, real_stack, valid_mask, min_valid=0.0):
+    """Notebook cell 72 verbatim semantics: deg 1, corrected = (x*a + b) as float32."""
+    coeffs, _ = fit_per_band_poly(pseudo_stack, real_stack, valid_mask, 1, min_valid, 50)
+    corrected = np.zeros_like(pseudo_stack, dtype=np.float32)
+    params = []
+    for k in range(pseudo_stack.shape[0]):
+        a, b = coeffs[k]
+        corrected[k] = (pseudo_stack[k] * a + b).astype(np.float32)
+        params.append((float(a), float(b)))
+    return corrected, params
+
+
+def apply_poly_planes(planes, coeffs, mask=None, clip=True):
+    """apply_poly_rgb semantics on a band-major (nb,H,W) stack (what the device pipeline uses)."""
+    hw_last = np.moveaxis(np.asarray(planes), 0, -1)
+    if clip:
+        res = apply_poly_rgb(hw_last, coeffs, mask)
+    else:
+        res = hw_last.copy().astype(np.float32)
+        for c in range(len(coeffs)):
+            y = np.polyval(coeffs[c], res[..., c])
+            if mask is None:
+                res[..., c] = y
+            else:
+                x2 = res[..., c].copy()
+                x2[mask] = y[mask]
+                res[..., c] = x2
+    return np.ascontiguousarray(np.moveaxis(res, -1, 0))
+
+
+# ---------------------------------------------------------------------------------------------
+# a7: the pipeline of poly_regression.py:96-139 on a grid-aligned synthetic pair
+#     ("per-band least squares" flavour: no OT, every valid pixel, nb bands).
+# ---------------------------------------------------------------------------------------------
+def fuse_lsq_reference(R, emit_w, srf_dict, good_mask, real_planes, deg, min_valid=0.0,
+                       min_count=50, clip=True):
+    """SRF -> per-band all-valid-pixel polyfit -> apply.  The C1..C3 workload, reference-ordered.
+
+    real_planes: (nb_supported, H, W) real-S2 planes for the supported bands, dict order.
+    Returns (pseudo (nb,H,W) f32, coeffs (nb,deg+1) f64, matched (nb,H,W) f32, names).
+    """
+    ps = pseudo_s2_srf_integral(R, emit_w, srf_dict, good_mask)
+    names = [b for b, v in ps.items() if v is not None]
+    pseudo = np.stack([ps[b] for b in names], axis=0).astype(np.float32)       # poly_regression.py:104
+    valid = np.ones(pseudo.shape[1:], dtype=bool)
+    coeffs, _ = fit_per_band_poly(pseudo, real_planes, valid, deg, min_valid, min_count)
+    fitmask = None
+    matched = apply_poly_planes(pseudo, coeffs, fitmask, clip=clip)
+    return pseudo, coeffs, matched, names
+
+
+# ---------------------------------------------------------------------------------------------
+# a9: multivariate fusion variant (legacy_notebooks/Spectral_matching.ipynb)
+# ---------------------------------------------------------------------------------------------
+def logit(p, eps=1e-4):
+    """Spectral_matching.ipynb raw line 174-176."""
+    p = np.clip(p, eps, 1 - eps)
+    return np.log(p / (1 - p))
+
+
+def sigmoid(z):
+    """Spectral_matching.ipynb raw line 178-181."""
+    z = np.clip(z, -50, 50)
+    return 1.0 / (1.0 + np.exp(-z))
+
+
+def poly_feature_exponents(n_inputs: int, degree: int) -> np.ndarray:
+    """Exponent table of sklearn PolynomialFeatures(degree, include_bias=False): degree-major,
+    combinations_with_replacement order.  (n_features, n_inputs) int."""
+    rows = []
+    for d in range(1, degree + 1):
+        for comb in combinations_with_replacement(range(n_inputs), d):
+            e = np.zeros(n_inputs, dtype=np.int64)
+            for i in comb:
+                e[i] += 1
+            rows.append(e)
+    return np.stack(rows)
+
+
+def poly_features(Z, degree: int) -> np.ndarray:
+    expo = poly_feature_exponents(Z.shape[1], degree)
+    out = np.ones((Z.shape[0], expo.shape[0]), dtype=Z.dtype)
+    for f, e in enumerate(expo):
+        for i, p in enumerate(e):
+            for _ in range(int(p)):
+                out[:, f] *= Z[:, i]
+    return out
+
+
+def ridge_poly_fit(X, Y, degree=3, alpha=1.0):
+    """StandardScaler -> PolynomialFeatures(degree, no bias) -> Ridge(alpha, intercept) in float64
+    (Spectral_matching.ipynb raw lines 475-490).  Returns dict(mean, scale, coef, intercept)."""
+    X = np.asarray(X, dtype=np.float64)
+    Y = np.asarray(Y, dtype=np.float64)
+    mean = X.mean(axis=0)
+    scale = X.std(axis=0)
+    scale[scale == 0] = 1.0
+    Phi = poly_features((X - mean) / scale, degree)
+    pm, ym = Phi.mean(axis=0), Y.mean(axis=0)
+    Pc, Yc = Phi - pm, Y - ym
+    G = Pc.T @ Pc
+    G[np.diag_indices_from(G)] += alpha
+    coef = np.linalg.solve(G, Pc.T @ Yc).T            # (n_targets, n_features)
+    return dict(mean=mean, scale=scale, coef=coef, intercept=ym - coef @ pm, degree=degree)
+
+
+def ridge_poly_predict(model, X):
+    Z = (np.asarray(X, dtype=np.float64) - model["mean"]) / model["scale"]
+    return poly_features(Z, int(model["degree"])) @ model["coef"].T + model["intercept"]
+
+
+def predict_cube_logit(model, s2_cube):
+    """Spectral_matching.ipynb raw lines 192-213: (C,H,W) -> sigmoid(model(px)) as (T,H,W) f32."""
+    C, H, W = s2_cube.shape
+    X = s2_cube.reshape(C, -1).T.astype(np.float32)
+    pred = sigmoid(ridge_poly_predict(model, X)).astype(np.float32)
+    return pred.T.reshape(-1, H, W)
+
+
+# ---------------------------------------------------------------------------------------------
+# f1: grid-aligned resamplers (integer factor) - GDAL parity unpinned, see module docstring
+# ---------------------------------------------------------------------------------------------
+def block_mean(planes, factor: int):
+    """'average' resampling of an exactly aligned (C, H*f, W*f) stack onto the coarse grid."""
+    C, H, W = planes.shape
+    return planes.reshape(C, H // factor, factor, W // factor, factor).mean(axis=(2, 4), dtype=np.float64).astype(np.float32)
+
+
+def bilinear_upsample(planes, factor: int):
+    """Pixel-centre-aligned separable bilinear upsampling by an integer factor with edge clamp
+    (what GDAL bilinear does for interior pixels of an aligned grid)."""
+    C, H, W = planes.shape
+
+    def taps(n):
+        pos = (np.arange(n * factor) + 0.5) / factor - 0.5
+        i0 = np.floor(pos).astype(np.int64)
+        t = pos - i0
+        return np.clip(i0, 0, n - 1), np.clip(i0 + 1, 0, n - 1), t
+
+    r0, r1, tr = taps(H)
+    c0, c1, tc = taps(W)
+    p = planes.astype(np.float64)
+    top = p[:, r0][:, :, c0] * (1 - tc) + p[:, r0][:, :, c1] * tc
+    bot = p[:, r1][:, :, c0] * (1 - tc) + p[:, r1][:, :, c1] * tc
+    return (top * (1 - tr)[None, :, None] + bot * tr[None, :, None]).astype(np.float32)
+
+
+# ---------------------------------------------------------------------------------------------
+# Synthetic inputs of SURVEY.md 8(d) (NumPy, for the small parity cases and the CPU baseline)
+# ---------------------------------------------------------------------------------------------
+S2A_CENTRES = [443, 490, 560, 665, 705, 740, 783, 842, 865, 945, 1375, 1610, 2190]
+S2A_WIDTHS = [20, 65, 35, 30, 15, 15, 20, 115, 20, 20, 30, 90, 180]
+
+
+def synthetic_srf(threshold=1e-3):
+    lam = np.arange(300.0, 2600.0, 1.0)
+    srf = {}
+    for name, c, fwhm in zip(S2_BANDS_13, S2A_CENTRES, S2A_WIDTHS):
+        r = np.exp(-0.5 * ((lam - c) / (fwhm / 2.3548200450309493)) ** 2)
+        m = r > threshold
+        srf[name] = (lam[m].copy(), r[m].copy())
+    return srf
+
+
+def synthetic_wavelengths(B=285):
+    w = np.linspace(381.00558, 2492.9, B, dtype=np.float32)
+    wf = w.astype(float)
+    good = ~(((wf > 1320) & (wf < 1440)) | ((wf > 1770) & (wf < 1970)))
+    return w, good
+
+
+def synthetic_cube(H, W, B=285, seed=0):
+    rng = np.random.default_rng(seed)
+    w, _ = synthetic_wavelengths(B)
+    t = (w.astype(float) - 381.0) / (2493.0 - 381.0)
+    E = np.stack([0.08 + 0.35 * np.exp(-((t - 0.25) / 0.3) ** 2),
+                  0.05 + 0.45 * t * np.exp(-t * 1.5) * 2.0,
+                  0.30 - 0.2 * t + 0.05 * np.sin(6 * t)])
+    A = rng.random((H, W, 3))
+    A /= A.sum(axis=-1, keepdims=True)
+    R = A @ E + 0.005 * rng.standard_normal((H, W, B))
+    return np.clip(R, -0.01, 0.6).astype(np.float32)
+
+
+def synthetic_real_planes(pseudo, seed=1):
+    """y_b = clip(g_b * x_b^gamma_b + o_b + 0.01 N(0,1), 0, 1) on the same grid."""
+    rng = np.random.default_rng(seed)
+    nb = pseudo.shape[0]
+    g = 0.8 + 0.4 * rng.random(nb)
+    gam = 0.8 + 0.4 * rng.random(nb)
+    o = 0.02 * rng.random(nb)
+    x = np.clip(pseudo.astype(np.float64), 1e-6, None)
+    y = g[:, None, None] * x ** gam[:, None, None] + o[:, None, None] + 0.01 * rng.standard_normal(pseudo.shape)
+    return np.clip(y, 0, 1).astype(np.float32)

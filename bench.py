@@ -1,0 +1,156 @@
+#!/usr/bin/env python3
+"""Headline benchmark: fused EMIT->S2 spectral matching throughput in Mpixel*bands/s.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over one batch of synthetic input: per GPU one 1024x1024x285
+EMIT-like cube + matching real-S2 planes (BASELINE.json configs[2]; weak scaling: one tile per GPU,
+configs[3]/[4]) -> K1+K2 (SRF integration + Vandermonde moments, one pass over the cube) ->
+C1 (RCCL exchange, N>1) -> polynomial solve (degree 3, per band, all valid pixels) -> K3 (apply).
+Inputs are resident in HBM before the timed region.  value = N*H*W*285*K / t / 1e6.
+
+The JSON line also carries:
+  roofline     dominant kernel (K1+K2 fused): algorithmic bytes = H*W*285*4 per launch (the cube read
+               exactly once) / its average duration measured with HIP events on the
+               launch stream inside the timed region, against the 8 TB/s HBM3E peak.
+  cpu_baseline the oracle (NumPy restatement in the reference's operation order) timed on this box's
+               host cores on a bounded row-slab of the same workload (rank 0, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (ROOT, os.path.join(ROOT, "hyperspectral_super-resolution_amd")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+HBM_PEAK_GBS = 8000.0          # MI355X HBM3E vendor peak (MI355X_MICROARCH.md)
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--height", type=int, default=1024)
+    ap.add_argument("--width", type=int, default=1024)
+    ap.add_argument("--bands", type=int, default=285)
+    ap.add_argument("--deg", type=int, default=3)
+    ap.add_argument("--coeff-sync", default="allreduce", choices=["local", "allreduce", "broadcast"])
+    ap.add_argument("--cpu-rows", type=int, default=96, help="rows of the cube the CPU baseline processes")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-probe", action="store_true")
+    return ap.parse_args()
+
+
+def cpu_baseline(args):
+    """Oracle ('port' of the reference's NumPy path) on a bounded slab: rows x W x B, same generator."""
+    import numpy as np
+    from oracle import oracle_np as onp
+    rows = min(args.cpu_rows, args.height)
+    srf = onp.synthetic_srf()
+    w, good = onp.synthetic_wavelengths(args.bands)
+    R = onp.synthetic_cube(rows, args.width, args.bands, seed=0)
+    ps = onp.pseudo_s2_srf_integral(R[:4], w, srf, good)
+    names = [k for k, v in ps.items() if v is not None]
+    nb = len(names)
+    real = np.clip(np.random.default_rng(1).random((nb, rows, args.width)), 0.01, 1).astype(np.float32)
+    t0 = time.perf_counter()
+    onp.fuse_lsq_reference(R, w, srf, good, real, args.deg)
+    dt = time.perf_counter() - t0
+    return {"value": rows * args.width * args.bands / dt / 1e6, "unit": "Mpixel*bands/s", "cores": 1,
+            "kind": "port", "host_cores": os.cpu_count(),
+            "sample": f"{rows}x{args.width}x{args.bands} row slab of the same synthetic cube, SRF (13 float64 passes) + "
+                      f"deg-{args.deg} np.polyfit per band + np.polyval apply, single-thread NumPy, {dt:.1f} s"}
+
+
+def main():
+    args = parse_args()
+    import torch
+    import torch.distributed as dist
+    from s2_emit import SpectralFusion
+    from s2_emit import _engine as eng
+    from s2_emit.synthetic import device_problem
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=device)     # "nccl" is RCCL on ROCm
+
+    H, W, B = args.height, args.width, args.bands
+    prob = device_problem(H, W, B, deg=args.deg, seed=rank, device=device)
+    plan = SpectralFusion(prob.emit_w, prob.srf, prob.good_mask, deg=args.deg, min_valid=0.0, min_count=50,
+                          clip=True, device=device, group=None, coeff_sync=args.coeff_sync if world > 1 else "local")
+    real = prob.real.reshape(len(prob.names), -1)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        plan.step(prob.cube, real)
+    barrier()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        plan.step(prob.cube, real, k1_events=ev[i])
+    barrier()
+    dt = time.perf_counter() - t0
+
+    k1_ms = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)
+    tt = torch.tensor([dt], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    dt_max = float(tt.item())
+
+    if rank == 0:
+        npb = H * W * B
+        value = world * npb * args.steps / dt_max / 1e6
+        cube_bytes = npb * 4
+        achieved = cube_bytes / (k1_ms * 1e-3) / 1e9
+        roof = {"bound": "hbm", "kernel": "srf_kernel<deg,fast> (K1+K2 fused)", "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": None, "algorithmic_bytes": cube_bytes, "kernel_ms": round(k1_ms, 4),
+                "step_frac_of_peak": round(cube_bytes * args.steps / dt_max / 1e9 / HBM_PEAK_GBS, 4)}
+        tf = os.path.join(ROOT, "profiles", "traffic.json")
+        if os.path.isfile(tf):
+            try:
+                roof["traffic"] = json.load(open(tf)).get("srf_kernel_hbm_bytes_per_launch")
+            except Exception:
+                pass
+        if not args.no_probe:
+            roof["measured_read_peak"] = round(eng.probe_read_bandwidth(1 << 30, 10, device) / 1e9, 1)
+        line = {"metric": "Mpixel*bands/s fused (SRF + deg-%d per-band LSQ fit + apply)" % args.deg,
+                "value": round(value, 1), "unit": "Mpixel*bands/s", "n_gpus": world, "steps": args.steps,
+                "warmup": args.warmup, "ms_per_step": round(dt_max / args.steps * 1e3, 4),
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                "data": "synthetic",
+                "config": {"workload": f"{H}x{W}x{B} EMIT-like cube + {len(prob.names)} real-S2 planes per GPU, "
+                                       f"deg-{args.deg} per-band least squares over all valid pixels "
+                                       f"(BASELINE.json configs[2]; one tile per GPU for N>1)",
+                           "tiles_per_gpu": 1, "coeff_sync": args.coeff_sync if world > 1 else "none"},
+                "roofline": roof}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

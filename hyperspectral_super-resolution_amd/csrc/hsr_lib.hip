@@ -1,0 +1,64 @@
+// Library-level entry points of libhsr_mi355x: error state, sizing helpers, and a pure-read
+// bandwidth probe used by bench.py to put the HBM roofline of THIS box next to the vendor peak.
+#include <string.h>
+
+#include "hsr_common.h"
+
+namespace hsr {
+
+static thread_local char g_error[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_error, sizeof(g_error), fmt, ap);
+  va_end(ap);
+}
+
+// Streams `n16` 16-byte words once and folds them into one float per workgroup (kept so the loads
+// cannot be eliminated).  Same access shape as the cube stream of K1: 16 B per lane, coalesced.
+__global__ __launch_bounds__(256) void probe_read_kernel(const float4* __restrict__ src, int64_t n16,
+                                                         float* __restrict__ sink) {
+  float acc = 0.0f;
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  for (; i + 3 * stride < n16; i += 4 * stride) {
+    const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+    acc += (a.x + a.y + a.z + a.w) + (b.x + b.y + b.z + b.w) + (c.x + c.y + c.z + c.w) + (d.x + d.y + d.z + d.w);
+  }
+  for (; i < n16; i += stride) {
+    const float4 a = src[i];
+    acc += a.x + a.y + a.z + a.w;
+  }
+  acc += __shfl_xor(acc, 32, 64);
+  acc += __shfl_xor(acc, 16, 64);
+  acc += __shfl_xor(acc, 8, 64);
+  acc += __shfl_xor(acc, 4, 64);
+  acc += __shfl_xor(acc, 2, 64);
+  acc += __shfl_xor(acc, 1, 64);
+  if ((threadIdx.x & 63) == 0) atomicAdd(&sink[blockIdx.x & 63], acc);
+}
+
+}  // namespace hsr
+
+extern "C" int hsr_abi_version(void) { return HSR_ABI_VERSION; }
+
+extern "C" const char* hsr_last_error(void) { return hsr::g_error; }
+
+extern "C" int hsr_moment_count(int32_t deg) { return deg >= 1 && deg <= HSR_MAX_DEG ? hsr::moment_count(deg) : -1; }
+
+extern "C" int hsr_partial_slots(int64_t npix) { return hsr::partial_slots(npix); }
+
+extern "C" size_t hsr_partials_bytes(int32_t nb, int32_t deg) {
+  if (nb < 1 || nb > HSR_MAX_BANDS || deg < 1 || deg > HSR_MAX_DEG) return 0;
+  return (size_t)nb * hsr::moment_count(deg) * HSR_MAX_PARTIALS * sizeof(double);
+}
+
+extern "C" int hsr_probe_read(const void* buf_dev, int64_t bytes, float* sink_dev, hsr_stream_t stream) {
+  HSR_REQUIRE(buf_dev && sink_dev && bytes >= 16, HSR_ERR_INVALID, "hsr_probe_read: bad argument");
+  HSR_REQUIRE(((uintptr_t)buf_dev & 15) == 0, HSR_ERR_INVALID, "hsr_probe_read: buffer not 16-byte aligned");
+  hipLaunchKernelGGL(hsr::probe_read_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream,
+                     (const float4*)buf_dev, bytes / 16, sink_dev);
+  HSR_LAUNCH_CHECK("probe_read_kernel");
+  return HSR_OK;
+}

@@ -1,0 +1,456 @@
+// K2 (Vandermonde moments of materialised planes), the fixed-order slot reduction, the polynomial
+// solve (np.polyfit semantics from moments) and K3 (polynomial apply) on gfx950.
+//
+// Reference: fit step np.polyfit per channel (s2_emit/poly_regression.py:59-60; all-pixel flavour
+// Pairs_EMIT_S2_demo-2.ipynb cell 72), apply step apply_poly_rgb (poly_regression.py:65-84),
+// stretch expression s2_emit/color.py:33.  All three kernels are streaming / HBM-bound; the only
+// arithmetic of note is float64 (power sums, Horner), which the CDNA4 vector ALU does at half rate.
+#include <math.h>
+#include <string.h>
+
+#include "hsr_common.h"
+
+namespace hsr {
+
+// ------------------------------------------------------------------------------------------------
+// K2: moments of planes
+// ------------------------------------------------------------------------------------------------
+struct MomArgs {
+  const float* x;
+  int64_t x_stride;
+  const float* y;
+  int64_t y_stride;
+  const uint8_t* mask;
+  int64_t npix;
+  float min_x, min_y;
+  const double* lohi_x;
+  const double* lohi_y;
+  double* partials;
+  int32_t slots;
+};
+
+template <int DEG, typename T>
+__device__ __forceinline__ void moment_add(double (&acc)[moment_count(DEG)], T xf, T yf) {
+  const double xd = (double)xf, yd = (double)yf;
+  acc[0] += 1.0;
+  acc[2 * DEG + 1] += yd;
+  double pw = 1.0;
+#pragma unroll
+  for (int k = 1; k <= 2 * DEG; ++k) {
+    pw *= xd;
+    acc[k] += pw;
+    if (k <= DEG) acc[2 * DEG + 1 + k] += pw * yd;
+  }
+}
+
+template <int DEG>
+__global__ __launch_bounds__(256) void moments_kernel(const MomArgs a) {
+  constexpr int M = moment_count(DEG);
+  __shared__ double red[4][M];
+  const int b = blockIdx.y;
+  const float* x = a.x + (size_t)b * a.x_stride;
+  const float* y = a.y + (size_t)b * a.y_stride;
+  const bool sx = a.lohi_x != nullptr, sy = a.lohi_y != nullptr;
+  const double lox = sx ? a.lohi_x[2 * b] : 0.0, hix = sx ? a.lohi_x[2 * b + 1] : 0.0;
+  const double loy = sy ? a.lohi_y[2 * b] : 0.0, hiy = sy ? a.lohi_y[2 * b + 1] : 0.0;
+
+  double acc[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) acc[m] = 0.0;
+
+  // contiguous pixel range per slot: the summation tree depends on (npix, slots) only
+  const int64_t per = (a.npix + a.slots - 1) / a.slots;
+  const int64_t beg = (int64_t)blockIdx.x * per;
+  int64_t end = beg + per;
+  if (end > a.npix) end = a.npix;
+  for (int64_t p = beg + threadIdx.x; p < end; p += 256) {
+    float xv = x[p], yv = y[p];
+    const bool m = a.mask ? a.mask[p] != 0 : true;
+    const bool ok = m && finite_f32(xv) && finite_f32(yv) && xv > a.min_x && yv > a.min_y;
+    if (ok) {
+      if (sx) xv = stretch_f64(xv, lox, hix);
+      if (sy) yv = stretch_f64(yv, loy, hiy);
+      moment_add<DEG, float>(acc, xv, yv);
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    const double s = wave_sum(acc[m]);
+    if (lane == 0) red[wave][m] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < M) {
+    const int m = threadIdx.x;
+    const double s = ((red[0][m] + red[1][m]) + red[2][m]) + red[3][m];
+    a.partials[((size_t)b * M + m) * a.slots + blockIdx.x] = s;
+  }
+}
+
+// float64 sample columns (no mask, no stretch): the (X, Ybar) columns of fit_ot_poly_rgb
+template <int DEG>
+__global__ __launch_bounds__(256) void moments_f64_kernel(const double* __restrict__ xb, int64_t xs,
+                                                          const double* __restrict__ yb, int64_t ys, int64_t npix,
+                                                          double* __restrict__ partials, int slots) {
+  constexpr int M = moment_count(DEG);
+  __shared__ double red[4][M];
+  const int b = blockIdx.y;
+  const double* x = xb + (size_t)b * xs;
+  const double* y = yb + (size_t)b * ys;
+  double acc[M];
+#pragma unroll
+  for (int m = 0; m < M; ++m) acc[m] = 0.0;
+  const int64_t per = (npix + slots - 1) / slots;
+  const int64_t beg = (int64_t)blockIdx.x * per;
+  int64_t end = beg + per;
+  if (end > npix) end = npix;
+  for (int64_t p = beg + threadIdx.x; p < end; p += 256) {
+    const double xv = x[p], yv = y[p];
+    if (isfinite(xv) && isfinite(yv)) moment_add<DEG, double>(acc, xv, yv);
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int m = 0; m < M; ++m) {
+    const double s = wave_sum(acc[m]);
+    if (lane == 0) red[wave][m] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x < M) {
+    const int m = threadIdx.x;
+    partials[((size_t)b * M + m) * slots + blockIdx.x] = ((red[0][m] + red[1][m]) + red[2][m]) + red[3][m];
+  }
+}
+
+// one wave per (band, moment) row; lane-strided partial sums then the fixed butterfly
+__global__ __launch_bounds__(64) void reduce_kernel(const double* __restrict__ partials, int slots,
+                                                    double* __restrict__ moments) {
+  const double* row = partials + (size_t)blockIdx.x * slots;
+  double s = 0.0;
+  for (int i = threadIdx.x; i < slots; i += 64) s += row[i];
+  s = wave_sum(s);
+  if (threadIdx.x == 0) moments[blockIdx.x] = s;
+}
+
+// ------------------------------------------------------------------------------------------------
+// solve: np.polyfit from the moments
+// ------------------------------------------------------------------------------------------------
+// np.polyfit(x, y, deg): V = vander(x, deg+1) (highest power first), s_j = ||V[:,j]||, least squares
+// of (V/s) c' = y by SVD with rcond = len(x)*eps, c = c'/s.  From the moments:
+//   A_jk = S_{(d-j)+(d-k)} / (s_j s_k),  s_j = sqrt(S_{2(d-j)}),  rhs_j = T_{d-j} / s_j,
+// eigen-decompose A (cyclic Jacobi, <= 5x5) and apply the pseudo-inverse keeping the eigenvalues
+// above rcond^2 * max (singular values of V/s are the square roots).
+__host__ __device__ inline void solve_band(const double* mom, int deg, long long min_count, double* coef) {
+  const int n = deg + 1;
+  const double* S = mom;
+  const double* T = mom + 2 * deg + 1;
+  const double count = S[0];
+  if (!(count >= (double)min_count) || count < 1.0) {  // reference fallback: identity polynomial
+    for (int j = 0; j < n; ++j) coef[j] = 0.0;
+    coef[n - 2] = 1.0;
+    return;
+  }
+  double s[HSR_MAX_DEG + 1], A[HSR_MAX_DEG + 1][HSR_MAX_DEG + 1], V[HSR_MAX_DEG + 1][HSR_MAX_DEG + 1],
+      rhs[HSR_MAX_DEG + 1];
+  for (int j = 0; j < n; ++j) {
+    const double d = S[2 * (deg - j)];
+    s[j] = d > 0.0 ? sqrt(d) : 1.0;
+  }
+  for (int j = 0; j < n; ++j) {
+    rhs[j] = T[deg - j] / s[j];
+    for (int k = 0; k < n; ++k) {
+      A[j][k] = S[(deg - j) + (deg - k)] / (s[j] * s[k]);
+      V[j][k] = j == k ? 1.0 : 0.0;
+    }
+  }
+  for (int sweep = 0; sweep < 60; ++sweep) {
+    double off = 0.0;
+    for (int p = 0; p < n; ++p)
+      for (int q = p + 1; q < n; ++q) off += A[p][q] * A[p][q];
+    if (off < 1e-300) break;
+    for (int p = 0; p < n; ++p) {
+      for (int q = p + 1; q < n; ++q) {
+        const double apq = A[p][q];
+        if (fabs(apq) < 1e-300) continue;
+        const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
+        const double tt = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
+        const double c = 1.0 / sqrt(tt * tt + 1.0), sn = tt * c;
+        for (int k = 0; k < n; ++k) {
+          const double akp = A[k][p], akq = A[k][q];
+          A[k][p] = c * akp - sn * akq;
+          A[k][q] = sn * akp + c * akq;
+        }
+        for (int k = 0; k < n; ++k) {
+          const double apk = A[p][k], aqk = A[q][k];
+          A[p][k] = c * apk - sn * aqk;
+          A[q][k] = sn * apk + c * aqk;
+        }
+        for (int k = 0; k < n; ++k) {
+          const double vkp = V[k][p], vkq = V[k][q];
+          V[k][p] = c * vkp - sn * vkq;
+          V[k][q] = sn * vkp + c * vkq;
+        }
+      }
+    }
+  }
+  double lmax = 0.0;
+  for (int i = 0; i < n; ++i) lmax = A[i][i] > lmax ? A[i][i] : lmax;
+  const double rcond = count * 2.220446049250313e-16;
+  const double thresh = rcond * rcond * lmax;
+  for (int j = 0; j < n; ++j) coef[j] = 0.0;
+  for (int i = 0; i < n; ++i) {
+    const double lam = A[i][i];
+    if (!(lam > thresh)) continue;
+    double proj = 0.0;
+    for (int k = 0; k < n; ++k) proj += V[k][i] * rhs[k];
+    proj /= lam;
+    for (int j = 0; j < n; ++j) coef[j] += V[j][i] * proj;
+  }
+  for (int j = 0; j < n; ++j) coef[j] /= s[j];
+}
+
+__global__ __launch_bounds__(64) void solve_kernel(const double* __restrict__ moments, int nb, int deg,
+                                                   long long min_count, double* __restrict__ coeffs) {
+  const int b = threadIdx.x;
+  if (b < nb) solve_band(moments + (size_t)b * moment_count(deg), deg, min_count, coeffs + (size_t)b * (deg + 1));
+}
+
+// ------------------------------------------------------------------------------------------------
+// K3: polynomial apply
+// ------------------------------------------------------------------------------------------------
+struct ApplyArgs {
+  const float* x;
+  int64_t x_stride;
+  const uint8_t* mask;
+  const double* coeffs;
+  const double* lohi;
+  int32_t nb, deg, clip;
+  int64_t npix;
+  float* out;
+  int64_t out_stride;
+};
+
+// np.polyval: y = 0; for c in coeffs: y = y*x + c  -- separate multiply and add in float64 (no FMA
+// contraction) so the float32 store is bit-identical to the NumPy >= 2 result.
+__device__ __forceinline__ float poly_eval(float xf, const double* c, int n) {
+  const double x = (double)xf;
+  double y = 0.0;
+  for (int i = 0; i < n; ++i) y = __dadd_rn(__dmul_rn(y, x), c[i]);
+  return (float)y;
+}
+
+__device__ __forceinline__ float clip01(float v) { return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); }
+
+template <bool VEC4>
+__global__ __launch_bounds__(256) void apply_planar_kernel(const ApplyArgs a) {
+  const int b = blockIdx.y;
+  const int n = a.deg + 1;
+  const bool has_poly = a.coeffs != nullptr;
+  double c[HSR_MAX_APPLY_DEG + 1];
+  for (int i = 0; i < n; ++i) c[i] = has_poly ? a.coeffs[(size_t)b * n + i] : 0.0;
+  const bool st = a.lohi != nullptr;
+  const double lo = st ? a.lohi[2 * b] : 0.0, hi = st ? a.lohi[2 * b + 1] : 0.0;
+  const float* x = a.x + (size_t)b * a.x_stride;
+  float* o = a.out + (size_t)b * a.out_stride;
+  const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t nthreads = (int64_t)gridDim.x * 256;
+  if (VEC4) {
+    const int64_t nv = a.npix >> 2;
+    for (int64_t i = tid; i < nv; i += nthreads) {
+      float4 v = reinterpret_cast<const float4*>(x)[i];
+      uint32_t m = 0x01010101u;
+      if (a.mask) m = reinterpret_cast<const uint32_t*>(a.mask)[i];
+      float r[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float xv = r[j];
+        if (st) xv = stretch_f64(xv, lo, hi);
+        if (has_poly && ((m >> (8 * j)) & 0xffu)) xv = poly_eval(xv, c, n);
+        r[j] = a.clip ? clip01(xv) : xv;
+      }
+      reinterpret_cast<float4*>(o)[i] = make_float4(r[0], r[1], r[2], r[3]);
+    }
+    for (int64_t p = (nv << 2) + tid; p < a.npix; p += nthreads) {
+      float xv = x[p];
+      if (st) xv = stretch_f64(xv, lo, hi);
+      if (has_poly && (!a.mask || a.mask[p])) xv = poly_eval(xv, c, n);
+      o[p] = a.clip ? clip01(xv) : xv;
+    }
+  } else {
+    for (int64_t p = tid; p < a.npix; p += nthreads) {
+      float xv = x[p];
+      if (st) xv = stretch_f64(xv, lo, hi);
+      if (has_poly && (!a.mask || a.mask[p])) xv = poly_eval(xv, c, n);
+      o[p] = a.clip ? clip01(xv) : xv;
+    }
+  }
+}
+
+// (N, C) band-last images, the layout of the reference API (H, W, 3)
+__global__ __launch_bounds__(256) void apply_interleaved_kernel(const ApplyArgs a) {
+  __shared__ double cs[HSR_MAX_BANDS * (HSR_MAX_APPLY_DEG + 1)];
+  __shared__ double lh[HSR_MAX_BANDS * 2];
+  const int n = a.deg + 1;
+  const bool has_poly = a.coeffs != nullptr;
+  if (has_poly)
+    for (int i = threadIdx.x; i < a.nb * n; i += 256) cs[i] = a.coeffs[i];
+  const bool st = a.lohi != nullptr;
+  if (st)
+    for (int i = threadIdx.x; i < a.nb * 2; i += 256) lh[i] = a.lohi[i];
+  __syncthreads();
+  const int64_t total = a.npix * a.nb;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+    const int64_t p = e / a.nb;
+    const int ch = (int)(e - p * a.nb);
+    float xv = a.x[e];
+    if (st) xv = stretch_f64(xv, lh[2 * ch], lh[2 * ch + 1]);
+    if (has_poly && (!a.mask || a.mask[p])) xv = poly_eval(xv, cs + ch * n, n);
+    a.out[e] = a.clip ? clip01(xv) : xv;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// validity mask of the pipeline (poly_regression.py:106,118)
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void valid_mask_kernel(const float* x, int64_t xs, int nbx, int pos_band,
+                                                         const float* y, int64_t ys, int nby, const uint8_t* min,
+                                                         int64_t npix, uint8_t* mout) {
+  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (int64_t)gridDim.x * 256) {
+    bool ok = min ? min[p] != 0 : true;
+    for (int b = 0; b < nbx; ++b) ok = ok && finite_f32(x[b * xs + p]);
+    if (pos_band >= 0) ok = ok && x[pos_band * xs + p] > 0.0f;
+    if (y)
+      for (int b = 0; b < nby; ++b) ok = ok && finite_f32(y[b * ys + p]);
+    mout[p] = ok ? 1 : 0;
+  }
+}
+
+static inline int stream_grid(int64_t work_items, int per_block) {
+  int64_t g = (work_items + per_block - 1) / per_block;
+  if (g < 1) g = 1;
+  return (int)(g > 2048 ? 2048 : g);  // 256 CUs x 8 blocks, grid-stride beyond
+}
+
+}  // namespace hsr
+
+using namespace hsr;
+
+extern "C" int hsr_poly_moments(const float* x_dev, int64_t x_stride, const float* y_dev, int64_t y_stride,
+                                const uint8_t* mask_dev, int64_t npix, int32_t nb, int32_t deg, float min_x,
+                                float min_y, const double* lohi_x_dev, const double* lohi_y_dev,
+                                double* partials_dev, int32_t* slots_out, hsr_stream_t stream) {
+  HSR_REQUIRE(x_dev && y_dev && partials_dev, HSR_ERR_INVALID, "hsr_poly_moments: NULL pointer");
+  HSR_REQUIRE(npix > 0, HSR_ERR_INVALID, "hsr_poly_moments: npix must be > 0");
+  HSR_REQUIRE(nb >= 1 && nb <= HSR_MAX_BANDS, HSR_ERR_UNSUPPORTED, "hsr_poly_moments: nb=%d outside [1,%d]", nb,
+              HSR_MAX_BANDS);
+  HSR_REQUIRE(deg >= 1 && deg <= HSR_MAX_DEG, HSR_ERR_UNSUPPORTED, "hsr_poly_moments: deg=%d outside [1,%d]", deg,
+              HSR_MAX_DEG);
+  HSR_REQUIRE(x_stride >= npix && y_stride >= npix, HSR_ERR_INVALID, "hsr_poly_moments: stride < npix");
+  MomArgs a{x_dev, x_stride, y_dev, y_stride, mask_dev, npix, min_x, min_y, lohi_x_dev, lohi_y_dev, partials_dev,
+            partial_slots(npix)};
+  const dim3 grid(a.slots, nb), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  switch (deg) {
+    case 1: hipLaunchKernelGGL(moments_kernel<1>, grid, block, 0, s, a); break;
+    case 2: hipLaunchKernelGGL(moments_kernel<2>, grid, block, 0, s, a); break;
+    case 3: hipLaunchKernelGGL(moments_kernel<3>, grid, block, 0, s, a); break;
+    default: hipLaunchKernelGGL(moments_kernel<4>, grid, block, 0, s, a); break;
+  }
+  HSR_LAUNCH_CHECK("moments_kernel");
+  if (slots_out) *slots_out = a.slots;
+  return HSR_OK;
+}
+
+extern "C" int hsr_poly_moments_f64(const double* x_dev, int64_t x_stride, const double* y_dev, int64_t y_stride,
+                                    int64_t npix, int32_t nb, int32_t deg, double* partials_dev,
+                                    int32_t* slots_out, hsr_stream_t stream) {
+  HSR_REQUIRE(x_dev && y_dev && partials_dev, HSR_ERR_INVALID, "hsr_poly_moments_f64: NULL pointer");
+  HSR_REQUIRE(npix > 0 && x_stride >= npix && y_stride >= npix, HSR_ERR_INVALID, "hsr_poly_moments_f64: bad shape");
+  HSR_REQUIRE(nb >= 1 && nb <= HSR_MAX_BANDS && deg >= 1 && deg <= HSR_MAX_DEG, HSR_ERR_UNSUPPORTED,
+              "hsr_poly_moments_f64: nb=%d deg=%d", nb, deg);
+  const int slots = partial_slots(npix);
+  const dim3 grid(slots, nb), block(256);
+  hipStream_t s = (hipStream_t)stream;
+  switch (deg) {
+    case 1: hipLaunchKernelGGL(moments_f64_kernel<1>, grid, block, 0, s, x_dev, x_stride, y_dev, y_stride, npix, partials_dev, slots); break;
+    case 2: hipLaunchKernelGGL(moments_f64_kernel<2>, grid, block, 0, s, x_dev, x_stride, y_dev, y_stride, npix, partials_dev, slots); break;
+    case 3: hipLaunchKernelGGL(moments_f64_kernel<3>, grid, block, 0, s, x_dev, x_stride, y_dev, y_stride, npix, partials_dev, slots); break;
+    default: hipLaunchKernelGGL(moments_f64_kernel<4>, grid, block, 0, s, x_dev, x_stride, y_dev, y_stride, npix, partials_dev, slots); break;
+  }
+  HSR_LAUNCH_CHECK("moments_f64_kernel");
+  if (slots_out) *slots_out = slots;
+  return HSR_OK;
+}
+
+extern "C" int hsr_moments_reduce(const double* partials_dev, int32_t slots, int32_t nb, int32_t deg,
+                                  double* moments_dev, hsr_stream_t stream) {
+  HSR_REQUIRE(partials_dev && moments_dev, HSR_ERR_INVALID, "hsr_moments_reduce: NULL pointer");
+  HSR_REQUIRE(slots >= 1 && slots <= HSR_MAX_PARTIALS, HSR_ERR_INVALID, "hsr_moments_reduce: slots=%d", slots);
+  HSR_REQUIRE(nb >= 1 && nb <= HSR_MAX_BANDS && deg >= 1 && deg <= HSR_MAX_DEG, HSR_ERR_UNSUPPORTED,
+              "hsr_moments_reduce: nb=%d deg=%d", nb, deg);
+  hipLaunchKernelGGL(reduce_kernel, dim3(nb * moment_count(deg)), dim3(64), 0, (hipStream_t)stream, partials_dev,
+                     slots, moments_dev);
+  HSR_LAUNCH_CHECK("reduce_kernel");
+  return HSR_OK;
+}
+
+extern "C" int hsr_poly_solve(const double* moments_dev, int32_t nb, int32_t deg, int64_t min_count,
+                              double* coeffs_dev, hsr_stream_t stream) {
+  HSR_REQUIRE(moments_dev && coeffs_dev, HSR_ERR_INVALID, "hsr_poly_solve: NULL pointer");
+  HSR_REQUIRE(nb >= 1 && nb <= HSR_MAX_BANDS && deg >= 1 && deg <= HSR_MAX_DEG, HSR_ERR_UNSUPPORTED,
+              "hsr_poly_solve: nb=%d deg=%d", nb, deg);
+  hipLaunchKernelGGL(solve_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, moments_dev, nb, deg,
+                     (long long)min_count, coeffs_dev);
+  HSR_LAUNCH_CHECK("solve_kernel");
+  return HSR_OK;
+}
+
+extern "C" int hsr_poly_solve_host(const double* moments, int32_t nb, int32_t deg, int64_t min_count,
+                                   double* coeffs) {
+  HSR_REQUIRE(moments && coeffs, HSR_ERR_INVALID, "hsr_poly_solve_host: NULL pointer");
+  HSR_REQUIRE(nb >= 1 && deg >= 1 && deg <= HSR_MAX_DEG, HSR_ERR_UNSUPPORTED, "hsr_poly_solve_host: nb=%d deg=%d", nb,
+              deg);
+  for (int b = 0; b < nb; ++b)
+    solve_band(moments + (size_t)b * moment_count(deg), deg, (long long)min_count, coeffs + (size_t)b * (deg + 1));
+  return HSR_OK;
+}
+
+extern "C" int hsr_poly_apply(const float* x_dev, int64_t x_stride, const uint8_t* mask_dev,
+                              const double* coeffs_dev, int32_t nb, int32_t deg, int64_t npix,
+                              const double* lohi_dev, int32_t clip, int32_t layout, float* out_dev,
+                              int64_t out_stride, hsr_stream_t stream) {
+  HSR_REQUIRE(x_dev && out_dev, HSR_ERR_INVALID, "hsr_poly_apply: NULL pointer");
+  HSR_REQUIRE(npix >= 0, HSR_ERR_INVALID, "hsr_poly_apply: npix < 0");
+  HSR_REQUIRE(nb >= 1 && nb <= HSR_MAX_BANDS && deg >= 0 && deg <= HSR_MAX_APPLY_DEG, HSR_ERR_UNSUPPORTED,
+              "hsr_poly_apply: nb=%d deg=%d", nb, deg);
+  if (npix == 0) return HSR_OK;
+  ApplyArgs a{x_dev, x_stride, mask_dev, coeffs_dev, lohi_dev, nb, deg, clip, npix, out_dev, out_stride};
+  hipStream_t s = (hipStream_t)stream;
+  if (layout == HSR_LAYOUT_INTERLEAVED) {
+    hipLaunchKernelGGL(apply_interleaved_kernel, dim3(stream_grid(npix * nb, 256 * 4)), dim3(256), 0, s, a);
+    HSR_LAUNCH_CHECK("apply_interleaved_kernel");
+    return HSR_OK;
+  }
+  HSR_REQUIRE(layout == HSR_LAYOUT_PLANAR, HSR_ERR_INVALID, "hsr_poly_apply: layout=%d", layout);
+  HSR_REQUIRE(x_stride >= npix && out_stride >= npix, HSR_ERR_INVALID, "hsr_poly_apply: stride < npix");
+  const bool vec = (((uintptr_t)x_dev | (uintptr_t)out_dev) & 15) == 0 && (x_stride & 3) == 0 &&
+                   (out_stride & 3) == 0 && (((uintptr_t)mask_dev) & 3) == 0;
+  const dim3 grid(stream_grid(npix, 256 * 4), nb);
+  if (vec)
+    hipLaunchKernelGGL(apply_planar_kernel<true>, grid, dim3(256), 0, s, a);
+  else
+    hipLaunchKernelGGL(apply_planar_kernel<false>, grid, dim3(256), 0, s, a);
+  HSR_LAUNCH_CHECK("apply_planar_kernel");
+  return HSR_OK;
+}
+
+extern "C" int hsr_valid_mask(const float* x_dev, int64_t x_stride, int32_t nbx, int32_t pos_band,
+                              const float* y_dev, int64_t y_stride, int32_t nby, const uint8_t* mask_in_dev,
+                              int64_t npix, uint8_t* mask_out_dev, hsr_stream_t stream) {
+  HSR_REQUIRE(x_dev && mask_out_dev, HSR_ERR_INVALID, "hsr_valid_mask: NULL pointer");
+  HSR_REQUIRE(nbx >= 1 && pos_band < nbx && npix >= 0, HSR_ERR_INVALID, "hsr_valid_mask: bad shape");
+  if (npix == 0) return HSR_OK;
+  hipLaunchKernelGGL(valid_mask_kernel, dim3(stream_grid(npix, 256)), dim3(256), 0, (hipStream_t)stream, x_dev,
+                     x_stride, nbx, pos_band, y_dev, y_stride, y_dev ? nby : 0, mask_in_dev, npix, mask_out_dev);
+  HSR_LAUNCH_CHECK("valid_mask_kernel");
+  return HSR_OK;
+}

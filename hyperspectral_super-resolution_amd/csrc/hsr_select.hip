@@ -1,0 +1,259 @@
+// a4: exact masked percentiles on the device (np.percentile(vals[mask], [pmin, pmax]), method
+// 'linear'), the limits of apply_shared_percentile_stretch (reference s2_emit/color.py:31-32).
+//
+// Exact order statistics by a 3-pass MSD radix select on the monotone uint32 image of the float32
+// values (11 + 11 + 10 bits), all four ranks (prev/next of both percentiles) of all channels at
+// once, integer histograms only (LDS-privatised, then integer global atomics -> deterministic).
+// Each pass streams the planes once: 3 x 4 B per masked sample, ~4 % of the cube's bytes.
+// The final interpolation mirrors NumPy's _lerp bit for bit:
+//   d = float32(b - a);  t < 0.5 ? a + d*t : b - d*(1 - t)   (float64), NaN if any masked NaN.
+#include "hsr_common.h"
+
+namespace hsr {
+
+constexpr int kBins1 = 2048, kBins2 = 2048, kBins3 = 1024, kQ = 4;
+
+struct SelState {      // one per channel
+  uint32_t n;          // masked sample count
+  uint32_t nan_count;  // masked NaNs
+  uint32_t prefix[kQ]; // key prefix fixed so far, per rank query
+  uint32_t rem[kQ];    // rank remaining inside that prefix
+  double gamma[2];     // interpolation weights of (pmin, pmax)
+};
+
+struct SelArgs {
+  const float* x;
+  int64_t cs, ps;  // element (c, p) at c*cs + p*ps
+  const uint8_t* mask;
+  int64_t npix;
+  int32_t nb;
+  uint32_t* hist1;   // [nb][kBins1]
+  uint32_t* hist2;   // [nb][kQ][kBins2]
+  uint32_t* hist3;   // [nb][kQ][kBins3]
+  SelState* state;   // [nb]
+};
+
+__device__ __forceinline__ uint32_t f32_key(float v) {
+  const uint32_t u = __float_as_uint(v);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float key_f32(uint32_t k) {
+  return __uint_as_float((k & 0x80000000u) ? (k & 0x7fffffffu) : ~k);
+}
+
+template <int PASS>
+__global__ __launch_bounds__(256) void select_hist_kernel(const SelArgs a) {
+  constexpr int NB = PASS == 1 ? kBins1 : (PASS == 2 ? kBins2 * kQ : kBins3 * kQ);
+  __shared__ uint32_t h[NB];
+  __shared__ uint32_t nanc;
+  const int c = blockIdx.y;
+  for (int i = threadIdx.x; i < NB; i += 256) h[i] = 0u;
+  if (threadIdx.x == 0) nanc = 0u;
+  uint32_t pre[kQ];
+  if (PASS > 1) {
+#pragma unroll
+    for (int q = 0; q < kQ; ++q) pre[q] = a.state[c].prefix[q];
+  }
+  __syncthreads();
+  const float* x = a.x + (size_t)c * a.cs;
+  for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < a.npix; p += (int64_t)gridDim.x * 256) {
+    if (a.mask && a.mask[p] == 0) continue;
+    const float v = x[p * a.ps];
+    const uint32_t k = f32_key(v);
+    if (PASS == 1) {
+      atomicAdd(&h[k >> 21], 1u);
+      if (v != v) atomicAdd(&nanc, 1u);
+    } else if (PASS == 2) {
+#pragma unroll
+      for (int q = 0; q < kQ; ++q)
+        if ((k >> 21) == pre[q]) atomicAdd(&h[q * kBins2 + ((k >> 10) & 2047u)], 1u);
+    } else {
+#pragma unroll
+      for (int q = 0; q < kQ; ++q)
+        if ((k >> 10) == pre[q]) atomicAdd(&h[q * kBins3 + (k & 1023u)], 1u);
+    }
+  }
+  __syncthreads();
+  uint32_t* g = PASS == 1 ? a.hist1 + (size_t)c * kBins1
+                          : (PASS == 2 ? a.hist2 + (size_t)c * kQ * kBins2 : a.hist3 + (size_t)c * kQ * kBins3);
+  for (int i = threadIdx.x; i < NB; i += 256)
+    if (h[i]) atomicAdd(&g[i], h[i]);
+  if (PASS == 1 && threadIdx.x == 0 && nanc) atomicAdd(&a.state[c].nan_count, nanc);
+}
+
+// Locate, for one histogram of `nbins` (multiple of 256) bins, the bin holding 0-based rank r:
+// returns bin and the rank remaining inside it.  Whole 256-thread block cooperates.
+__device__ void block_locate(const uint32_t* hist, int nbins, uint32_t r, uint32_t* scratch /*[256]*/,
+                             uint32_t* out_bin, uint32_t* out_rem) {
+  const int per = nbins / 256;
+  const int t = threadIdx.x;
+  uint32_t local = 0;
+  for (int i = 0; i < per; ++i) local += hist[t * per + i];
+  scratch[t] = local;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {  // inclusive Hillis-Steele scan
+    const uint32_t add = t >= off ? scratch[t - off] : 0u;
+    __syncthreads();
+    scratch[t] += add;
+    __syncthreads();
+  }
+  const uint32_t incl = scratch[t];
+  uint32_t before = incl - local;
+  if (r >= before && r < incl) {  // exactly one thread
+    for (int i = 0; i < per; ++i) {
+      const uint32_t cnt = hist[t * per + i];
+      if (r < before + cnt) {
+        *out_bin = (uint32_t)(t * per + i);
+        *out_rem = r - before;
+        break;
+      }
+      before += cnt;
+    }
+  }
+  __syncthreads();
+}
+
+template <int PASS>
+__global__ __launch_bounds__(256) void select_scan_kernel(const SelArgs a, double qlo, double qhi, double* lohi) {
+  __shared__ uint32_t scratch[256];
+  __shared__ uint32_t bins[kQ], rems[kQ], ranks[kQ];
+  __shared__ uint32_t total;
+  const int c = blockIdx.x;
+  SelState* st = a.state + c;
+  if (PASS == 1) {
+    // total masked count, then the four ranks NumPy would index
+    uint32_t local = 0;
+    for (int i = threadIdx.x; i < kBins1; i += 256) local += a.hist1[(size_t)c * kBins1 + i];
+    scratch[threadIdx.x] = local;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      uint32_t n = 0;
+      for (int i = 0; i < 256; ++i) n += scratch[i];
+      total = n;
+      st->n = n;
+      const double q[2] = {qlo, qhi};
+      for (int j = 0; j < 2; ++j) {
+        uint32_t prev = 0, next = 0;
+        double g = 0.0;
+        if (n > 0) {
+          const double vi = (double)(n - 1) * q[j];  // (n - 1) * quantile
+          if (vi >= (double)(n - 1)) {
+            prev = next = n - 1;
+            g = vi - floor(vi);
+          } else if (vi < 0.0) {
+            prev = next = 0;
+            g = vi - floor(vi);
+          } else {
+            const double f = floor(vi);
+            prev = (uint32_t)f;
+            next = prev + 1;
+            g = vi - f;
+          }
+        }
+        ranks[2 * j] = prev;
+        ranks[2 * j + 1] = next;
+        st->gamma[j] = g;
+      }
+    }
+    __syncthreads();
+    if (total == 0) return;
+    for (int q = 0; q < kQ; ++q) {
+      block_locate(a.hist1 + (size_t)c * kBins1, kBins1, ranks[q], scratch, &bins[q], &rems[q]);
+      if (threadIdx.x == 0) {
+        st->prefix[q] = bins[q];
+        st->rem[q] = rems[q];
+      }
+      __syncthreads();
+    }
+  } else {
+    if (st->n == 0) {
+      if (PASS == 3 && threadIdx.x == 0) lohi[2 * c] = lohi[2 * c + 1] = __longlong_as_double(0x7ff8000000000000LL);
+      return;
+    }
+    constexpr int NBINS = PASS == 2 ? kBins2 : kBins3;
+    constexpr int SHIFT = PASS == 2 ? 11 : 10;
+    const uint32_t* hist = PASS == 2 ? a.hist2 + (size_t)c * kQ * kBins2 : a.hist3 + (size_t)c * kQ * kBins3;
+    for (int q = 0; q < kQ; ++q) {
+      block_locate(hist + (size_t)q * NBINS, NBINS, st->rem[q], scratch, &bins[q], &rems[q]);
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      for (int q = 0; q < kQ; ++q) {
+        st->prefix[q] = (st->prefix[q] << SHIFT) | bins[q];
+        st->rem[q] = rems[q];
+      }
+      if (PASS == 3) {
+        for (int j = 0; j < 2; ++j) {
+          const float va = key_f32(st->prefix[2 * j]), vb = key_f32(st->prefix[2 * j + 1]);
+          const double t = st->gamma[j];
+          const float d = vb - va;  // NumPy subtracts in the array dtype (float32)
+          double r = t >= 0.5 ? (double)vb - (double)d * (1.0 - t) : (double)va + (double)d * t;
+          if (st->nan_count) r = __longlong_as_double(0x7ff8000000000000LL);
+          lohi[2 * c + j] = r;
+        }
+      }
+    }
+  }
+}
+
+static size_t hist1_bytes(int nb) { return (size_t)nb * kBins1 * 4; }
+static size_t hist2_bytes(int nb) { return (size_t)nb * kQ * kBins2 * 4; }
+static size_t hist3_bytes(int nb) { return (size_t)nb * kQ * kBins3 * 4; }
+static size_t state_bytes(int nb) { return (size_t)nb * sizeof(SelState); }
+
+}  // namespace hsr
+
+using namespace hsr;
+
+extern "C" size_t hsr_percentile_work_bytes(int32_t nb) {
+  if (nb < 1) nb = 1;
+  return hist1_bytes(nb) + hist2_bytes(nb) + hist3_bytes(nb) + state_bytes(nb) + 64;
+}
+
+extern "C" int hsr_percentile_limits(const float* x_dev, int64_t x_stride, int32_t layout,
+                                     const uint8_t* mask_dev, int64_t npix, int32_t nb, double pmin, double pmax,
+                                     void* work_dev, double* lohi_dev, hsr_stream_t stream) {
+  HSR_REQUIRE(x_dev && work_dev && lohi_dev, HSR_ERR_INVALID, "hsr_percentile_limits: NULL pointer");
+  HSR_REQUIRE(nb >= 1 && nb <= HSR_MAX_BANDS, HSR_ERR_UNSUPPORTED, "hsr_percentile_limits: nb=%d", nb);
+  HSR_REQUIRE(npix >= 1 && npix < ((int64_t)1 << 31), HSR_ERR_UNSUPPORTED, "hsr_percentile_limits: npix=%lld",
+              (long long)npix);
+  HSR_REQUIRE(pmin >= 0.0 && pmin <= 100.0 && pmax >= 0.0 && pmax <= 100.0, HSR_ERR_INVALID,
+              "hsr_percentile_limits: percentiles must be in the range [0, 100]");
+  HSR_REQUIRE(((uintptr_t)work_dev & 7) == 0, HSR_ERR_INVALID, "hsr_percentile_limits: workspace not 8-byte aligned");
+  hipStream_t s = (hipStream_t)stream;
+  SelArgs a{};
+  a.x = x_dev;
+  if (layout == HSR_LAYOUT_INTERLEAVED) {
+    a.cs = 1;
+    a.ps = nb;
+  } else {
+    HSR_REQUIRE(layout == HSR_LAYOUT_PLANAR && x_stride >= npix, HSR_ERR_INVALID, "hsr_percentile_limits: layout/stride");
+    a.cs = x_stride;
+    a.ps = 1;
+  }
+  a.mask = mask_dev;
+  a.npix = npix;
+  a.nb = nb;
+  unsigned char* w = (unsigned char*)work_dev;
+  a.state = (SelState*)w;
+  w += (state_bytes(nb) + 7) & ~(size_t)7;
+  a.hist1 = (uint32_t*)w;
+  w += hist1_bytes(nb);
+  a.hist2 = (uint32_t*)w;
+  w += hist2_bytes(nb);
+  a.hist3 = (uint32_t*)w;
+  int rc = check_hip(hipMemsetAsync(work_dev, 0, hsr_percentile_work_bytes(nb), s), "hipMemsetAsync");
+  if (rc != HSR_OK) return rc;
+  int64_t gx = (npix + 256 * 8 - 1) / (256 * 8);
+  if (gx > 1024) gx = 1024;
+  const dim3 grid((unsigned)gx, nb), block(256);
+  const double qlo = pmin / 100.0, qhi = pmax / 100.0;
+  hipLaunchKernelGGL(select_hist_kernel<1>, grid, block, 0, s, a);
+  hipLaunchKernelGGL(select_scan_kernel<1>, dim3(nb), block, 0, s, a, qlo, qhi, lohi_dev);
+  hipLaunchKernelGGL(select_hist_kernel<2>, grid, block, 0, s, a);
+  hipLaunchKernelGGL(select_scan_kernel<2>, dim3(nb), block, 0, s, a, qlo, qhi, lohi_dev);
+  hipLaunchKernelGGL(select_hist_kernel<3>, grid, block, 0, s, a);
+  hipLaunchKernelGGL(select_scan_kernel<3>, dim3(nb), block, 0, s, a, qlo, qhi, lohi_dev);
+  HSR_LAUNCH_CHECK("select kernels");
+  return HSR_OK;
+}

@@ -1,0 +1,41 @@
+"""s2_emit on MI355X: drop-in for the reference package ``s2_emit`` (same names, same signatures).
+
+The hot path - SRF band integration, percentile stretch, per-band polynomial fit and apply - runs as
+hand-written HIP kernels for gfx950 behind a C ABI (include/hsr.h, csrc/*.hip -> lib/libhsr_mi355x.so).
+Importing the package needs neither the GPU nor the extension; calling a compute function without
+them raises ``HsrUnavailable`` (no CPU fallback).
+"""
+from .srf import load_s2_srf_from_xlsx, S2_BANDS_13, DEFAULT_SRF_XLSX_URL
+from .emit_io import load_emit_envi_rfl, load_emit_wavelengths_from_nc
+from .synth import pseudo_s2_srf_integral, pseudo_s2_rgb
+from .viz import show_side_by_side, resize_s2_rgb_to, load_s2_rgb_u8
+from .color import (
+    robust_norm, robust_norm_rgb, apply_shared_percentile_stretch,
+    histogram_match_rgb, ot_match_rgb_sinkhorn_pot
+)
+from .poly_regression import fit_ot_poly_rgb, apply_poly_rgb
+from .fusion import SpectralFusion, fuse_pair, calibrate_pseudo_to_real_linear
+from ._native import HsrUnavailable, HsrError
+
+# the reference's __all__ (s2_emit/__init__.py:10-24), verbatim order ...
+__all__ = [
+    "load_s2_srf_from_xlsx",
+    "load_emit_envi_rfl",
+    "load_emit_wavelengths_from_nc",
+    "pseudo_s2_srf_integral",
+    "pseudo_s2_rgb",
+    "show_side_by_side",
+    "resize_s2_rgb_to",
+    "robust_norm",
+    "robust_norm_rgb",
+    "apply_shared_percentile_stretch",
+    "histogram_match_rgb",
+    "ot_match_rgb_sinkhorn_pot",
+    "load_s2_rgb_u8",
+    # ... plus the two functions callers copy out of poly_regression.py, and the fused pipeline
+    "fit_ot_poly_rgb",
+    "apply_poly_rgb",
+    "SpectralFusion",
+    "fuse_pair",
+    "calibrate_pseudo_to_real_linear",
+]

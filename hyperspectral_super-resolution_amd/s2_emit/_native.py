@@ -1,0 +1,105 @@
+"""ctypes binding of libhsr_mi355x.so (C ABI: include/hsr.h).
+
+The HIP library is the product path.  There is deliberately NO CPU fallback: if the shared
+library is missing, or no MI355X-class device is visible, every compute entry point raises
+``HsrUnavailable`` loudly instead of silently computing something else.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_DEFAULT_SO = os.path.join(os.path.dirname(_HERE), "lib", "libhsr_mi355x.so")
+
+HSR_OK = 0
+HSR_MAX_BANDS = 16
+HSR_MAX_DEG = 4
+HSR_MAX_APPLY_DEG = 8
+HSR_MAX_SPECTRAL = 560
+HSR_TILE_PIXELS = 64
+HSR_MAX_PARTIALS = 2048
+LAYOUT_PLANAR = 0
+LAYOUT_INTERLEAVED = 1
+
+
+class HsrUnavailable(RuntimeError):
+    """The HIP extension (or a GPU to run it on) is not available."""
+
+
+class HsrError(RuntimeError):
+    """A library call returned an error code."""
+
+
+_i32, _i64, _f32, _f64, _vp = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_void_p
+_pi32 = C.POINTER(C.c_int32)
+
+# name -> (restype, argtypes); must list every symbol include/hsr.h declares
+SIGNATURES = {
+    "hsr_abi_version": (C.c_int, []),
+    "hsr_last_error": (C.c_char_p, []),
+    "hsr_moment_count": (C.c_int, [_i32]),
+    "hsr_partial_slots": (C.c_int, [_i64]),
+    "hsr_partials_bytes": (C.c_size_t, [_i32, _i32]),
+    "hsr_srf_integrate": (C.c_int, [_vp, _i64, _i32, _vp, _pi32, _pi32, _i32, _vp, _i64, _vp]),
+    "hsr_srf_integrate_moments": (C.c_int, [_vp, _i64, _i32, _vp, _pi32, _pi32, _i32, _vp, _i64,
+                                            _vp, _i64, _vp, _f32, _f32, _i32, _vp, _pi32, _vp]),
+    "hsr_poly_moments": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _f32, _f32, _vp, _vp,
+                                   _vp, _pi32, _vp]),
+    "hsr_poly_moments_f64": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _pi32, _vp]),
+    "hsr_moments_reduce": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp]),
+    "hsr_poly_solve": (C.c_int, [_vp, _i32, _i32, _i64, _vp, _vp]),
+    "hsr_poly_solve_host": (C.c_int, [C.POINTER(_f64), _i32, _i32, _i64, C.POINTER(_f64)]),
+    "hsr_poly_apply": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _i32, _i64, _vp, _i32, _i32, _vp, _i64, _vp]),
+    "hsr_percentile_work_bytes": (C.c_size_t, [_i32]),
+    "hsr_percentile_limits": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _f64, _f64, _vp, _vp, _vp]),
+    "hsr_valid_mask": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _i32, _vp, _i64, _vp, _vp]),
+    "hsr_probe_read": (C.c_int, [_vp, _i64, _vp, _vp]),
+}
+
+_lib: Optional[C.CDLL] = None
+_lib_path: Optional[str] = None
+
+
+def library_path() -> str:
+    return os.environ.get("HSR_LIBRARY", _DEFAULT_SO)
+
+
+def load() -> C.CDLL:
+    """Load the shared library (once) and type every entry point."""
+    global _lib, _lib_path
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.isfile(path):
+        raise HsrUnavailable(
+            f"HIP extension not built: {path} is missing. Build it with "
+            f"`make -C hyperspectral_super-resolution_amd/csrc` (or __graft_entry__.build()). "
+            f"There is no CPU fallback for the s2_emit hot path.")
+    try:
+        lib = C.CDLL(path)
+    except OSError as e:  # e.g. libamdhip64 not resolvable
+        raise HsrUnavailable(f"cannot load {path}: {e}") from e
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib, _lib_path = lib, path
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != HSR_OK:
+        msg = load().hsr_last_error().decode("utf-8", "replace")
+        raise HsrError(f"{what or 'libhsr'} failed (code {rc}): {msg}")
+
+
+def require_gpu():
+    """torch is the device-memory / stream plumbing; a real GPU is mandatory for compute."""
+    import torch
+    if not torch.cuda.is_available():
+        raise HsrUnavailable("no ROCm device visible (torch.cuda.is_available() is False); "
+                             "the s2_emit hot path runs only on the GPU - there is no CPU fallback.")
+    load()
+    return torch

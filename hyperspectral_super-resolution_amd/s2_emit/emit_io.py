@@ -1,0 +1,64 @@
+"""EMIT file loaders.  Mirrors reference ``s2_emit/emit_io.py`` (signatures and return types).
+
+File I/O is outside the accelerated path; these feed K1.  The ENVI
+loader is self-contained (header parse + numpy.memmap, BSQ/BIL/BIP -> (H, W, B)) so it works
+without the ``spectral`` package; the netCDF reader needs h5py, imported lazily.
+"""
+from __future__ import annotations
+
+import re
+from typing import Optional, Tuple
+
+import numpy as np
+
+_ENVI_DTYPES = {1: np.uint8, 2: np.int16, 3: np.int32, 4: np.float32, 5: np.float64,
+                12: np.uint16, 13: np.uint32, 14: np.int64, 15: np.uint64}
+
+
+def _parse_envi_header(hdr_path: str) -> dict:
+    text = open(hdr_path, "r", errors="replace").read()
+    fields = {}
+    for m in re.finditer(r"^\s*([^=\n]+?)\s*=\s*(\{.*?\}|[^\n]*)", text, flags=re.S | re.M):
+        fields[m.group(1).strip().lower()] = m.group(2).strip()
+    return fields
+
+
+def load_emit_envi_rfl(hdr_path: str, bin_path: str, as_float32: bool = True) -> np.ndarray:
+    """
+    Loads EMIT reflectance ENVI pair into memory.
+    Returns R: (H, W, B)
+    """
+    h = _parse_envi_header(hdr_path)
+    lines, samples, bands = int(h["lines"]), int(h["samples"]), int(h["bands"])
+    dtype = np.dtype(_ENVI_DTYPES[int(h.get("data type", 4))])
+    dtype = dtype.newbyteorder(">" if int(h.get("byte order", 0)) == 1 else "<")
+    offset = int(h.get("header offset", 0))
+    interleave = h.get("interleave", "bsq").lower()
+    raw = np.memmap(bin_path, dtype=dtype, mode="r", offset=offset)
+    if interleave == "bip":
+        R = raw[: lines * samples * bands].reshape(lines, samples, bands)
+    elif interleave == "bil":
+        R = raw[: lines * samples * bands].reshape(lines, bands, samples).transpose(0, 2, 1)
+    else:
+        R = raw[: lines * samples * bands].reshape(bands, lines, samples).transpose(1, 2, 0)
+    R = np.ascontiguousarray(R)
+    if as_float32:
+        R = R.astype(np.float32, copy=False)
+    return R
+
+
+def load_emit_wavelengths_from_nc(
+    nc_path: str,
+    wavelengths_key: str = "sensor_band_parameters/wavelengths",
+    good_key: str = "sensor_band_parameters/good_wavelengths",
+) -> Tuple[np.ndarray, Optional[np.ndarray]]:
+    """
+    Returns (emit_wavelengths_nm, good_mask_bool_or_None)
+    """
+    import h5py
+    with h5py.File(nc_path, "r") as f:
+        emit_w = f[wavelengths_key][:].astype(np.float32)
+        good_mask = None
+        if good_key in f:
+            good_mask = f[good_key][:].astype(bool)
+    return emit_w, good_mask

@@ -1,0 +1,154 @@
+"""The fused EMIT -> Sentinel-2 spectral matching pipeline, device resident.
+
+This is the build's counterpart of the reference driver (s2_emit/poly_regression.py:96-139 ==
+Pairs_EMIT_S2_demo-2.ipynb cell 81) for a grid-aligned pair, in its "per-band least squares"
+flavour (calibrate_pseudo_to_real_linear, notebook cell 72, degree generalised):
+
+    phase 1  K1+K2  one pass over the (H,W,B) cube: pseudo-S2 planes + Vandermonde moments
+    phase 2  C1     (multi-GPU) RCCL exchange of the tiny moment / coefficient vectors
+    phase 3  solve  np.polyfit from the moments, on the device (no host round trip)
+    phase 4  K3     polynomial apply (+ optional mask, clip) -> matched planes
+
+Everything is stream ordered; nothing synchronises with the host.  One process per GPU; with a
+torch.distributed group (backend "nccl" = RCCL over xGMI on ROCm, "gloo" in CPU tests) every
+rank owns whole spatial tiles and only (nb x (3deg+2)) doubles cross the fabric per step.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _engine as eng
+from . import _native as nat
+
+COEFF_SYNC_MODES = ("local", "allreduce", "broadcast")
+
+
+@dataclass
+class FusionOutput:
+    names: List[str]           # supported bands, srf_dict order
+    pseudo: object             # (nb, H*W) float32 device tensor - pseudo-S2 planes (K1)
+    moments: object            # (nb, 3deg+2) float64 device tensor (after the exchange, if any)
+    coeffs: object             # (nb, deg+1) float64 device tensor, highest power first
+    matched: object            # (nb, H*W) float32 device tensor (K3)
+
+
+def exchange_moments(moments, coeffs_solver, group=None, mode: str = "allreduce"):
+    """C1: make every rank fit the same polynomial.  ``moments`` (nb, M) float64 tensor (CPU tensor
+    with gloo, GPU tensor with RCCL); ``coeffs_solver(moments) -> coeffs`` tensor on the same device.
+
+    mode "local"     : no exchange - independent coefficients per tile (what the reference's own
+                       tiling does, tiles_helpers/utils.py:223-305)
+    mode "allreduce" : one all-reduce(sum) of the moments, every rank solves redundantly; the
+                       result is bit-identical on all ranks because they solve identical inputs
+    mode "broadcast" : reduce(sum) to rank 0, rank 0 solves, broadcast of the fitted coefficients
+    """
+    import torch.distributed as dist
+    if mode not in COEFF_SYNC_MODES:
+        raise ValueError(f"mode must be one of {COEFF_SYNC_MODES}, got {mode!r}")
+    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
+    if mode == "local" or world == 1:
+        return moments, coeffs_solver(moments)
+    if mode == "allreduce":
+        dist.all_reduce(moments, op=dist.ReduceOp.SUM, group=group)
+        return moments, coeffs_solver(moments)
+    root = dist.get_global_rank(group, 0) if group is not None else 0
+    dist.reduce(moments, dst=root, op=dist.ReduceOp.SUM, group=group)
+    coeffs = coeffs_solver(moments)          # only rank 0's is meaningful; shape is what matters
+    dist.broadcast(coeffs, src=root, group=group)
+    return moments, coeffs
+
+
+class SpectralFusion:
+    """Plan object: SRF weight table + workspaces on one GPU, reused across tiles/steps."""
+
+    def __init__(self, emit_w, srf_dict, good_mask=None, deg: int = 3, min_valid: Optional[float] = 0.0,
+                 min_count: int = 50, clip: bool = True, apply_mask: bool = False, device=None,
+                 group=None, coeff_sync: str = "allreduce"):
+        torch = nat.require_gpu()
+        if not 1 <= deg <= nat.HSR_MAX_DEG:
+            raise ValueError(f"deg must be in [1, {nat.HSR_MAX_DEG}], got {deg}")
+        if coeff_sync not in COEFF_SYNC_MODES:
+            raise ValueError(f"coeff_sync must be one of {COEFF_SYNC_MODES}")
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self.table = eng.build_srf_table(emit_w, srf_dict, good_mask)
+        if self.table.nb == 0:
+            raise ValueError("no band of srf_dict has support on the (masked) EMIT wavelength grid")
+        if self.table.nb > nat.HSR_MAX_BANDS:
+            raise ValueError(f"at most {nat.HSR_MAX_BANDS} supported bands per fusion plan")
+        self.deg, self.min_count, self.clip, self.apply_mask = deg, int(min_count), bool(clip), bool(apply_mask)
+        self.min_valid = float("-inf") if min_valid is None else float(min_valid)
+        self.group, self.coeff_sync = group, coeff_sync
+        self.ws = eng.MomentWorkspace(self.device, self.table.nb, deg)
+        self.table.device_weights(self.device)
+        self._buf: Dict[int, Tuple[object, object]] = {}
+
+    @property
+    def names(self) -> List[str]:
+        return list(self.table.supported)
+
+    def _buffers(self, npix: int):
+        torch = nat.require_gpu()
+        if npix not in self._buf:
+            nb = self.table.nb
+            self._buf[npix] = (torch.empty((nb, npix), dtype=torch.float32, device=self.device),
+                               torch.empty((nb, npix), dtype=torch.float32, device=self.device))
+        return self._buf[npix]
+
+    def _solve(self, moments):
+        return eng.poly_solve(moments, self.deg, self.min_count, out=self.ws.coeffs)
+
+    def step(self, cube, real_planes, mask=None, reuse_buffers: bool = True, k1_events=None) -> FusionOutput:
+        """One pass of the hot path over one tile.
+        cube (H,W,B) or (npix,B) float32 GPU tensor; real_planes (nb,H,W)/(nb,npix) float32;
+        mask optional uint8 (npix) validity (1 = use)."""
+        torch = nat.require_gpu()
+        npix = cube.numel() // cube.shape[-1]
+        if reuse_buffers:
+            pseudo, matched = self._buffers(npix)
+        else:
+            pseudo = matched = None
+        pseudo, moments = eng.srf_integrate_moments(cube, self.table, real_planes, self.deg, self.ws, mask,
+                                                    self.min_valid, self.min_valid, out=pseudo, events=k1_events)
+        moments, coeffs = exchange_moments(moments, self._solve, self.group, self.coeff_sync)
+        matched = eng.poly_apply(pseudo, coeffs, mask if self.apply_mask else None, None, self.clip,
+                                 nat.LAYOUT_PLANAR, out=matched)
+        return FusionOutput(self.names, pseudo, moments, coeffs, matched)
+
+
+def fuse_pair(R, emit_w, srf_dict, good_mask, real_s2: Dict[str, np.ndarray], deg: int = 3,
+              min_valid: Optional[float] = 0.0, min_count: int = 50, clip: bool = True):
+    """NumPy convenience wrapper: one EMIT cube + real S2 planes (dict band -> (H,W)) on the same
+    grid -> (pseudo dict, coeffs dict, matched dict), all host arrays.  Bands without SRF support map
+    to None like pseudo_s2_srf_integral."""
+    torch = nat.require_gpu()
+    plan = SpectralFusion(emit_w, srf_dict, good_mask, deg, min_valid, min_count, clip)
+    H, W = R.shape[:2]
+    cube = torch.from_numpy(np.ascontiguousarray(R, dtype=np.float32)).to(plan.device)
+    real = torch.from_numpy(np.stack([np.asarray(real_s2[b], dtype=np.float32) for b in plan.names])).to(plan.device)
+    out = plan.step(cube, real.reshape(len(plan.names), -1), reuse_buffers=False)
+    ps, co, ma = out.pseudo.cpu().numpy(), out.coeffs.cpu().numpy(), out.matched.cpu().numpy()
+    pseudo = {b: None for b in plan.table.names}
+    coeffs = {b: None for b in plan.table.names}
+    matched = {b: None for b in plan.table.names}
+    for i, b in enumerate(plan.names):
+        pseudo[b], coeffs[b], matched[b] = ps[i].reshape(H, W), co[i], ma[i].reshape(H, W)
+    return pseudo, coeffs, matched
+
+
+def calibrate_pseudo_to_real_linear(pseudo_stack, real_stack, valid_mask, min_valid=0.0):
+    """Per-band linear least squares over all valid pixels (Pairs_EMIT_S2_demo-2.ipynb cell 72):
+    returns (corrected (nb,H,W) float32, [(a, b)] * nb).  NumPy in / NumPy out, computed on the GPU."""
+    torch = nat.require_gpu()
+    nb, H, W = pseudo_stack.shape
+    x = torch.from_numpy(np.ascontiguousarray(pseudo_stack, dtype=np.float32)).cuda().reshape(nb, -1)
+    y = torch.from_numpy(np.ascontiguousarray(real_stack, dtype=np.float32)).cuda().reshape(nb, -1)
+    m = torch.from_numpy(np.ascontiguousarray(valid_mask, dtype=np.bool_).view(np.uint8)).cuda().reshape(-1)
+    ws = eng.MomentWorkspace(x.device, nb, 1)
+    mom = eng.poly_moments(x, y, 1, ws, m, float(min_valid), float(min_valid))
+    coeffs = eng.poly_solve(mom, 1, 50)
+    corrected = eng.poly_apply(x, coeffs, None, None, clip=False)
+    params = [(float(a), float(b)) for a, b in coeffs.cpu().numpy()]
+    return corrected.reshape(nb, H, W).cpu().numpy(), params

@@ -1,0 +1,163 @@
+/* hsr.h - C ABI of libhsr_mi355x.so: the EMIT -> Sentinel-2 spectral-fusion hot path on MI355X (gfx950).
+ *
+ * The reference (martasumyk/hyperspectral_super-resolution) is pure Python/NumPy and has no FFI
+ * layer; its boundary for this path is the plain function API of `s2_emit` (s2_emit/__init__.py:1-24,
+ * s2_emit/poly_regression.py:16-84).  Each entry point below names the reference code it replaces.
+ * The Python package `s2_emit` of this repository binds these symbols with ctypes (see
+ * INTEGRATION.md for the stub a maintainer of the reference would add).
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no C++/torch types.  `*_dev` pointers are device (HBM) addresses
+ *     owned by the caller; the library never allocates or frees on a launch path, never
+ *     synchronises the device, and is safe to capture in a hipGraph.
+ *   - every call is stream ordered on `stream` (a hipStream_t passed as void*; NULL = default).
+ *   - return value: HSR_OK or an error code; hsr_last_error() gives the thread-local message.
+ *   - planes are band-major: plane b of pixel p lives at base[b * plane_stride + p].
+ *   - moments of band b for degree d: M = 3d+2 doubles, [S_0..S_2d | T_0..T_d] with
+ *     S_k = sum x^k, T_j = sum x^j y over the valid pixels (S_0 = count).
+ */
+#ifndef HSR_H_
+#define HSR_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HSR_ABI_VERSION 1
+
+#define HSR_OK 0
+#define HSR_ERR_INVALID 1      /* bad argument (shape, alignment, NULL)            */
+#define HSR_ERR_UNSUPPORTED 2  /* outside what the kernels are built for           */
+#define HSR_ERR_HIP 3          /* HIP runtime / launch failure                     */
+
+#define HSR_MAX_BANDS 16       /* output bands per call (S2 has 13)                */
+#define HSR_MAX_DEG 4          /* polynomial degree of a FIT (reference uses 1, 2, 4) */
+#define HSR_MAX_APPLY_DEG 8    /* polynomial degree K3 can evaluate                  */
+#define HSR_MAX_SPECTRAL 560   /* input bands B per pixel (EMIT: 285)              */
+#define HSR_TILE_PIXELS 64     /* pixels staged per LDS tile                       */
+#define HSR_MAX_PARTIALS 2048  /* upper bound of per-launch partial-sum slots      */
+
+#define HSR_LAYOUT_PLANAR 0      /* (C, N): element (c, p) at c*stride + p         */
+#define HSR_LAYOUT_INTERLEAVED 1 /* (N, C): element (c, p) at p*C + c   (H,W,3)    */
+
+typedef void* hsr_stream_t;
+
+/* ---- library ------------------------------------------------------------------------------ */
+int hsr_abi_version(void);
+const char* hsr_last_error(void);
+/* Number of moments per band for a degree: 3*deg + 2. */
+int hsr_moment_count(int32_t deg);
+/* Partial-sum slots a launch over `npix` pixels uses (depends on npix only -> reproducible). */
+int hsr_partial_slots(int64_t npix);
+/* Bytes of the partials workspace for (nb, deg): nb * (3deg+2) * HSR_MAX_PARTIALS doubles. */
+size_t hsr_partials_bytes(int32_t nb, int32_t deg);
+
+/* ---- K1: SRF band integration ------------------------------------------------------------
+ * Replaces the hot loop of pseudo_s2_srf_integral (s2_emit/synth.py:32-43): for every pixel and
+ * every supported band b,  planes[b][p] = sum_k cube[p][k] * wn[b][k]  with IEEE semantics of the
+ * dense product (a non-finite sample poisons every band whose weight there is zero, synth.py:41).
+ *   cube_dev   (npix, B) float32, pixel-major / band-last, the in-memory layout of
+ *              load_emit_envi_rfl (s2_emit/emit_io.py:13); 4-byte aligned (16-byte = fast path)
+ *   wn_dev     (nb, B) float32 dense normalised trapezoid weights (host builds them in float64
+ *              from np.interp exactly as synth.py:33-35,42-43 and rounds once)
+ *   k0, klen   host arrays [nb]: support [k0, k0+klen) of each row of wn (zeros outside)
+ *   planes_dev (nb, plane_stride) float32 out
+ */
+int hsr_srf_integrate(const float* cube_dev, int64_t npix, int32_t B,
+                      const float* wn_dev, const int32_t* k0, const int32_t* klen, int32_t nb,
+                      float* planes_dev, int64_t plane_stride, hsr_stream_t stream);
+
+/* ---- K1+K2 fused: SRF integration and Vandermonde moments in one pass over the cube --------
+ * K1 as above and, in the same pass, the per-band power sums that np.polyfit's normal equations
+ * need (s2_emit/poly_regression.py:59-60; all-valid-pixel flavour of
+ * calibrate_pseudo_to_real_linear, Pairs_EMIT_S2_demo-2.ipynb cell 72 raw lines 4484-4510):
+ * pixel p counts for band b iff mask[p] (if given) && finite(x) && finite(y) && x > min_x && y > min_y,
+ * with x = planes[b][p] (float32) and y = real_dev[b][p]; sums are float64.
+ *   partials_dev  workspace of hsr_partials_bytes(nb, deg); slot layout [nb][3deg+2][slots]
+ *   returns the slot count used in *slots_out (== hsr_partial_slots(npix)).
+ */
+int hsr_srf_integrate_moments(const float* cube_dev, int64_t npix, int32_t B,
+                              const float* wn_dev, const int32_t* k0, const int32_t* klen, int32_t nb,
+                              float* planes_dev, int64_t plane_stride,
+                              const float* real_dev, int64_t real_stride, const uint8_t* mask_dev,
+                              float min_x, float min_y, int32_t deg,
+                              double* partials_dev, int32_t* slots_out, hsr_stream_t stream);
+
+/* ---- K2: moments of already materialised planes -----------------------------------------------
+ * Same sums as above for x/y planes that exist already (after a percentile stretch, or for the
+ * OT-sampled columns of fit_ot_poly_rgb, poly_regression.py:59-60).  If lohi_x_dev / lohi_y_dev
+ * (nb x 2 doubles: lo, hi) is given, the value is first stretched as color.py:33 does:
+ * float32(clip((v - lo) / (hi - lo + 1e-12), 0, 1)) and validity is tested on the raw value.
+ */
+int hsr_poly_moments(const float* x_dev, int64_t x_stride, const float* y_dev, int64_t y_stride,
+                     const uint8_t* mask_dev, int64_t npix, int32_t nb, int32_t deg,
+                     float min_x, float min_y, const double* lohi_x_dev, const double* lohi_y_dev,
+                     double* partials_dev, int32_t* slots_out, hsr_stream_t stream);
+
+/* Same sums for float64 sample columns (the OT-sampled X / barycentric Ybar columns of
+ * fit_ot_poly_rgb, poly_regression.py:46-60, which the reference keeps in float64). */
+int hsr_poly_moments_f64(const double* x_dev, int64_t x_stride, const double* y_dev, int64_t y_stride,
+                         int64_t npix, int32_t nb, int32_t deg,
+                         double* partials_dev, int32_t* slots_out, hsr_stream_t stream);
+
+/* Fixed-order reduction of the partial slots -> moments_dev (nb, 3deg+2) doubles. */
+int hsr_moments_reduce(const double* partials_dev, int32_t slots, int32_t nb, int32_t deg,
+                       double* moments_dev, hsr_stream_t stream);
+
+/* ---- polynomial solve ------------------------------------------------------------------------
+ * np.polyfit semantics (column-scaled least squares, rcond = count*eps, minimum-norm on rank loss)
+ * from the moments: scaled normal equations, symmetric Jacobi eigen-solve, float64.
+ * count < min_count -> identity polynomial (coeffs[-2] = 1), the reference's fallback
+ * (poly_regression.py:38-41 with 200; notebook cell 72 with 50).
+ * coeffs (nb, deg+1) doubles, highest power first (np.polyfit order).
+ */
+int hsr_poly_solve(const double* moments_dev, int32_t nb, int32_t deg, int64_t min_count,
+                   double* coeffs_dev, hsr_stream_t stream);
+/* Host twin (same code compiled for the CPU) for callers that hold the moments on the host. */
+int hsr_poly_solve_host(const double* moments, int32_t nb, int32_t deg, int64_t min_count,
+                        double* coeffs);
+
+/* ---- K3: polynomial apply ----------------------------------------------------------------------
+ * apply_poly_rgb (s2_emit/poly_regression.py:65-84): out = float32(x); where mask (or everywhere
+ * if mask_dev is NULL) out = float32(polyval_f64(coeffs[c], x)); then clip to [0,1] if `clip`
+ * (NaN stays NaN).  Optional stretch first (lohi_dev: nb x 2 doubles, color.py:33).
+ * coeffs_dev == NULL: no polynomial (stretch and/or clip only = apply_shared_percentile_stretch).
+ * deg in [0, HSR_MAX_APPLY_DEG].
+ * layout: HSR_LAYOUT_PLANAR (stride = plane stride) or HSR_LAYOUT_INTERLEAVED ((N, nb), stride ignored).
+ */
+int hsr_poly_apply(const float* x_dev, int64_t x_stride, const uint8_t* mask_dev,
+                   const double* coeffs_dev, int32_t nb, int32_t deg, int64_t npix,
+                   const double* lohi_dev, int32_t clip, int32_t layout,
+                   float* out_dev, int64_t out_stride, hsr_stream_t stream);
+
+/* ---- a4: exact masked percentiles (np.percentile, linear interpolation) ------------------------
+ * color.py:31-32: per channel the (pmin, pmax) percentiles of the masked values, exact order
+ * statistics + NumPy's lerp, in float64.  3-pass radix select on the float32 keys.
+ *   work_dev: workspace of hsr_percentile_work_bytes(nb) bytes;  lohi_dev: (nb, 2) doubles out.
+ */
+size_t hsr_percentile_work_bytes(int32_t nb);
+int hsr_percentile_limits(const float* x_dev, int64_t x_stride, int32_t layout,
+                          const uint8_t* mask_dev, int64_t npix, int32_t nb,
+                          double pmin, double pmax, void* work_dev, double* lohi_dev,
+                          hsr_stream_t stream);
+
+/* Validity mask of the pipeline (poly_regression.py:106,118): mask[p] = all bands of x finite
+ * && x[pos_band][p] > 0 (pos_band < 0: skip) && all bands of y finite (y_dev may be NULL),
+ * optionally AND-ed with mask_in_dev. */
+int hsr_valid_mask(const float* x_dev, int64_t x_stride, int32_t nbx, int32_t pos_band,
+                   const float* y_dev, int64_t y_stride, int32_t nby,
+                   const uint8_t* mask_in_dev, int64_t npix, uint8_t* mask_out_dev,
+                   hsr_stream_t stream);
+
+/* ---- diagnostics -------------------------------------------------------------------------------
+ * Pure streaming read of `bytes` bytes (16 B per lane, coalesced) folded into sink_dev[64]: the
+ * measured HBM read rate of the box, reported by bench.py beside the vendor peak. */
+int hsr_probe_read(const void* buf_dev, int64_t bytes, float* sink_dev, hsr_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HSR_H_ */

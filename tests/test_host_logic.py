@@ -1,0 +1,279 @@
+"""CPU-side tests of the product: host logic, the C-ABI surface, loud failure without a GPU."""
+import ctypes
+import os
+import re
+import zipfile
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, load_golden, unpack_srf
+from oracle import oracle_np as onp
+
+import s2_emit
+from s2_emit import _engine as eng
+from s2_emit import _native as nat
+
+
+# ---------------------------------------------------------------------------------------------
+# C ABI
+# ---------------------------------------------------------------------------------------------
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "hsr.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(hsr_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = nat.load()
+    names = _declared_symbols()
+    assert len(names) >= 15
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/hsr.h but not exported"
+        assert n in nat.SIGNATURES, f"{n} has no ctypes signature in _native.py"
+    assert set(nat.SIGNATURES) == set(names)
+    assert lib.hsr_abi_version() == 1
+
+
+def test_sizing_helpers_and_error_strings():
+    lib = nat.load()
+    assert [lib.hsr_moment_count(d) for d in (1, 2, 3, 4)] == [5, 8, 11, 14]
+    assert lib.hsr_moment_count(0) == -1 and lib.hsr_moment_count(5) == -1
+    assert lib.hsr_partial_slots(1) == 1 and lib.hsr_partial_slots(64) == 1 and lib.hsr_partial_slots(65) == 2
+    assert lib.hsr_partial_slots(1 << 20) == 512 and lib.hsr_partial_slots(1 << 30) == 512
+    assert lib.hsr_partials_bytes(12, 3) == 12 * 11 * 2048 * 8
+    assert lib.hsr_percentile_work_bytes(3) > 3 * (2048 + 4 * 2048 + 4 * 1024) * 4
+    # argument validation happens before any device work -> testable without a GPU
+    k = (ctypes.c_int32 * 1)(0)
+    rc = lib.hsr_srf_integrate(None, 10, 285, None, k, k, 1, None, 10, None)
+    assert rc == 1 and b"NULL" in lib.hsr_last_error()
+    rc = lib.hsr_srf_integrate(ctypes.c_void_p(16), 10, 9999, ctypes.c_void_p(16), k, k, 1, ctypes.c_void_p(16), 10, None)
+    assert rc == 2 and b"B=9999" in lib.hsr_last_error()
+    rc = lib.hsr_poly_solve(None, 3, 2, 50, None, None)
+    assert rc == 1
+
+
+def test_compute_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    srf = onp.synthetic_srf()
+    w, good = onp.synthetic_wavelengths()
+    with pytest.raises(nat.HsrUnavailable):
+        s2_emit.pseudo_s2_srf_integral(np.zeros((2, 2, 285), np.float32), w, srf, good)
+    with pytest.raises(nat.HsrUnavailable):
+        s2_emit.apply_poly_rgb(np.zeros((2, 2, 3), np.float32), np.zeros((3, 3)))
+    with pytest.raises(nat.HsrUnavailable):
+        s2_emit.apply_shared_percentile_stretch(np.zeros((2, 2, 3), np.float32), np.ones((2, 2), bool))
+
+
+def test_missing_library_message(monkeypatch):
+    monkeypatch.setattr(nat, "_lib", None)
+    monkeypatch.setenv("HSR_LIBRARY", "/nonexistent/libhsr.so")
+    with pytest.raises(nat.HsrUnavailable) as ei:
+        nat.load()
+    assert "no CPU fallback" in str(ei.value)
+    monkeypatch.delenv("HSR_LIBRARY")
+    nat.load()
+
+
+# ---------------------------------------------------------------------------------------------
+# host solve: np.polyfit from moments
+# ---------------------------------------------------------------------------------------------
+def _moments(x, y, deg):
+    x = x.astype(np.float64)
+    S = [np.sum(x ** k) for k in range(2 * deg + 1)]
+    T = [np.sum(x ** j * y) for j in range(deg + 1)]
+    return np.array(S + T)
+
+
+@pytest.mark.parametrize("deg", [1, 2, 3, 4])
+def test_solve_host_matches_polyfit_golden(deg):
+    g = load_golden("g3_polyfit")
+    for N in (200, 5000):
+        x, y = g[f"x_{N}"], g[f"y_{N}"]
+        c = eng.poly_solve_host(_moments(x, y, deg)[None], deg, 0)[0]
+        np.testing.assert_allclose(c, g[f"coef_{N}_{deg}"], rtol=2e-8, atol=1e-10)
+    xf, yf = g["xf32"].astype(np.float64), g["yf32"].astype(np.float64)
+    c = eng.poly_solve_host(_moments(xf, yf, deg)[None], deg, 50)[0]
+    np.testing.assert_allclose(c, g[f"coef_f32_{deg}"], rtol=2e-8, atol=1e-10)
+
+
+def test_solve_host_fallbacks_and_rank_loss():
+    m = _moments(np.linspace(0, 1, 40), np.linspace(0, 1, 40), 2)
+    np.testing.assert_array_equal(eng.poly_solve_host(m[None], 2, 50)[0], [0.0, 1.0, 0.0])
+    np.testing.assert_array_equal(eng.poly_solve_host(np.zeros((1, 14)), 4, 0)[0], [0, 0, 0, 1, 0])
+    # constant x: rank-1 Vandermonde -> minimum-norm solution like np.polyfit (no NaN, same values)
+    x = np.full(300, 0.5)
+    y = np.full(300, 0.25)
+    c = eng.poly_solve_host(_moments(x, y, 2)[None], 2, 50)[0]
+    with np.errstate(all="ignore"):
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            ref = np.polyfit(x, y, 2)
+    np.testing.assert_allclose(c, ref, rtol=1e-9, atol=1e-12)
+
+
+# ---------------------------------------------------------------------------------------------
+# SRF weight table
+# ---------------------------------------------------------------------------------------------
+def test_srf_table_matches_oracle_weights():
+    g = load_golden("g1_srf")
+    srf = unpack_srf(g)
+    t = eng.build_srf_table(g["emit_w"], srf, g["good_mask"])
+    Wn, names = onp.srf_weight_matrix(g["emit_w"], srf, g["good_mask"])
+    assert t.names == list(srf) and t.supported == names and "B10" not in t.supported
+    np.testing.assert_array_equal(t.weights, Wn)
+    for b in range(t.nb):
+        nz = np.nonzero(t.weights[b])[0]
+        assert t.k0[b] == nz[0] and t.k0[b] + t.klen[b] == nz[-1] + 1
+    assert t.klen.sum() < 400            # the sparse structure the kernel exploits
+    # weight-matrix product reproduces the reference planes (float64)
+    got = g["R"].astype(np.float64) @ t.weights.T
+    for i, k in enumerate(t.supported):
+        np.testing.assert_allclose(got[..., i], g[f"masked_{k}"], rtol=1e-12, atol=1e-15)
+    t2 = eng.build_srf_table(g["emit_w"], srf, None)
+    assert "B10" in t2.supported and t2.nb == 13
+
+
+def test_shape_errors_match_reference_text():
+    g = load_golden("g2_srf_edge")
+    srf = unpack_srf(g)
+    R, w = g["R"], g["emit_w"]
+    for (bR, bw), msg in zip(((R[0], w), (R, w[:-1]), (R, w.reshape(1, -1))), g["error_messages"]):
+        with pytest.raises(ValueError) as ei:
+            s2_emit.pseudo_s2_srf_integral(bR, bw, srf)
+        assert str(ei.value) == str(msg)
+    with pytest.raises(ValueError) as ei:
+        s2_emit.pseudo_s2_rgb({"B4": np.zeros((2, 2)), "B3": np.zeros((2, 2)), "B2": None})
+    assert str(ei.value) == "Band B2 is None/missing in pseudo_s2."
+    rgb = s2_emit.pseudo_s2_rgb({"B4": np.ones((2, 2)), "B3": np.zeros((2, 2)), "B2": np.zeros((2, 2))})
+    assert rgb.shape == (2, 2, 3) and rgb[0, 0, 0] == 1
+    # every band unsupported -> dict of None, no GPU needed
+    out = s2_emit.pseudo_s2_srf_integral(R, w, srf, np.zeros(285, bool))
+    assert list(out) == list(srf) and all(v is None for v in out.values())
+
+
+# ---------------------------------------------------------------------------------------------
+# SRF table loader (xlsx / csv / npz), API surface
+# ---------------------------------------------------------------------------------------------
+def _write_xlsx(path, sheets):
+    """Minimal xlsx writer for the test: sheets = {name: (header list, rows list)}."""
+    def col(i):
+        s = ""
+        i += 1
+        while i:
+            i, r = divmod(i - 1, 26)
+            s = chr(65 + r) + s
+        return s
+    with zipfile.ZipFile(path, "w") as z:
+        z.writestr("[Content_Types].xml", "<Types xmlns='http://schemas.openxmlformats.org/package/2006/content-types'/>")
+        wb = ["<workbook xmlns='http://schemas.openxmlformats.org/spreadsheetml/2006/main' "
+              "xmlns:r='http://schemas.openxmlformats.org/officeDocument/2006/relationships'><sheets>"]
+        rels = ["<Relationships xmlns='http://schemas.openxmlformats.org/package/2006/relationships'>"]
+        for i, (name, (header, rows)) in enumerate(sheets.items(), 1):
+            wb.append(f"<sheet name='{name}' sheetId='{i}' r:id='rId{i}'/>")
+            rels.append(f"<Relationship Id='rId{i}' Type='x' Target='worksheets/sheet{i}.xml'/>")
+            xml = ["<worksheet xmlns='http://schemas.openxmlformats.org/spreadsheetml/2006/main'><sheetData>"]
+            xml.append("<row r='1'>" + "".join(
+                f"<c r='{col(j)}1' t='inlineStr'><is><t>{h}</t></is></c>" for j, h in enumerate(header)) + "</row>")
+            for r, row in enumerate(rows, 2):
+                cells = []
+                for j, v in enumerate(row):
+                    if v is None:
+                        continue
+                    if isinstance(v, str):
+                        cells.append(f"<c r='{col(j)}{r}' t='inlineStr'><is><t>{v}</t></is></c>")
+                    else:
+                        cells.append(f"<c r='{col(j)}{r}'><v>{v!r}</v></c>")
+                xml.append(f"<row r='{r}'>" + "".join(cells) + "</row>")
+            xml.append("</sheetData></worksheet>")
+            z.writestr(f"xl/worksheets/sheet{i}.xml", "".join(xml))
+        wb.append("</sheets></workbook>")
+        rels.append("</Relationships>")
+        z.writestr("xl/workbook.xml", "".join(wb))
+        z.writestr("xl/_rels/workbook.xml.rels", "".join(rels))
+
+
+def test_load_s2_srf_from_xlsx_local_file(tmp_path):
+    lam = np.arange(400.0, 460.0)
+    header = ["SR_WL"] + [f"S2A_SR_AV_{b}" for b in s2_emit.S2_BANDS_13]
+    rows = []
+    for i, l in enumerate(lam):
+        row = [float(l)]
+        for j in range(13):
+            v = float(np.exp(-0.5 * ((l - 410 - 3 * j) / 6.0) ** 2))
+            row.append(v if v > 1e-3 else 0.0)
+        rows.append(row)
+    rows[5][1] = None            # blank cell -> NaN -> dropped
+    rows[6][2] = "n/a"           # text -> coerced to NaN -> dropped
+    p = tmp_path / "srf.xlsx"
+    _write_xlsx(p, {"Readme": (["x"], [[1.0]]), "Spectral Responses (S2A)": (header, rows),
+                    "Spectral Responses (S2B)": (header, rows)})
+    srf = s2_emit.load_s2_srf_from_xlsx(str(p))
+    assert list(srf) == s2_emit.S2_BANDS_13
+    lam1, r1 = srf["B1"]
+    assert lam1.dtype == np.float64 and (r1 > 0).all() and 405.0 not in lam1
+    assert 406.0 not in srf["B2"][0]
+    assert len(srf["B12"][0]) < len(lam)           # zero responses filtered (resp > 0)
+    sub = s2_emit.load_s2_srf_from_xlsx(str(p), bands=["B2", "B3"])
+    assert list(sub) == ["B2", "B3"]
+    with pytest.raises(ValueError) as ei:
+        s2_emit.load_s2_srf_from_xlsx(str(p), platform="S2C")
+    assert "No sheet containing 'Spectral Responses' and 'S2C' found." in str(ei.value)
+    with pytest.raises(KeyError) as ei:
+        s2_emit.load_s2_srf_from_xlsx(str(p), bands=["B99"])
+    assert "Column 'S2A_SR_AV_B99' not found in sheet 'Spectral Responses (S2A)'." in str(ei.value)
+    # csv / npz / dict sources give the same table
+    import csv
+    with open(tmp_path / "srf.csv", "w", newline="") as f:
+        wr = csv.writer(f)
+        wr.writerow(header)
+        for row in rows:
+            wr.writerow(["" if v is None else v for v in row])
+    c = s2_emit.load_s2_srf_from_xlsx(str(tmp_path / "srf.csv"))
+    for b in srf:
+        np.testing.assert_array_equal(c[b][0], srf[b][0])
+        np.testing.assert_allclose(c[b][1], srf[b][1], rtol=1e-15)
+
+
+def test_api_surface_matches_reference_all():
+    ref_all = ["load_s2_srf_from_xlsx", "load_emit_envi_rfl", "load_emit_wavelengths_from_nc",
+               "pseudo_s2_srf_integral", "pseudo_s2_rgb", "show_side_by_side", "resize_s2_rgb_to",
+               "robust_norm", "robust_norm_rgb", "apply_shared_percentile_stretch",
+               "histogram_match_rgb", "ot_match_rgb_sinkhorn_pot", "load_s2_rgb_u8"]
+    assert s2_emit.__all__[:13] == ref_all
+    for n in s2_emit.__all__:
+        assert callable(getattr(s2_emit, n))
+    import inspect
+    sig = inspect.signature(s2_emit.fit_ot_poly_rgb)
+    assert [(k, v.default) for k, v in sig.parameters.items()][3:] == [
+        ("deg", 2), ("n_samples", 5000), ("reg", 0.05), ("numItermax", 300), ("stopThr", 1e-6), ("seed", 0)]
+    assert list(inspect.signature(s2_emit.apply_poly_rgb).parameters) == ["rgb", "coeffs", "mask"]
+    assert list(inspect.signature(s2_emit.pseudo_s2_srf_integral).parameters)[:4] == ["R", "emit_w", "srf_dict", "good_mask"]
+    assert list(inspect.signature(s2_emit.apply_shared_percentile_stretch).parameters) == ["img", "mask", "pmin", "pmax"]
+
+
+def test_host_numpy_api_functions_against_golden():
+    g5 = load_golden("g5_stretch")
+    np.testing.assert_array_equal(s2_emit.robust_norm_rgb(g5["img"], g5["mask"]), g5["robust_norm_rgb"])
+    np.testing.assert_array_equal(s2_emit.robust_norm(g5["img"][..., 0]), g5["robust_norm"])
+    g8 = load_golden("g8_histmatch")
+    np.testing.assert_array_equal(s2_emit.histogram_match_rgb(g8["src"], g8["ref"], g8["mask"]), g8["out"])
+    g9 = load_golden("g9_fit_fallback")     # identity fallback needs no GPU
+    np.testing.assert_array_equal(s2_emit.fit_ot_poly_rgb(g9["src"], g9["ref"], g9["mask"], deg=2), g9["coeffs_deg2"])
+    np.testing.assert_array_equal(s2_emit.fit_ot_poly_rgb(g9["src_nan"], g9["ref"], g9["mask_b"], deg=3), g9["coeffs_nan_deg3"])
+
+
+def test_envi_loader_layouts(tmp_path):
+    rng = np.random.default_rng(0)
+    cube = rng.random((5, 7, 9)).astype(np.float32)          # (H, W, B)
+    for inter, arr in (("bip", cube), ("bil", cube.transpose(0, 2, 1)), ("bsq", cube.transpose(2, 0, 1))):
+        np.ascontiguousarray(arr).tofile(tmp_path / f"c_{inter}.bin")
+        (tmp_path / f"c_{inter}.hdr").write_text(
+            f"ENVI\ndescription = {{\n test }}\nsamples = 7\nlines = 5\nbands = 9\nheader offset = 0\n"
+            f"data type = 4\ninterleave = {inter}\nbyte order = 0\n")
+        R = s2_emit.load_emit_envi_rfl(str(tmp_path / f"c_{inter}.hdr"), str(tmp_path / f"c_{inter}.bin"))
+        assert R.dtype == np.float32 and R.flags.c_contiguous
+        np.testing.assert_array_equal(R, cube)

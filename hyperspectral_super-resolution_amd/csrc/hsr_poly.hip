@@ -17,9 +17,9 @@ namespace hsr {
 // ------------------------------------------------------------------------------------------------
 struct MomArgs {
   const float* x;
-  int64_t x_stride;
+  int64_t x_bs, x_ps;
   const float* y;
-  int64_t y_stride;
+  int64_t y_bs, y_ps;
   const uint8_t* mask;
   int64_t npix;
   float min_x, min_y;
@@ -48,8 +48,8 @@ __global__ __launch_bounds__(256) void moments_kernel(const MomArgs a) {
   constexpr int M = moment_count(DEG);
   __shared__ double red[4][M];
   const int b = blockIdx.y;
-  const float* x = a.x + (size_t)b * a.x_stride;
-  const float* y = a.y + (size_t)b * a.y_stride;
+  const float* x = a.x + (size_t)b * a.x_bs;
+  const float* y = a.y + (size_t)b * a.y_bs;
   const bool sx = a.lohi_x != nullptr, sy = a.lohi_y != nullptr;
   const double lox = sx ? a.lohi_x[2 * b] : 0.0, hix = sx ? a.lohi_x[2 * b + 1] : 0.0;
   const double loy = sy ? a.lohi_y[2 * b] : 0.0, hiy = sy ? a.lohi_y[2 * b + 1] : 0.0;
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void moments_kernel(const MomArgs a) {
   int64_t end = beg + per;
   if (end > a.npix) end = a.npix;
   for (int64_t p = beg + threadIdx.x; p < end; p += 256) {
-    float xv = x[p], yv = y[p];
+    float xv = x[p * a.x_ps], yv = y[p * a.y_ps];
     const bool m = a.mask ? a.mask[p] != 0 : true;
     const bool ok = m && finite_f32(xv) && finite_f32(yv) && xv > a.min_x && yv > a.min_y;
     if (ok) {
@@ -122,12 +122,26 @@ __global__ __launch_bounds__(256) void moments_f64_kernel(const double* __restri
 }
 
 // one wave per (band, moment) row; lane-strided partial sums then the fixed butterfly
+// Lane-strided sum of one slot row in a fixed order (slot = lane, lane+64, ...), the loads issued in
+// independent batches of 8 so that the row costs one memory round trip instead of slots/64.
+__device__ __forceinline__ double row_sum(const double* __restrict__ row, int slots, int lane) {
+  double s = 0.0;
+  for (int i0 = lane; i0 < slots; i0 += 64 * 8) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + 64 * u;
+      v[u] = i < slots ? row[i] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v[u];   // adding +0.0 for absent slots does not change the sum
+  }
+  return wave_sum(s);
+}
+
 __global__ __launch_bounds__(64) void reduce_kernel(const double* __restrict__ partials, int slots,
                                                     double* __restrict__ moments) {
-  const double* row = partials + (size_t)blockIdx.x * slots;
-  double s = 0.0;
-  for (int i = threadIdx.x; i < slots; i += 64) s += row[i];
-  s = wave_sum(s);
+  const double s = row_sum(partials + (size_t)blockIdx.x * slots, slots, threadIdx.x);
   if (threadIdx.x == 0) moments[blockIdx.x] = s;
 }
 
@@ -139,34 +153,20 @@ __global__ __launch_bounds__(64) void reduce_kernel(const double* __restrict__ p
 //   A_jk = S_{(d-j)+(d-k)} / (s_j s_k),  s_j = sqrt(S_{2(d-j)}),  rhs_j = T_{d-j} / s_j,
 // eigen-decompose A (cyclic Jacobi, <= 5x5) and apply the pseudo-inverse keeping the eigenvalues
 // above rcond^2 * max (singular values of V/s are the square roots).
-__host__ __device__ inline void solve_band(const double* mom, int deg, long long min_count, double* coef) {
-  const int n = deg + 1;
-  const double* S = mom;
-  const double* T = mom + 2 * deg + 1;
-  const double count = S[0];
-  if (!(count >= (double)min_count) || count < 1.0) {  // reference fallback: identity polynomial
-    for (int j = 0; j < n; ++j) coef[j] = 0.0;
-    coef[n - 2] = 1.0;
-    return;
-  }
-  double s[HSR_MAX_DEG + 1], A[HSR_MAX_DEG + 1][HSR_MAX_DEG + 1], V[HSR_MAX_DEG + 1][HSR_MAX_DEG + 1],
-      rhs[HSR_MAX_DEG + 1];
-  for (int j = 0; j < n; ++j) {
-    const double d = S[2 * (deg - j)];
-    s[j] = d > 0.0 ? sqrt(d) : 1.0;
-  }
-  for (int j = 0; j < n; ++j) {
-    rhs[j] = T[deg - j] / s[j];
-    for (int k = 0; k < n; ++k) {
-      A[j][k] = S[(deg - j) + (deg - k)] / (s[j] * s[k]);
-      V[j][k] = j == k ? 1.0 : 0.0;
-    }
-  }
-  for (int sweep = 0; sweep < 60; ++sweep) {
-    double off = 0.0;
-    for (int p = 0; p < n; ++p)
+// Rank-revealing path: symmetric cyclic Jacobi on the scaled Gram, pseudo-inverse with NumPy's cut-off.
+__host__ __device__ inline void solve_band_jacobi(double (&A)[HSR_MAX_DEG + 1][HSR_MAX_DEG + 1],
+                                                  const double* rhs, const double* s, int n, double count,
+                                                  double* coef) {
+  double V[HSR_MAX_DEG + 1][HSR_MAX_DEG + 1];
+  for (int j = 0; j < n; ++j)
+    for (int k = 0; k < n; ++k) V[j][k] = j == k ? 1.0 : 0.0;
+  for (int sweep = 0; sweep < 40; ++sweep) {
+    double off = 0.0, diag = 0.0;
+    for (int p = 0; p < n; ++p) {
+      diag += A[p][p] * A[p][p];
       for (int q = p + 1; q < n; ++q) off += A[p][q] * A[p][q];
-    if (off < 1e-300) break;
+    }
+    if (off <= 1e-36 * diag) break;
     for (int p = 0; p < n; ++p) {
       for (int q = p + 1; q < n; ++q) {
         const double apq = A[p][q];
@@ -208,10 +208,107 @@ __host__ __device__ inline void solve_band(const double* mom, int deg, long long
   for (int j = 0; j < n; ++j) coef[j] /= s[j];
 }
 
+// Fast path: Cholesky of the scaled Gram with every loop unrolled (N is a template constant, so the
+// whole factorisation lives in registers).  A pivot below 1e-13 (the scaled diagonal is exactly 1, so
+// this is cond(V/s) > ~3e6) hands the band to the rank-revealing Jacobi path, which reproduces
+// np.polyfit's singular-value cut-off; above it both paths agree to ~cond * eps.
+template <int DEG>
+__host__ __device__ inline void solve_band_t(const double* mom, long long min_count, double* coef) {
+  constexpr int n = DEG + 1;
+  const double* S = mom;
+  const double* T = mom + 2 * DEG + 1;
+  const double count = S[0];
+  if (!(count >= (double)min_count) || count < 1.0) {  // reference fallback: identity polynomial
+#pragma unroll
+    for (int j = 0; j < n; ++j) coef[j] = j == n - 2 ? 1.0 : 0.0;
+    return;
+  }
+  double s[HSR_MAX_DEG + 1], A[HSR_MAX_DEG + 1][HSR_MAX_DEG + 1], rhs[HSR_MAX_DEG + 1];
+#pragma unroll
+  for (int j = 0; j < n; ++j) {
+    const double d = S[2 * (DEG - j)];
+    s[j] = d > 0.0 ? sqrt(d) : 1.0;
+  }
+#pragma unroll
+  for (int j = 0; j < n; ++j) {
+    rhs[j] = T[DEG - j] / s[j];
+#pragma unroll
+    for (int k = 0; k < n; ++k) A[j][k] = S[(DEG - j) + (DEG - k)] / (s[j] * s[k]);
+  }
+  double L[n][n];
+  bool ok = true;
+#pragma unroll
+  for (int j = 0; j < n; ++j) {
+    double d = A[j][j];
+#pragma unroll
+    for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
+    ok = ok && (d > 1e-13);
+    const double ljj = sqrt(d > 1e-13 ? d : 1.0);
+    L[j][j] = ljj;
+#pragma unroll
+    for (int i = j + 1; i < n; ++i) {
+      double v = A[i][j];
+#pragma unroll
+      for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k];
+      L[i][j] = v / ljj;
+    }
+  }
+  if (ok) {
+    double z[n];
+#pragma unroll
+    for (int i = 0; i < n; ++i) {
+      double v = rhs[i];
+#pragma unroll
+      for (int k = 0; k < i; ++k) v -= L[i][k] * z[k];
+      z[i] = v / L[i][i];
+    }
+#pragma unroll
+    for (int i = n - 1; i >= 0; --i) {
+      double v = z[i];
+#pragma unroll
+      for (int k = i + 1; k < n; ++k) v -= L[k][i] * z[k];
+      z[i] = v / L[i][i];
+    }
+#pragma unroll
+    for (int j = 0; j < n; ++j) coef[j] = z[j] / s[j];
+    return;
+  }
+  solve_band_jacobi(A, rhs, s, n, count, coef);
+}
+
+__host__ __device__ inline void solve_band(const double* mom, int deg, long long min_count, double* coef) {
+  switch (deg) {
+    case 1: solve_band_t<1>(mom, min_count, coef); break;
+    case 2: solve_band_t<2>(mom, min_count, coef); break;
+    case 3: solve_band_t<3>(mom, min_count, coef); break;
+    default: solve_band_t<4>(mom, min_count, coef); break;
+  }
+}
+
 __global__ __launch_bounds__(64) void solve_kernel(const double* __restrict__ moments, int nb, int deg,
                                                    long long min_count, double* __restrict__ coeffs) {
   const int b = threadIdx.x;
   if (b < nb) solve_band(moments + (size_t)b * moment_count(deg), deg, min_count, coeffs + (size_t)b * (deg + 1));
+}
+
+// reduce + solve in one launch: one workgroup per band sums its 3deg+2 slot rows (same tree as
+// reduce_kernel: lane-strided sums, then the fixed butterfly), writes the moments, thread 0 solves.
+__global__ __launch_bounds__(1024) void reduce_solve_kernel(const double* __restrict__ partials, int slots, int deg,
+                                                            long long min_count, double* __restrict__ moments,
+                                                            double* __restrict__ coeffs) {
+  __shared__ double mom[3 * HSR_MAX_DEG + 2];
+  const int M = moment_count(deg);
+  const int b = blockIdx.x;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int m = wave; m < M; m += 16) {   // one wave per moment row (M <= 14 < 16 waves)
+    const double s = row_sum(partials + ((size_t)b * M + m) * slots, slots, lane);
+    if (lane == 0) {
+      mom[m] = s;
+      moments[(size_t)b * M + m] = s;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) solve_band(mom, deg, min_count, coeffs + (size_t)b * (deg + 1));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -219,14 +316,14 @@ __global__ __launch_bounds__(64) void solve_kernel(const double* __restrict__ mo
 // ------------------------------------------------------------------------------------------------
 struct ApplyArgs {
   const float* x;
-  int64_t x_stride;
+  int64_t x_bs, x_ps;
   const uint8_t* mask;
   const double* coeffs;
   const double* lohi;
   int32_t nb, deg, clip;
   int64_t npix;
   float* out;
-  int64_t out_stride;
+  int64_t out_bs, out_ps;
 };
 
 // np.polyval: y = 0; for c in coeffs: y = y*x + c  -- separate multiply and add in float64 (no FMA
@@ -240,6 +337,7 @@ __device__ __forceinline__ float poly_eval(float xf, const double* c, int n) {
 
 __device__ __forceinline__ float clip01(float v) { return v < 0.0f ? 0.0f : (v > 1.0f ? 1.0f : v); }
 
+// band-major planes, 16 bytes per lane along the pixel axis
 template <bool VEC4>
 __global__ __launch_bounds__(256) void apply_planar_kernel(const ApplyArgs a) {
   const int b = blockIdx.y;
@@ -249,8 +347,8 @@ __global__ __launch_bounds__(256) void apply_planar_kernel(const ApplyArgs a) {
   for (int i = 0; i < n; ++i) c[i] = has_poly ? a.coeffs[(size_t)b * n + i] : 0.0;
   const bool st = a.lohi != nullptr;
   const double lo = st ? a.lohi[2 * b] : 0.0, hi = st ? a.lohi[2 * b + 1] : 0.0;
-  const float* x = a.x + (size_t)b * a.x_stride;
-  float* o = a.out + (size_t)b * a.out_stride;
+  const float* x = a.x + (size_t)b * a.x_bs;
+  float* o = a.out + (size_t)b * a.out_bs;
   const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t nthreads = (int64_t)gridDim.x * 256;
   if (VEC4) {
@@ -277,16 +375,20 @@ __global__ __launch_bounds__(256) void apply_planar_kernel(const ApplyArgs a) {
     }
   } else {
     for (int64_t p = tid; p < a.npix; p += nthreads) {
-      float xv = x[p];
+      float xv = x[p * a.x_ps];
       if (st) xv = stretch_f64(xv, lo, hi);
       if (has_poly && (!a.mask || a.mask[p])) xv = poly_eval(xv, c, n);
-      o[p] = a.clip ? clip01(xv) : xv;
+      o[p * a.out_ps] = a.clip ? clip01(xv) : xv;
     }
   }
 }
 
-// (N, C) band-last images, the layout of the reference API (H, W, 3)
-__global__ __launch_bounds__(256) void apply_interleaved_kernel(const ApplyArgs a) {
+// pixel-major (band-last) images, the layout of the reference API (H, W, C) and of the fused path:
+// a pure contiguous stream.  VEC4: rows of ps floats with ps % 4 == 0, 16 bytes per lane (4 channels
+// of one pixel); channels >= nb of a padded row pass through unchanged.
+template <int Q>  // Q > 0: rows of 4*Q floats, 16 bytes per lane; Q == 0: scalar, any row stride
+__global__ __launch_bounds__(256) void apply_pixmajor_kernel(const ApplyArgs a) {
+  constexpr bool VEC4 = Q > 0;
   __shared__ double cs[HSR_MAX_BANDS * (HSR_MAX_APPLY_DEG + 1)];
   __shared__ double lh[HSR_MAX_BANDS * 2];
   const int n = a.deg + 1;
@@ -297,29 +399,66 @@ __global__ __launch_bounds__(256) void apply_interleaved_kernel(const ApplyArgs 
   if (st)
     for (int i = threadIdx.x; i < a.nb * 2; i += 256) lh[i] = a.lohi[i];
   __syncthreads();
-  const int64_t total = a.npix * a.nb;
-  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
-    const int64_t p = e / a.nb;
-    const int ch = (int)(e - p * a.nb);
-    float xv = a.x[e];
-    if (st) xv = stretch_f64(xv, lh[2 * ch], lh[2 * ch + 1]);
-    if (has_poly && (!a.mask || a.mask[p])) xv = poly_eval(xv, cs + ch * n, n);
-    a.out[e] = a.clip ? clip01(xv) : xv;
+  const int ps = (int)a.x_ps;
+  const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t nthreads = (int64_t)gridDim.x * 256;
+  if (VEC4) {
+    constexpr uint32_t q = VEC4 ? Q : 1;  // float4 per pixel row (compile-time: division by constant)
+    const uint32_t nv = (uint32_t)(a.npix * q);   // host guarantees npix * q < 2^31
+    constexpr int U = 4;    // independent 16-byte loads in flight per thread
+    for (uint32_t i0 = (uint32_t)tid; i0 < nv; i0 += (uint32_t)nthreads * U) {
+      float4 v[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t i = i0 + u * (uint32_t)nthreads;
+        if (i < nv) v[u] = reinterpret_cast<const float4*>(a.x)[i];
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t i = i0 + u * (uint32_t)nthreads;
+        if (i >= nv) break;
+        const uint32_t p = i / q;
+        const int c0 = (int)(i - p * q) * 4;
+        const bool m = !a.mask || a.mask[p];
+        float r[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int ch = c0 + j;
+          if (ch < a.nb) {
+            float xv = r[j];
+            if (st) xv = stretch_f64(xv, lh[2 * ch], lh[2 * ch + 1]);
+            if (has_poly && m) xv = poly_eval(xv, cs + ch * n, n);
+            r[j] = a.clip ? clip01(xv) : xv;
+          }
+        }
+        reinterpret_cast<float4*>(a.out)[i] = make_float4(r[0], r[1], r[2], r[3]);
+      }
+    }
+  } else {
+    const int64_t total = a.npix * a.nb;
+    for (int64_t e = tid; e < total; e += nthreads) {
+      const int64_t p = e / a.nb;
+      const int ch = (int)(e - p * a.nb);
+      float xv = a.x[p * a.x_ps + ch];
+      if (st) xv = stretch_f64(xv, lh[2 * ch], lh[2 * ch + 1]);
+      if (has_poly && (!a.mask || a.mask[p])) xv = poly_eval(xv, cs + ch * n, n);
+      a.out[p * a.out_ps + ch] = a.clip ? clip01(xv) : xv;
+    }
   }
 }
 
 // ------------------------------------------------------------------------------------------------
 // validity mask of the pipeline (poly_regression.py:106,118)
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void valid_mask_kernel(const float* x, int64_t xs, int nbx, int pos_band,
-                                                         const float* y, int64_t ys, int nby, const uint8_t* min,
-                                                         int64_t npix, uint8_t* mout) {
+__global__ __launch_bounds__(256) void valid_mask_kernel(const float* x, int64_t xbs, int64_t xps, int nbx,
+                                                         int pos_band, const float* y, int64_t ybs, int64_t yps,
+                                                         int nby, const uint8_t* min, int64_t npix, uint8_t* mout) {
   for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < npix; p += (int64_t)gridDim.x * 256) {
     bool ok = min ? min[p] != 0 : true;
-    for (int b = 0; b < nbx; ++b) ok = ok && finite_f32(x[b * xs + p]);
-    if (pos_band >= 0) ok = ok && x[pos_band * xs + p] > 0.0f;
+    for (int b = 0; b < nbx; ++b) ok = ok && finite_f32(x[b * xbs + p * xps]);
+    if (pos_band >= 0) ok = ok && x[pos_band * xbs + p * xps] > 0.0f;
     if (y)
-      for (int b = 0; b < nby; ++b) ok = ok && finite_f32(y[b * ys + p]);
+      for (int b = 0; b < nby; ++b) ok = ok && finite_f32(y[b * ybs + p * yps]);
     mout[p] = ok ? 1 : 0;
   }
 }
@@ -334,8 +473,12 @@ static inline int stream_grid(int64_t work_items, int per_block) {
 
 using namespace hsr;
 
-extern "C" int hsr_poly_moments(const float* x_dev, int64_t x_stride, const float* y_dev, int64_t y_stride,
-                                const uint8_t* mask_dev, int64_t npix, int32_t nb, int32_t deg, float min_x,
+static bool strides_ok(int64_t bs, int64_t ps, int64_t npix, int nb) {
+  return (ps == 1 && bs >= npix) || (bs == 1 && ps >= nb);
+}
+
+extern "C" int hsr_poly_moments(const float* x_dev, int64_t x_bs, int64_t x_ps, const float* y_dev, int64_t y_bs,
+                                int64_t y_ps, const uint8_t* mask_dev, int64_t npix, int32_t nb, int32_t deg, float min_x,
                                 float min_y, const double* lohi_x_dev, const double* lohi_y_dev,
                                 double* partials_dev, int32_t* slots_out, hsr_stream_t stream) {
   HSR_REQUIRE(x_dev && y_dev && partials_dev, HSR_ERR_INVALID, "hsr_poly_moments: NULL pointer");
@@ -344,8 +487,9 @@ extern "C" int hsr_poly_moments(const float* x_dev, int64_t x_stride, const floa
               HSR_MAX_BANDS);
   HSR_REQUIRE(deg >= 1 && deg <= HSR_MAX_DEG, HSR_ERR_UNSUPPORTED, "hsr_poly_moments: deg=%d outside [1,%d]", deg,
               HSR_MAX_DEG);
-  HSR_REQUIRE(x_stride >= npix && y_stride >= npix, HSR_ERR_INVALID, "hsr_poly_moments: stride < npix");
-  MomArgs a{x_dev, x_stride, y_dev, y_stride, mask_dev, npix, min_x, min_y, lohi_x_dev, lohi_y_dev, partials_dev,
+  HSR_REQUIRE(strides_ok(x_bs, x_ps, npix, nb) && strides_ok(y_bs, y_ps, npix, nb), HSR_ERR_INVALID,
+              "hsr_poly_moments: strides are neither band-major nor pixel-major");
+  MomArgs a{x_dev, x_bs, x_ps, y_dev, y_bs, y_ps, mask_dev, npix, min_x, min_y, lohi_x_dev, lohi_y_dev, partials_dev,
             partial_slots(npix)};
   const dim3 grid(a.slots, nb), block(256);
   hipStream_t s = (hipStream_t)stream;
@@ -404,6 +548,19 @@ extern "C" int hsr_poly_solve(const double* moments_dev, int32_t nb, int32_t deg
   return HSR_OK;
 }
 
+extern "C" int hsr_moments_reduce_solve(const double* partials_dev, int32_t slots, int32_t nb, int32_t deg,
+                                        int64_t min_count, double* moments_dev, double* coeffs_dev,
+                                        hsr_stream_t stream) {
+  HSR_REQUIRE(partials_dev && moments_dev && coeffs_dev, HSR_ERR_INVALID, "hsr_moments_reduce_solve: NULL pointer");
+  HSR_REQUIRE(slots >= 1 && slots <= HSR_MAX_PARTIALS, HSR_ERR_INVALID, "hsr_moments_reduce_solve: slots=%d", slots);
+  HSR_REQUIRE(nb >= 1 && nb <= HSR_MAX_BANDS && deg >= 1 && deg <= HSR_MAX_DEG, HSR_ERR_UNSUPPORTED,
+              "hsr_moments_reduce_solve: nb=%d deg=%d", nb, deg);
+  hipLaunchKernelGGL(reduce_solve_kernel, dim3(nb), dim3(1024), 0, (hipStream_t)stream, partials_dev, slots, deg,
+                     (long long)min_count, moments_dev, coeffs_dev);
+  HSR_LAUNCH_CHECK("reduce_solve_kernel");
+  return HSR_OK;
+}
+
 extern "C" int hsr_poly_solve_host(const double* moments, int32_t nb, int32_t deg, int64_t min_count,
                                    double* coeffs) {
   HSR_REQUIRE(moments && coeffs, HSR_ERR_INVALID, "hsr_poly_solve_host: NULL pointer");
@@ -414,43 +571,56 @@ extern "C" int hsr_poly_solve_host(const double* moments, int32_t nb, int32_t de
   return HSR_OK;
 }
 
-extern "C" int hsr_poly_apply(const float* x_dev, int64_t x_stride, const uint8_t* mask_dev,
+extern "C" int hsr_poly_apply(const float* x_dev, int64_t x_bs, int64_t x_ps, const uint8_t* mask_dev,
                               const double* coeffs_dev, int32_t nb, int32_t deg, int64_t npix,
-                              const double* lohi_dev, int32_t clip, int32_t layout, float* out_dev,
-                              int64_t out_stride, hsr_stream_t stream) {
+                              const double* lohi_dev, int32_t clip, float* out_dev, int64_t out_bs, int64_t out_ps,
+                              hsr_stream_t stream) {
   HSR_REQUIRE(x_dev && out_dev, HSR_ERR_INVALID, "hsr_poly_apply: NULL pointer");
   HSR_REQUIRE(npix >= 0, HSR_ERR_INVALID, "hsr_poly_apply: npix < 0");
   HSR_REQUIRE(nb >= 1 && nb <= HSR_MAX_BANDS && deg >= 0 && deg <= HSR_MAX_APPLY_DEG, HSR_ERR_UNSUPPORTED,
               "hsr_poly_apply: nb=%d deg=%d", nb, deg);
+  HSR_REQUIRE(strides_ok(x_bs, x_ps, npix, nb) && strides_ok(out_bs, out_ps, npix, nb), HSR_ERR_INVALID,
+              "hsr_poly_apply: strides are neither band-major nor pixel-major");
   if (npix == 0) return HSR_OK;
-  ApplyArgs a{x_dev, x_stride, mask_dev, coeffs_dev, lohi_dev, nb, deg, clip, npix, out_dev, out_stride};
+  ApplyArgs a{x_dev, x_bs, x_ps, mask_dev, coeffs_dev, lohi_dev, nb, deg, clip, npix, out_dev, out_bs, out_ps};
   hipStream_t s = (hipStream_t)stream;
-  if (layout == HSR_LAYOUT_INTERLEAVED) {
-    hipLaunchKernelGGL(apply_interleaved_kernel, dim3(stream_grid(npix * nb, 256 * 4)), dim3(256), 0, s, a);
-    HSR_LAUNCH_CHECK("apply_interleaved_kernel");
+  const bool aligned = ((((uintptr_t)x_dev) | ((uintptr_t)out_dev)) & 15) == 0;
+  if (x_bs == 1 && out_bs == 1 && x_ps == out_ps && !(x_ps == 1 && nb > 1)) {  // pixel-major in and out, same rows
+    const int64_t q = x_ps >> 2;
+    if (aligned && (x_ps & 3) == 0 && q >= 1 && q <= 4 && npix * q < ((int64_t)1 << 31)) {
+      const dim3 grid(stream_grid(npix * q, 256 * 4));
+      switch (q) {
+        case 1: hipLaunchKernelGGL(apply_pixmajor_kernel<1>, grid, dim3(256), 0, s, a); break;
+        case 2: hipLaunchKernelGGL(apply_pixmajor_kernel<2>, grid, dim3(256), 0, s, a); break;
+        case 3: hipLaunchKernelGGL(apply_pixmajor_kernel<3>, grid, dim3(256), 0, s, a); break;
+        default: hipLaunchKernelGGL(apply_pixmajor_kernel<4>, grid, dim3(256), 0, s, a); break;
+      }
+    } else {
+      hipLaunchKernelGGL(apply_pixmajor_kernel<0>, dim3(stream_grid(npix * nb, 256 * 4)), dim3(256), 0, s, a);
+    }
+    HSR_LAUNCH_CHECK("apply_pixmajor_kernel");
     return HSR_OK;
   }
-  HSR_REQUIRE(layout == HSR_LAYOUT_PLANAR, HSR_ERR_INVALID, "hsr_poly_apply: layout=%d", layout);
-  HSR_REQUIRE(x_stride >= npix && out_stride >= npix, HSR_ERR_INVALID, "hsr_poly_apply: stride < npix");
-  const bool vec = (((uintptr_t)x_dev | (uintptr_t)out_dev) & 15) == 0 && (x_stride & 3) == 0 &&
-                   (out_stride & 3) == 0 && (((uintptr_t)mask_dev) & 3) == 0;
+  const bool vec = aligned && x_ps == 1 && out_ps == 1 && (x_bs & 3) == 0 && (out_bs & 3) == 0 &&
+                   (((uintptr_t)mask_dev) & 3) == 0;
   const dim3 grid(stream_grid(npix, 256 * 4), nb);
   if (vec)
     hipLaunchKernelGGL(apply_planar_kernel<true>, grid, dim3(256), 0, s, a);
   else
-    hipLaunchKernelGGL(apply_planar_kernel<false>, grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(apply_planar_kernel<false>, grid, dim3(256), 0, s, a);  // any mix of strides
   HSR_LAUNCH_CHECK("apply_planar_kernel");
   return HSR_OK;
 }
 
-extern "C" int hsr_valid_mask(const float* x_dev, int64_t x_stride, int32_t nbx, int32_t pos_band,
-                              const float* y_dev, int64_t y_stride, int32_t nby, const uint8_t* mask_in_dev,
-                              int64_t npix, uint8_t* mask_out_dev, hsr_stream_t stream) {
+extern "C" int hsr_valid_mask(const float* x_dev, int64_t x_bs, int64_t x_ps, int32_t nbx, int32_t pos_band,
+                              const float* y_dev, int64_t y_bs, int64_t y_ps, int32_t nby,
+                              const uint8_t* mask_in_dev, int64_t npix, uint8_t* mask_out_dev,
+                              hsr_stream_t stream) {
   HSR_REQUIRE(x_dev && mask_out_dev, HSR_ERR_INVALID, "hsr_valid_mask: NULL pointer");
   HSR_REQUIRE(nbx >= 1 && pos_band < nbx && npix >= 0, HSR_ERR_INVALID, "hsr_valid_mask: bad shape");
   if (npix == 0) return HSR_OK;
   hipLaunchKernelGGL(valid_mask_kernel, dim3(stream_grid(npix, 256)), dim3(256), 0, (hipStream_t)stream, x_dev,
-                     x_stride, nbx, pos_band, y_dev, y_stride, y_dev ? nby : 0, mask_in_dev, npix, mask_out_dev);
+                     x_bs, x_ps, nbx, pos_band, y_dev, y_bs, y_ps, y_dev ? nby : 0, mask_in_dev, npix, mask_out_dev);
   HSR_LAUNCH_CHECK("valid_mask_kernel");
   return HSR_OK;
 }

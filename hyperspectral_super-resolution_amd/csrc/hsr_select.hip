@@ -210,7 +210,7 @@ extern "C" size_t hsr_percentile_work_bytes(int32_t nb) {
   return hist1_bytes(nb) + hist2_bytes(nb) + hist3_bytes(nb) + state_bytes(nb) + 64;
 }
 
-extern "C" int hsr_percentile_limits(const float* x_dev, int64_t x_stride, int32_t layout,
+extern "C" int hsr_percentile_limits(const float* x_dev, int64_t x_bs, int64_t x_ps,
                                      const uint8_t* mask_dev, int64_t npix, int32_t nb, double pmin, double pmax,
                                      void* work_dev, double* lohi_dev, hsr_stream_t stream) {
   HSR_REQUIRE(x_dev && work_dev && lohi_dev, HSR_ERR_INVALID, "hsr_percentile_limits: NULL pointer");
@@ -223,14 +223,10 @@ extern "C" int hsr_percentile_limits(const float* x_dev, int64_t x_stride, int32
   hipStream_t s = (hipStream_t)stream;
   SelArgs a{};
   a.x = x_dev;
-  if (layout == HSR_LAYOUT_INTERLEAVED) {
-    a.cs = 1;
-    a.ps = nb;
-  } else {
-    HSR_REQUIRE(layout == HSR_LAYOUT_PLANAR && x_stride >= npix, HSR_ERR_INVALID, "hsr_percentile_limits: layout/stride");
-    a.cs = x_stride;
-    a.ps = 1;
-  }
+  HSR_REQUIRE((x_ps == 1 && x_bs >= npix) || (x_bs == 1 && x_ps >= nb), HSR_ERR_INVALID,
+              "hsr_percentile_limits: strides are neither band-major nor pixel-major");
+  a.cs = x_bs;
+  a.ps = x_ps;
   a.mask = mask_dev;
   a.npix = npix;
   a.nb = nb;

@@ -3,17 +3,23 @@
 // Replaces the hot loop of pseudo_s2_srf_integral (reference s2_emit/synth.py:32-43).  The reference
 // makes 13 full-cube float64 passes; here the cube is streamed from HBM exactly once.
 //
-// Data flow per workgroup (256 threads = 4 waves, 2 workgroups resident per CU):
+// Data flow per workgroup (512 threads = 8 waves, 2 workgroups resident per CU):
 //   1. a tile of 64 consecutive pixels (64*B*4 bytes, one linear 16-byte-aligned slab because the
 //      cube is pixel-major) goes HBM -> LDS with global_load_lds_dwordx4 (no VGPR round trip,
 //      1 KiB per wave instruction, fully coalesced).  ~73 KB in flight per workgroup.
 //   2. one linear ds_read_b128 sweep flags pixels holding a non-finite sample.
 //   3. lane = pixel, wave = band group: each band is a short dot product over its SRF support read
-//      from LDS with a row stride of B words (B odd -> bank-conflict free); the weights are
-//      wave-uniform and arrive through the scalar cache (s_load) as SGPR operands of v_fmac.
+//      from LDS with a row stride of B words (B odd -> bank-conflict free).  The weight taps of all
+//      bands (a few hundred floats, 16-byte aligned segments) are staged into LDS once per
+//      workgroup and read as broadcast ds_read_b128 - no scalar-load latency inside the tile loop
+//      (the first version fetched them with s_load per tile and spent ~5 us per tile waiting).
 //      Flagged pixels take the dense product so that 0*Inf -> NaN poisons exactly the bands the
 //      reference poisons (synth.py:41 multiplies all B samples of every band).
-//   4. planes[b][pixel] is stored coalesced (256 B per wave store).  With DEG > 0 the same lane
+//   4. output.  Pixel-major (band-last) output is staged in LDS as the tile's contiguous
+//      [pixel][band] slab and flushed with 16-byte stores AFTER the next tile's DMA has been issued:
+//      one contiguous ~3 KB write per tile.  (Band-major planes are stored directly: nb scattered
+//      256-B segments per tile; measured 10 % slower on the whole kernel because of the write
+//      pattern, although the planes are only 4 % of the bytes.)  With DEG > 0 the same lane
 //      also accumulates the Vandermonde power sums of (x = plane value, y = real S2 value) in
 //      float64 registers; they are reduced over the wave by a fixed butterfly and written to a
 //      per-workgroup slot (no float atomics -> bitwise reproducible).
@@ -25,7 +31,10 @@ namespace hsr {
 struct SrfBands {
   int32_t k0[HSR_MAX_BANDS];
   int32_t klen[HSR_MAX_BANDS];
+  int32_t woff[HSR_MAX_BANDS];  // offset (floats, multiple of 4) of the band's taps in the LDS weight area
 };
+
+constexpr int kWeightCap = 1024;  // floats of LDS reserved for compact weight taps (4 KiB)
 
 struct SrfArgs {
   const float* cube;
@@ -33,24 +42,57 @@ struct SrfArgs {
   int64_t ntiles;
   int32_t B;
   int32_t ldsB;  // LDS row stride in words (odd)
+  int32_t wtaps; // floats used in the LDS weight area (0: weights do not fit, read them from global)
   const float* wn;
   SrfBands bands;
   int32_t nb;
-  float* planes;
-  int64_t plane_stride;
-  const float* real;
-  int64_t real_stride;
+  float* out;        // element (b, p) at out[b * out_bs + p * out_ps]
+  int64_t out_bs, out_ps;
+  const float* real;  // element (b, p) at real[b * real_bs + p * real_ps]
+  int64_t real_bs, real_ps;
   const uint8_t* mask;
   float min_x, min_y;
   double* partials;
   int32_t slots;
+#ifdef HSR_PHASE_STAMPS
+  unsigned long long* stamps;
+#endif
 };
 
-constexpr int kBlock = 256;
-constexpr int kBandSlots = HSR_MAX_BANDS / 4;  // bands per wave
+#ifdef HSR_PHASE_STAMPS
+// Diagnostic build only (tools/k1_lab): per-phase s_memtime stamps, written to a buffer nothing else
+// reads.  Never compiled into libhsr_mi355x.so.
+unsigned long long* g_stamp_buffer = nullptr;
+__device__ __forceinline__ unsigned long long phase_stamp() {
+  unsigned long long t;
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+#define HSR_STAMP(var) const unsigned long long var = phase_stamp()
+#else
+#define HSR_STAMP(var)
+#endif
+
+constexpr int kGroups = 8;                          // band groups per workgroup (band = group + 8 * slot)
+constexpr int kBandSlots = HSR_MAX_BANDS / kGroups;  // 2 bands per thread
+constexpr int kTapChunk = 16;                       // taps per unrolled dot-product chunk
+constexpr int kScanBatch = 5;                       // ds_read_b128 in flight per thread in the sweep
+
+// Tile geometry: P pixels per LDS tile, 8*P threads per workgroup.
+//   P = 64: 512 threads (8 waves), lane = pixel, wave = band group;      2 workgroups per CU
+//   P = 32: 256 threads (4 waves), lane&31 = pixel, each wave half = one band group; 4 per CU
+// Both keep 16 waves (4 per SIMD, <= 128 VGPRs) and ~146 KB of LDS tiles per CU; the smaller tile
+// gives the CU's memory pipe four queued customers instead of two (see DESIGN.md, K1 tuning).
+static int g_tile_pixels = 64;
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
+
+// Workgroup barrier that orders LDS accesses only: s_waitcnt lgkmcnt(0) (leaves vmcnt untouched, so
+// the plane stores just issued are not waited for) + s_barrier.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
 
 // x*0 is NaN exactly when x is NaN or +-Inf; four of them chained cost 4 VALU ops.
 __device__ __forceinline__ bool any_nonfinite4(const float4& v) {
@@ -61,19 +103,61 @@ __device__ __forceinline__ bool any_nonfinite4(const float4& v) {
   return z != z;
 }
 
-template <int DEG, bool FAST>
-__global__ __launch_bounds__(kBlock, 2) void srf_kernel(const SrfArgs a) {
+// Flush the staged [pixel][band] slab of the previous tile: contiguous in HBM, 16 bytes per lane.
+template <int T>
+__device__ __forceinline__ void flush_stage(const float* ostage, float* out, int64_t pix0, int npx, int ops, int t) {
+  const int n4 = (npx * ops) >> 2;  // ops is a multiple of 4
+  float4* dst = reinterpret_cast<float4*>(out + pix0 * ops);
+  const float4* src = reinterpret_cast<const float4*>(ostage);
+  for (int i = t; i < n4; i += T) dst[i] = src[i];
+}
+
+template <int DEG, bool FAST, bool WLDS, int P, bool OUTV>
+__global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
+  constexpr int T = 8 * P;
+  constexpr int NW = T / 64;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* tile = reinterpret_cast<float*>(smem);
   const int B = a.B;
   const int ldsB = a.ldsB;
-  uint32_t* flags = reinterpret_cast<uint32_t*>(smem + (size_t)HSR_TILE_PIXELS * ldsB * 4);
+  uint32_t* flags = reinterpret_cast<uint32_t*>(smem + (size_t)P * ldsB * 4);
+  const float* wl = reinterpret_cast<const float*>(flags + 64);  // 16-byte aligned
+  float* ostage = const_cast<float*>(wl) + (WLDS ? a.wtaps : 0);  // [P][out_ps] output slab (OUTV only)
+  const int ops = (int)a.out_ps;
+  int64_t prev_pix0 = 0;
+  int prev_npx = 0;
 
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int nchunk = 16 * B;  // 16-byte chunks of a full tile
+  const int pl = t % P;     // pixel of this thread inside the tile
+  const int grp = t / P;    // band group 0..7 (wave-uniform for P = 64, per half-wave for P = 32)
+  const int nchunk = P * B / 4;  // 16-byte chunks of a full tile (P is a multiple of 4)
 
+  // the (at most two) bands of this thread, fixed for the whole launch
+  int bk0[kBandSlots], bkl[kBandSlots], bwo[kBandSlots];
+  bool bval[kBandSlots];
+#pragma unroll
+  for (int j = 0; j < kBandSlots; ++j) {
+    const int b = grp + kGroups * j;
+    bval[j] = b < a.nb;
+    const int bb = bval[j] ? b : 0;
+    bk0[j] = a.bands.k0[bb];
+    bkl[j] = bval[j] ? a.bands.klen[bb] : 0;
+    bwo[j] = a.bands.woff[bb];
+  }
+
+  if (WLDS) {  // compact weight taps -> LDS, once per workgroup (visible after the first barrier below)
+    float* wlw = const_cast<float*>(wl);
+    for (int b = 0; b < a.nb; ++b) {
+      const int kl = a.bands.klen[b];  // whole 16-tap chunks inside [0, B) (srf_common)
+      for (int i = t; i < kl; i += T) wlw[a.bands.woff[b] + i] = a.wn[(size_t)b * B + a.bands.k0[b] + i];
+    }
+  }
+
+#ifdef HSR_PHASE_STAMPS
+  unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
   constexpr int M = DEG > 0 ? moment_count(DEG) : 1;
   double acc_m[kBandSlots][M];
   if (DEG > 0) {
@@ -84,51 +168,73 @@ __global__ __launch_bounds__(kBlock, 2) void srf_kernel(const SrfArgs a) {
   }
 
   for (int64_t tileidx = blockIdx.x; tileidx < a.ntiles; tileidx += gridDim.x) {
-    const int64_t pix0 = tileidx * HSR_TILE_PIXELS;
+    const int64_t pix0 = tileidx * P;
     const int64_t left = a.npix - pix0;
-    const int npx = left < HSR_TILE_PIXELS ? (int)left : HSR_TILE_PIXELS;
+    const int npx = left < P ? (int)left : P;
     const float* src = a.cube + pix0 * B;
-    const bool pvalid = lane < npx;
+    const bool pvalid = pl < npx;
 
     // operands of the fused fit: issue these loads before waiting for the tile
     float yv[kBandSlots];
     bool mv = true;
     if (DEG > 0) {
 #pragma unroll
-      for (int j = 0; j < kBandSlots; ++j) {
-        const int b = wave + 4 * j;
-        yv[j] = (b < a.nb && pvalid) ? a.real[b * a.real_stride + pix0 + lane] : 0.0f;
-      }
-      if (a.mask != nullptr) mv = pvalid && a.mask[pix0 + lane] != 0;
+      for (int j = 0; j < kBandSlots; ++j)
+        yv[j] = (bval[j] && pvalid) ? a.real[(grp + kGroups * j) * a.real_bs + (pix0 + pl) * a.real_ps] : 0.0f;
+      if (a.mask != nullptr) mv = pvalid && a.mask[pix0 + pl] != 0;
     }
 
-    if (t < HSR_TILE_PIXELS) flags[t] = 0u;
+    HSR_STAMP(st0);
+    if (t < P) flags[t] = 0u;
 
-    const bool fast_tile = FAST && npx == HSR_TILE_PIXELS;
+    const bool fast_tile = FAST && npx == P;
     if (fast_tile) {
       const char* srcb = reinterpret_cast<const char*>(src);
-      for (int c0 = wave * 64; c0 < nchunk; c0 += kBlock) {  // c0 is wave-uniform
+      for (int c0 = wave * 64; c0 < nchunk; c0 += T) {  // c0 is wave-uniform
         const int c = c0 + lane;
         if (c < nchunk)
           __builtin_amdgcn_global_load_lds((gptr_t)(srcb + (size_t)c * 16), (lptr_t)(smem + (size_t)c0 * 16),
                                            16, 0, 0);
       }
+      if (OUTV) flush_stage<8 * P>(ostage, a.out, prev_pix0, prev_npx, ops, t);
+      HSR_STAMP(st1);
       __syncthreads();
+      HSR_STAMP(st2);
+      // non-finite sweep: kScanBatch independent ds_read_b128 in flight per thread (a serial
+      // read->wait->test loop cost 3.7k cycles per tile; batched it is LDS-bandwidth bound).
+      // Indices past the tile are clamped to its last chunk (a harmless re-read, no predication).
       const float4* t4 = reinterpret_cast<const float4*>(smem);
-      for (int c = t; c < nchunk; c += kBlock) {
-        const float4 v = t4[c];
-        if (any_nonfinite4(v)) {  // rare
-          const int e = c * 4;
-          if (!finite_f32(v.x)) flags[(e + 0) / B] = 1u;
-          if (!finite_f32(v.y)) flags[(e + 1) / B] = 1u;
-          if (!finite_f32(v.z)) flags[(e + 2) / B] = 1u;
-          if (!finite_f32(v.w)) flags[(e + 3) / B] = 1u;
+      for (int c0 = t; c0 < nchunk; c0 += T * kScanBatch) {
+        float4 v[kScanBatch];
+#pragma unroll
+        for (int u = 0; u < kScanBatch; ++u) {
+          const int c = c0 + u * T;
+          v[u] = t4[c < nchunk ? c : nchunk - 1];
+        }
+        bool bad = false;
+#pragma unroll
+        for (int u = 0; u < kScanBatch; ++u) bad |= any_nonfinite4(v[u]);
+        if (bad) {  // rare
+#pragma unroll
+          for (int u = 0; u < kScanBatch; ++u) {
+            const int c = c0 + u * T;
+            const int e = (c < nchunk ? c : nchunk - 1) * 4;
+            if (!finite_f32(v[u].x)) flags[(e + 0) / B] = 1u;
+            if (!finite_f32(v[u].y)) flags[(e + 1) / B] = 1u;
+            if (!finite_f32(v[u].z)) flags[(e + 2) / B] = 1u;
+            if (!finite_f32(v[u].w)) flags[(e + 3) / B] = 1u;
+          }
         }
       }
+#ifdef HSR_PHASE_STAMPS
+      HSR_STAMP(st3);
+      if (a.stamps) { stamp_acc[0] += st1 - st0; stamp_acc[1] += st2 - st1; stamp_acc[2] += st3 - st2; }
+#endif
     } else {
       // generic loader: any 4-byte alignment, any B, ragged last tile.  One pixel row per wave step.
+      if (OUTV) flush_stage<8 * P>(ostage, a.out, prev_pix0, prev_npx, ops, t);
       __syncthreads();  // flags zeroed before anybody sets one
-      for (int pp = wave; pp < npx; pp += 4) {
+      for (int pp = wave; pp < npx; pp += NW) {
         bool bad = false;
         for (int k = lane; k < B; k += 64) {
           const float v = src[(size_t)pp * B + k];
@@ -140,24 +246,59 @@ __global__ __launch_bounds__(kBlock, 2) void srf_kernel(const SrfArgs a) {
     }
     __syncthreads();
 
-    const bool slow = flags[lane] != 0u;
-    const float* v = tile + lane * ldsB;
+    HSR_STAMP(st4);
+    const bool slow = flags[pl] != 0u;
+    const float* v = tile + pl * ldsB;
+    float accv[kBandSlots];
 #pragma unroll
     for (int j = 0; j < kBandSlots; ++j) {
-      const int b = wave + 4 * j;  // wave-uniform
-      if (b < a.nb) {
-        const float* w = a.wn + (size_t)b * B;
-        float acc = 0.0f;
-        if (!slow) {
-          const int k0 = a.bands.k0[b];
-          const int kl = a.bands.klen[b];
-          const float* ws = w + k0;
-          const float* vs = v + k0;
-          for (int i = 0; i < kl; ++i) acc = fmaf(ws[i], vs[i], acc);
-        } else {
-          for (int k = 0; k < B; ++k) acc = fmaf(w[k], v[k], acc);
+      float acc = 0.0f;
+      const float* vs = v + bk0[j];
+      if (WLDS) {
+        // [k0, k0+kl) was widened by srf_common to whole 16-tap chunks that stay inside this pixel's
+        // row; the added taps carry weight 0 and (for an unflagged pixel) multiply finite samples,
+        // so the sum is bit-identical to the exact-support sum.  One chunk = 4 broadcast
+        // ds_read_b128 (weights) + 16 ds_read_b32 (samples, stride ldsB words: conflict-free)
+        // issued together, then a 16-deep fma chain: no serial remainder loop.
+        const float4* w4 = reinterpret_cast<const float4*>(wl + bwo[j]);
+        for (int i0 = 0; i0 < bkl[j]; i0 += kTapChunk) {
+          float4 ww[kTapChunk / 4];
+          float xv[kTapChunk];
+#pragma unroll
+          for (int u = 0; u < kTapChunk / 4; ++u) ww[u] = w4[(i0 >> 2) + u];
+#pragma unroll
+          for (int u = 0; u < kTapChunk; ++u) xv[u] = vs[i0 + u];
+#pragma unroll
+          for (int u = 0; u < kTapChunk / 4; ++u) {
+            acc = fmaf(ww[u].x, xv[4 * u + 0], acc);
+            acc = fmaf(ww[u].y, xv[4 * u + 1], acc);
+            acc = fmaf(ww[u].z, xv[4 * u + 2], acc);
+            acc = fmaf(ww[u].w, xv[4 * u + 3], acc);
+          }
         }
-        if (pvalid) a.planes[b * a.plane_stride + pix0 + lane] = acc;
+      } else {
+        const float* ws = a.wn + (size_t)(grp + kGroups * j) * B + bk0[j];
+        for (int i = 0; i < bkl[j]; ++i) acc = fmaf(ws[i], vs[i], acc);
+      }
+      accv[j] = acc;
+    }
+    if (slow) {  // rare: the dense product reproduces the reference's Inf/NaN classification per band
+#pragma unroll
+      for (int j = 0; j < kBandSlots; ++j) {
+        if (bval[j]) {
+          const float* w = a.wn + (size_t)(grp + kGroups * j) * B;
+          float acc = 0.0f;
+          for (int k = 0; k < B; ++k) acc = fmaf(w[k], v[k], acc);
+          accv[j] = acc;
+        }
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < kBandSlots; ++j) {
+      if (bval[j]) {
+        const float acc = accv[j];
+        if (OUTV) ostage[pl * ops + grp + kGroups * j] = acc;
+        else if (pvalid) a.out[(grp + kGroups * j) * a.out_bs + (pix0 + pl) * a.out_ps] = acc;
         if (DEG > 0) {
           const float y = yv[j];
           const bool ok = pvalid && mv && finite_f32(acc) && finite_f32(y) && acc > a.min_x && y > a.min_y;
@@ -176,101 +317,184 @@ __global__ __launch_bounds__(kBlock, 2) void srf_kernel(const SrfArgs a) {
         }
       }
     }
-    __syncthreads();  // tile and flags are rewritten by the next iteration
+    prev_pix0 = pix0;
+    prev_npx = npx;
+    HSR_STAMP(st5);
+    // The tile and the flags are rewritten by the next iteration: an LDS-only hazard.  A plain
+    // __syncthreads() here would also wait (vmcnt(0)) for the plane stores just issued.
+    lds_barrier();
+#ifdef HSR_PHASE_STAMPS
+    {
+      HSR_STAMP(st6);
+      if (a.stamps) { stamp_acc[3] += st5 - st4; stamp_acc[4] += st6 - st5; stamp_acc[5] += st6 - st0; stamp_acc[6] += 1; }
+    }
+#endif
   }
+  if (OUTV) flush_stage<8 * P>(ostage, a.out, prev_pix0, prev_npx, ops, t);  // last tile (after the barrier)
+#ifdef HSR_PHASE_STAMPS
+  if (a.stamps && lane == 0)
+    for (int k = 0; k < 8; ++k) a.stamps[((size_t)blockIdx.x * NW + wave) * 8 + k] = stamp_acc[k];
+#endif
 
   if (DEG > 0) {
+    // fixed butterfly over the P lanes that share a band (whole wave for P = 64, half wave for P = 32)
 #pragma unroll
     for (int j = 0; j < kBandSlots; ++j) {
-      const int b = wave + 4 * j;
-      if (b < a.nb) {
 #pragma unroll
-        for (int m = 0; m < M; ++m) {
-          const double s = wave_sum(acc_m[j][m]);
-          if (lane == 0) a.partials[((size_t)b * M + m) * a.slots + blockIdx.x] = s;
-        }
+      for (int m = 0; m < M; ++m) {
+        double sv = acc_m[j][m];
+#pragma unroll
+        for (int off = (P < 64 ? P : 64) / 2; off >= 1; off >>= 1) sv += __shfl_xor(sv, off, 64);
+        if (bval[j] && (lane % P) == 0)
+          a.partials[((size_t)(grp + kGroups * j) * M + m) * a.slots + blockIdx.x] = sv;
       }
     }
   }
 }
 
-template <int DEG, bool FAST>
+template <int DEG, bool FAST, bool WLDS, int P, bool OUTV>
 static int launch_srf(const SrfArgs& a, hipStream_t stream) {
-  const size_t lds = (size_t)HSR_TILE_PIXELS * a.ldsB * 4 + HSR_TILE_PIXELS * sizeof(uint32_t);
-  auto kern = srf_kernel<DEG, FAST>;
+  const size_t lds = (size_t)P * a.ldsB * 4 + 64 * sizeof(uint32_t) + (WLDS ? (size_t)a.wtaps * 4 : 0) +
+                     (OUTV ? (size_t)P * a.out_ps * 4 : 0);
+  auto kern = srf_kernel<DEG, FAST, WLDS, P, OUTV>;
   static thread_local size_t configured = 0;
   if (lds > configured) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipGetLastError();
     configured = lds;
   }
-  hipLaunchKernelGGL(kern, dim3(a.slots), dim3(kBlock), lds, stream, a);
+#ifdef HSR_PHASE_STAMPS
+  const_cast<SrfArgs&>(a).stamps = g_stamp_buffer;
+#endif
+  hipLaunchKernelGGL(kern, dim3(a.slots), dim3(8 * P), lds, stream, a);
   HSR_LAUNCH_CHECK("srf_kernel");
   return HSR_OK;
 }
 
-template <int DEG>
+template <int DEG, int P>
 static int dispatch_fast(const SrfArgs& a, bool fast, hipStream_t s) {
-  return fast ? launch_srf<DEG, true>(a, s) : launch_srf<DEG, false>(a, s);
+  // pixel-major output with a 16-byte friendly row: stage the slab in LDS and flush it vectorised
+  const bool outv = a.out_bs == 1 && (a.out_ps & 3) == 0 && a.out_ps <= HSR_MAX_BANDS &&
+                    (((uintptr_t)a.out) & 15) == 0;
+  if (a.wtaps == 0) return launch_srf<DEG, false, false, 64, false>(a, s);  // rare fallback: one generic kernel
+  if (outv) return fast ? launch_srf<DEG, true, true, P, true>(a, s) : launch_srf<DEG, false, true, P, true>(a, s);
+  return fast ? launch_srf<DEG, true, true, P, false>(a, s) : launch_srf<DEG, false, true, P, false>(a, s);
+}
+
+template <int P>
+static int dispatch_deg(const SrfArgs& a, int deg, bool fast, hipStream_t s) {
+  switch (deg) {
+    case 0: return dispatch_fast<0, P>(a, fast, s);
+    case 1: return dispatch_fast<1, P>(a, fast, s);
+    case 2: return dispatch_fast<2, P>(a, fast, s);
+    case 3: return dispatch_fast<3, P>(a, fast, s);
+    case 4: return dispatch_fast<4, P>(a, fast, s);
+  }
+  set_error("hsr_srf_integrate_moments: deg=%d outside [1,%d]", deg, HSR_MAX_DEG);
+  return HSR_ERR_UNSUPPORTED;
+}
+
+int srf_partial_slots(int64_t npix) {
+  const int P = g_tile_pixels;
+  int64_t tiles = (npix + P - 1) / P;
+  if (tiles < 1) tiles = 1;
+  const int64_t cap = P == 64 ? 512 : 1024;  // 256 CUs x (2 | 4) resident workgroups
+  return (int)(tiles < cap ? tiles : cap);
 }
 
 static int srf_common(SrfArgs& a, const int32_t* k0, const int32_t* klen, int32_t deg, hipStream_t stream) {
-  HSR_REQUIRE(a.cube && a.wn && a.planes && k0 && klen, HSR_ERR_INVALID, "hsr_srf_integrate: NULL pointer");
+  HSR_REQUIRE(a.cube && a.wn && a.out && k0 && klen, HSR_ERR_INVALID, "hsr_srf_integrate: NULL pointer");
   HSR_REQUIRE(a.npix >= 0, HSR_ERR_INVALID, "hsr_srf_integrate: npix < 0");
   HSR_REQUIRE(a.B >= 1 && a.B <= HSR_MAX_SPECTRAL, HSR_ERR_UNSUPPORTED,
               "hsr_srf_integrate: B=%d outside [1,%d]", a.B, HSR_MAX_SPECTRAL);
   HSR_REQUIRE(a.nb >= 1 && a.nb <= HSR_MAX_BANDS, HSR_ERR_UNSUPPORTED,
               "hsr_srf_integrate: nb=%d outside [1,%d]", a.nb, HSR_MAX_BANDS);
-  HSR_REQUIRE(a.plane_stride >= a.npix, HSR_ERR_INVALID, "hsr_srf_integrate: plane_stride < npix");
+  HSR_REQUIRE((a.out_ps == 1 && a.out_bs >= a.npix) || (a.out_bs == 1 && a.out_ps >= a.nb), HSR_ERR_INVALID,
+              "hsr_srf_integrate: output strides (%lld, %lld) are neither band-major nor pixel-major",
+              (long long)a.out_bs, (long long)a.out_ps);
   HSR_REQUIRE(((uintptr_t)a.cube & 3) == 0, HSR_ERR_INVALID, "hsr_srf_integrate: cube not 4-byte aligned");
   for (int b = 0; b < a.nb; ++b) {
     HSR_REQUIRE(k0[b] >= 0 && klen[b] >= 0 && k0[b] + klen[b] <= a.B, HSR_ERR_INVALID,
                 "hsr_srf_integrate: support of band %d = [%d,%d) outside [0,%d)", b, k0[b], k0[b] + klen[b], a.B);
     a.bands.k0[b] = k0[b];
     a.bands.klen[b] = klen[b];
+    a.bands.woff[b] = 0;
   }
-  for (int b = a.nb; b < HSR_MAX_BANDS; ++b) a.bands.k0[b] = a.bands.klen[b] = 0;
+  for (int b = a.nb; b < HSR_MAX_BANDS; ++b) a.bands.k0[b] = a.bands.klen[b] = a.bands.woff[b] = 0;
+  // LDS weight segments: widen every support to whole 16-tap chunks that stay inside [0, B) (the
+  // added taps have weight 0 in the dense rows of wn); if that is impossible (B < 16 * chunks) or the
+  // taps do not fit the reserved LDS, the kernel reads the weights from global memory instead.
+  {
+    int32_t sk0[HSR_MAX_BANDS], skl[HSR_MAX_BANDS], off[HSR_MAX_BANDS], total = 0;
+    bool fits = true;
+    for (int b = 0; b < a.nb && fits; ++b) {
+      const int nc = (klen[b] + kTapChunk - 1) / kTapChunk;
+      int s0 = k0[b];
+      if (s0 + kTapChunk * nc > a.B) s0 = a.B - kTapChunk * nc;
+      if (s0 < 0) fits = false;
+      sk0[b] = s0;
+      skl[b] = kTapChunk * nc;
+      off[b] = total;
+      total += kTapChunk * nc;
+    }
+    if (fits && total <= kWeightCap) {
+      for (int b = 0; b < a.nb; ++b) {
+        a.bands.k0[b] = sk0[b];
+        a.bands.klen[b] = skl[b];
+        a.bands.woff[b] = off[b];
+      }
+      a.wtaps = total > 0 ? total : kTapChunk;
+    } else {
+      a.wtaps = 0;
+    }
+  }
   if (a.npix == 0) return HSR_OK;
-  a.ntiles = (a.npix + HSR_TILE_PIXELS - 1) / HSR_TILE_PIXELS;
-  a.slots = partial_slots(a.npix);
+  int P = g_tile_pixels;
+  if (a.wtaps == 0) P = 64;  // the generic fallback kernel exists for 64-pixel tiles only
+  a.ntiles = (a.npix + P - 1) / P;
+  a.slots = srf_partial_slots(a.npix);
+  if (a.wtaps == 0) { int64_t tl = a.ntiles; a.slots = (int)(tl < 512 ? tl : 512); }
   a.ldsB = (a.B & 1) ? a.B : a.B + 1;
   const bool fast = (a.B & 1) && (((uintptr_t)a.cube & 15) == 0);
-  switch (deg) {
-    case 0: return dispatch_fast<0>(a, fast, stream);
-    case 1: return dispatch_fast<1>(a, fast, stream);
-    case 2: return dispatch_fast<2>(a, fast, stream);
-    case 3: return dispatch_fast<3>(a, fast, stream);
-    case 4: return dispatch_fast<4>(a, fast, stream);
-  }
-  set_error("hsr_srf_integrate_moments: deg=%d outside [1,%d]", deg, HSR_MAX_DEG);
-  return HSR_ERR_UNSUPPORTED;
+  return P == 64 ? dispatch_deg<64>(a, deg, fast, stream) : dispatch_deg<32>(a, deg, fast, stream);
 }
 
 }  // namespace hsr
 
+extern "C" int hsr_set_srf_tile(int32_t pixels) {
+  HSR_REQUIRE(pixels == 64 || pixels == 32, HSR_ERR_INVALID, "hsr_set_srf_tile: pixels must be 64 or 32, got %d", pixels);
+  hsr::g_tile_pixels = pixels;
+  return HSR_OK;
+}
+
+extern "C" int hsr_get_srf_tile(void) { return hsr::g_tile_pixels; }
+
 extern "C" int hsr_srf_integrate(const float* cube_dev, int64_t npix, int32_t B, const float* wn_dev,
-                                 const int32_t* k0, const int32_t* klen, int32_t nb, float* planes_dev,
-                                 int64_t plane_stride, hsr_stream_t stream) {
+                                 const int32_t* k0, const int32_t* klen, int32_t nb, float* out_dev,
+                                 int64_t out_bs, int64_t out_ps, hsr_stream_t stream) {
   hsr::SrfArgs a{};
   a.cube = cube_dev;
   a.npix = npix;
   a.B = B;
   a.wn = wn_dev;
   a.nb = nb;
-  a.planes = planes_dev;
-  a.plane_stride = plane_stride;
+  a.out = out_dev;
+  a.out_bs = out_bs;
+  a.out_ps = out_ps;
   return hsr::srf_common(a, k0, klen, 0, (hipStream_t)stream);
 }
 
 extern "C" int hsr_srf_integrate_moments(const float* cube_dev, int64_t npix, int32_t B, const float* wn_dev,
-                                         const int32_t* k0, const int32_t* klen, int32_t nb, float* planes_dev,
-                                         int64_t plane_stride, const float* real_dev, int64_t real_stride,
-                                         const uint8_t* mask_dev, float min_x, float min_y, int32_t deg,
+                                         const int32_t* k0, const int32_t* klen, int32_t nb, float* out_dev,
+                                         int64_t out_bs, int64_t out_ps, const float* real_dev, int64_t real_bs,
+                                         int64_t real_ps, const uint8_t* mask_dev, float min_x, float min_y, int32_t deg,
                                          double* partials_dev, int32_t* slots_out, hsr_stream_t stream) {
   HSR_REQUIRE(deg >= 1 && deg <= HSR_MAX_DEG, HSR_ERR_UNSUPPORTED, "hsr_srf_integrate_moments: deg=%d outside [1,%d]",
               deg, HSR_MAX_DEG);
   HSR_REQUIRE(real_dev && partials_dev, HSR_ERR_INVALID, "hsr_srf_integrate_moments: NULL pointer");
-  HSR_REQUIRE(real_stride >= npix, HSR_ERR_INVALID, "hsr_srf_integrate_moments: real_stride < npix");
+  HSR_REQUIRE((real_ps == 1 && real_bs >= npix) || (real_bs == 1 && real_ps >= nb), HSR_ERR_INVALID,
+              "hsr_srf_integrate_moments: real strides (%lld, %lld) are neither band-major nor pixel-major",
+              (long long)real_bs, (long long)real_ps);
   HSR_REQUIRE(npix > 0, HSR_ERR_INVALID, "hsr_srf_integrate_moments: npix must be > 0");
   hsr::SrfArgs a{};
   a.cube = cube_dev;
@@ -278,10 +502,12 @@ extern "C" int hsr_srf_integrate_moments(const float* cube_dev, int64_t npix, in
   a.B = B;
   a.wn = wn_dev;
   a.nb = nb;
-  a.planes = planes_dev;
-  a.plane_stride = plane_stride;
+  a.out = out_dev;
+  a.out_bs = out_bs;
+  a.out_ps = out_ps;
   a.real = real_dev;
-  a.real_stride = real_stride;
+  a.real_bs = real_bs;
+  a.real_ps = real_ps;
   a.mask = mask_dev;
   a.min_x = min_x;
   a.min_y = min_y;

@@ -3,17 +3,22 @@
 PyTorch is used only as plumbing (HBM allocations, the current HIP stream, torch.distributed);
 every operator here is one or a few stream-ordered calls into libhsr_mi355x.so through its C ABI
 (include/hsr.h).  Nothing in this module synchronises the device.
+
+Image-like tensors come in two layouts (include/hsr.h, "band_stride / pixel_stride"):
+  PLANAR    (nb, npix)   band-major planes
+  PIXMAJOR  (npix, row)  pixel-major / band-last, row >= nb (rows padded to a multiple of 4 floats
+                         take the vectorised paths); the layout of the cube and of (H, W, C) images.
 """
 from __future__ import annotations
 
 import ctypes as C
-import math
 from dataclasses import dataclass, field
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Dict, List, Optional
 
 import numpy as np
 
 from . import _native as nat
+from ._native import PIXMAJOR, PLANAR
 
 _NEG_INF = float("-inf")
 
@@ -24,6 +29,39 @@ def _stream(torch):
 
 def _ptr(t):
     return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def padded_row(nb: int) -> int:
+    """Row length (floats) of a pixel-major image with nb channels: next multiple of 4."""
+    return (nb + 3) // 4 * 4
+
+
+def _img(t, layout: str, nb: Optional[int] = None):
+    """(band_stride, pixel_stride, nb, npix) of a 2-D float32 image tensor in the given layout."""
+    if t.dim() != 2:
+        raise ValueError(f"image tensors are 2-D ((nb, npix) or (npix, row)); got shape {tuple(t.shape)}")
+    if layout == PLANAR:
+        n, npix = t.shape
+        if npix > 1 and t.stride(1) != 1:
+            raise ValueError("planar image must have unit pixel stride")
+        bs = t.stride(0) if n > 1 else max(int(t.stride(0)), int(npix))
+        return int(bs), 1, int(nb or n), int(npix)
+    if layout == PIXMAJOR:
+        npix, row = t.shape
+        if row > 1 and t.stride(1) != 1:
+            raise ValueError("pixel-major image must have unit band stride")
+        ps = t.stride(0) if npix > 1 else max(int(t.stride(0)), int(row))
+        n = int(nb or row)
+        if n > row:
+            raise ValueError(f"pixel-major image has rows of {row} < nb={n}")
+        return 1, int(ps), n, int(npix)
+    raise ValueError(f"unknown layout {layout!r}")
+
+
+def alloc_image(torch, nb: int, npix: int, layout: str, device):
+    if layout == PLANAR:
+        return torch.empty((nb, npix), dtype=torch.float32, device=device)
+    return torch.empty((npix, padded_row(nb)), dtype=torch.float32, device=device)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -108,8 +146,8 @@ def _i32arr(a):
     return a, a.ctypes.data_as(C.POINTER(C.c_int32))
 
 
-def srf_integrate(cube, table: SrfTable, out=None):
-    """K1.  cube (..., B) float32 on the GPU -> planes (nb, npix) float32 (band-major)."""
+def srf_integrate(cube, table: SrfTable, out=None, layout: str = PLANAR):
+    """K1.  cube (..., B) float32 on the GPU -> pseudo-S2 image in ``layout`` (float32)."""
     torch = nat.require_gpu()
     lib = nat.load()
     c2 = _as_cube2d(cube)
@@ -117,16 +155,17 @@ def srf_integrate(cube, table: SrfTable, out=None):
     if B != table.B:
         raise ValueError(f"emit_w must be (B,) matching R bands. Got {(table.B,)} vs {B}")
     nb = table.nb
-    planes = out if out is not None else torch.empty((nb, npix), dtype=torch.float32, device=cube.device)
+    img = out if out is not None else alloc_image(torch, nb, npix, layout, cube.device)
+    bs, ps, _, _ = _img(img, layout, nb)
     wn = table.device_weights(cube.device)
     for b0 in range(0, nb, nat.HSR_MAX_BANDS):          # >16 bands: one more pass over the cube
         b1 = min(nb, b0 + nat.HSR_MAX_BANDS)
-        k0a, k0p = _i32arr(table.k0[b0:b1])      # keep the arrays alive across the call
+        k0a, k0p = _i32arr(table.k0[b0:b1])              # keep the arrays alive across the call
         kla, klp = _i32arr(table.klen[b0:b1])
+        dst = img[b0:b1] if layout == PLANAR else img[:, b0:]
         nat.check(lib.hsr_srf_integrate(_ptr(c2), npix, B, _ptr(wn[b0:b1]), k0p, klp, b1 - b0,
-                                        _ptr(planes[b0:b1]), planes.stride(0), _stream(torch)),
-                  "hsr_srf_integrate")
-    return planes
+                                        _ptr(dst), bs, ps, _stream(torch)), "hsr_srf_integrate")
+    return img
 
 
 class MomentWorkspace:
@@ -141,11 +180,14 @@ class MomentWorkspace:
         self.partials = torch.empty(nbytes // 8, dtype=torch.float64, device=device)
         self.moments = torch.zeros((nb, self.M), dtype=torch.float64, device=device)
         self.coeffs = torch.zeros((nb, deg + 1), dtype=torch.float64, device=device)
+        self.slots = 0
 
 
-def srf_integrate_moments(cube, table: SrfTable, real_planes, deg: int, ws: MomentWorkspace,
-                          mask=None, min_x=_NEG_INF, min_y=_NEG_INF, out=None, events=None):
-    """K1+K2 fused: planes and the per-band Vandermonde moments (nb, 3deg+2) in one cube pass.
+def srf_integrate_moments(cube, table: SrfTable, real, deg: int, ws: MomentWorkspace, mask=None,
+                          min_x=_NEG_INF, min_y=_NEG_INF, out=None, events=None, reduce=True,
+                          layout: str = PIXMAJOR, real_layout: Optional[str] = None):
+    """K1+K2 fused: pseudo-S2 image and the per-band Vandermonde moments in one cube pass.
+    ``real``: real-S2 image in ``real_layout`` (default: same as ``layout``).
     ``events``: optional (start, stop) torch.cuda.Event pair recorded on the launch stream right
     around the fused kernel (bench.py's live roofline measurement)."""
     torch = nat.require_gpu()
@@ -157,45 +199,65 @@ def srf_integrate_moments(cube, table: SrfTable, real_planes, deg: int, ws: Mome
         raise ValueError(f"fused SRF+moments handles at most {nat.HSR_MAX_BANDS} bands per call")
     if B != table.B:
         raise ValueError(f"emit_w must be (B,) matching R bands. Got {(table.B,)} vs {B}")
-    real2 = real_planes.reshape(nb, -1)
-    if not (real2.dtype == torch.float32 and real2.is_cuda and real2.stride(1) == 1 and real2.shape[1] == npix):
-        raise ValueError("real_planes must be (nb, npix) float32 on the GPU")
+    rbs, rps, _, rn = _img(real, real_layout or layout, nb)
+    if rn != npix or real.dtype != torch.float32 or not real.is_cuda:
+        raise ValueError("real must be a float32 GPU image with one value per pixel and band")
     if mask is not None and not (mask.dtype == torch.uint8 and mask.numel() == npix and mask.is_contiguous()):
         raise ValueError("mask must be a contiguous uint8 tensor with one byte per pixel")
-    planes = out if out is not None else torch.empty((nb, npix), dtype=torch.float32, device=cube.device)
+    img = out if out is not None else alloc_image(torch, nb, npix, layout, cube.device)
+    bs, ps, _, _ = _img(img, layout, nb)
     wn = table.device_weights(cube.device)
     k0a, k0p = _i32arr(table.k0)                 # keep the arrays alive across the call
     kla, klp = _i32arr(table.klen)
     slots = C.c_int32(0)
     if events is not None:
         events[0].record()
-    nat.check(lib.hsr_srf_integrate_moments(_ptr(c2), npix, B, _ptr(wn), k0p, klp, nb, _ptr(planes),
-                                            planes.stride(0), _ptr(real2), real2.stride(0), _ptr(mask),
-                                            min_x, min_y, deg, _ptr(ws.partials), C.byref(slots),
-                                            _stream(torch)), "hsr_srf_integrate_moments")
+    nat.check(lib.hsr_srf_integrate_moments(_ptr(c2), npix, B, _ptr(wn), k0p, klp, nb, _ptr(img), bs, ps,
+                                            _ptr(real), rbs, rps, _ptr(mask), min_x, min_y, deg,
+                                            _ptr(ws.partials), C.byref(slots), _stream(torch)),
+              "hsr_srf_integrate_moments")
     if events is not None:
         events[1].record()
-    nat.check(lib.hsr_moments_reduce(_ptr(ws.partials), slots.value, nb, deg, _ptr(ws.moments),
+    ws.slots = slots.value
+    if not reduce:                      # caller continues with moments_reduce_solve / moments_reduce
+        return img, None
+    return img, moments_reduce(ws)
+
+
+def moments_reduce(ws: MomentWorkspace):
+    """Fixed-order reduction of the partial slots of the last moments launch -> ws.moments."""
+    torch = nat.require_gpu()
+    lib = nat.load()
+    nat.check(lib.hsr_moments_reduce(_ptr(ws.partials), ws.slots, ws.nb, ws.deg, _ptr(ws.moments),
                                      _stream(torch)), "hsr_moments_reduce")
-    return planes, ws.moments
+    return ws.moments
+
+
+def moments_reduce_solve(ws: MomentWorkspace, min_count: int):
+    """Reduce + np.polyfit solve in one launch (no exchange in between) -> (ws.moments, ws.coeffs)."""
+    torch = nat.require_gpu()
+    lib = nat.load()
+    nat.check(lib.hsr_moments_reduce_solve(_ptr(ws.partials), ws.slots, ws.nb, ws.deg, int(min_count),
+                                           _ptr(ws.moments), _ptr(ws.coeffs), _stream(torch)),
+              "hsr_moments_reduce_solve")
+    return ws.moments, ws.coeffs
 
 
 def poly_moments(x, y, deg: int, ws: MomentWorkspace, mask=None, min_x=_NEG_INF, min_y=_NEG_INF,
-                 lohi_x=None, lohi_y=None):
-    """K2 on materialised (nb, npix) float32 planes -> moments (nb, 3deg+2) float64 on the device."""
+                 lohi_x=None, lohi_y=None, layout: str = PLANAR, nb: Optional[int] = None):
+    """K2 on materialised float32 images -> moments (nb, 3deg+2) float64 on the device."""
     torch = nat.require_gpu()
     lib = nat.load()
-    nb, npix = x.shape
-    for t in (x, y):
-        if not (t.dtype == torch.float32 and t.is_cuda and t.stride(1) == 1 and tuple(t.shape) == (nb, npix)):
-            raise ValueError("x and y must be (nb, npix) float32 on the GPU")
+    xbs, xps, n, npix = _img(x, layout, nb)
+    ybs, yps, _, ny = _img(y, layout, n)
+    if ny != npix or x.dtype != torch.float32 or y.dtype != torch.float32:
+        raise ValueError("x and y must be float32 images of the same shape")
     slots = C.c_int32(0)
-    nat.check(lib.hsr_poly_moments(_ptr(x), x.stride(0), _ptr(y), y.stride(0), _ptr(mask), npix, nb, deg,
+    nat.check(lib.hsr_poly_moments(_ptr(x), xbs, xps, _ptr(y), ybs, yps, _ptr(mask), npix, n, deg,
                                    min_x, min_y, _ptr(lohi_x), _ptr(lohi_y), _ptr(ws.partials),
                                    C.byref(slots), _stream(torch)), "hsr_poly_moments")
-    nat.check(lib.hsr_moments_reduce(_ptr(ws.partials), slots.value, nb, deg, _ptr(ws.moments),
-                                     _stream(torch)), "hsr_moments_reduce")
-    return ws.moments
+    ws.slots = slots.value
+    return moments_reduce(ws)
 
 
 def poly_moments_f64(x, y, deg: int, ws: MomentWorkspace):
@@ -204,14 +266,15 @@ def poly_moments_f64(x, y, deg: int, ws: MomentWorkspace):
     lib = nat.load()
     nb, npix = x.shape
     for t in (x, y):
-        if not (t.dtype == torch.float64 and t.is_cuda and t.stride(1) == 1 and tuple(t.shape) == (nb, npix)):
+        if not (t.dtype == torch.float64 and t.is_cuda and (npix == 1 or t.stride(1) == 1) and tuple(t.shape) == (nb, npix)):
             raise ValueError("x and y must be (nb, n) float64 on the GPU")
+    xs = x.stride(0) if nb > 1 else max(int(x.stride(0)), npix)
+    ys = y.stride(0) if nb > 1 else max(int(y.stride(0)), npix)
     slots = C.c_int32(0)
-    nat.check(lib.hsr_poly_moments_f64(_ptr(x), x.stride(0), _ptr(y), y.stride(0), npix, nb, deg,
+    nat.check(lib.hsr_poly_moments_f64(_ptr(x), xs, _ptr(y), ys, npix, nb, deg,
                                        _ptr(ws.partials), C.byref(slots), _stream(torch)), "hsr_poly_moments_f64")
-    nat.check(lib.hsr_moments_reduce(_ptr(ws.partials), slots.value, nb, deg, _ptr(ws.moments),
-                                     _stream(torch)), "hsr_moments_reduce")
-    return ws.moments
+    ws.slots = slots.value
+    return moments_reduce(ws)
 
 
 def poly_solve(moments, deg: int, min_count: int, out=None):
@@ -236,73 +299,53 @@ def poly_solve_host(moments: np.ndarray, deg: int, min_count: int) -> np.ndarray
     return out
 
 
-def poly_apply(x, coeffs, mask=None, lohi=None, clip=True, layout=nat.LAYOUT_PLANAR, out=None):
-    """K3.  planar: x (nb, npix); interleaved: x (npix, nb).  float32 in, float32 out."""
+def poly_apply(x, coeffs, mask=None, lohi=None, clip=True, layout: str = PLANAR, out=None,
+               nb: Optional[int] = None):
+    """K3.  float32 image in, float32 image out (same layout).  ``coeffs`` None: stretch/clip only."""
     torch = nat.require_gpu()
     lib = nat.load()
-    if layout == nat.LAYOUT_PLANAR:
-        nb, npix = x.shape
-        if x.stride(1) != 1:
-            raise ValueError("planar x must have unit pixel stride")
-        xs = x.stride(0)
-    else:
-        npix, nb = x.shape
-        if not x.is_contiguous():
-            raise ValueError("interleaved x must be contiguous")
-        xs = 0
-    deg = coeffs.shape[1] - 1
-    if coeffs.shape[0] != nb or coeffs.dtype != torch.float64 or not coeffs.is_contiguous():
-        raise ValueError("coeffs must be a contiguous (nb, deg+1) float64 tensor")
+    xbs, xps, n, npix = _img(x, layout, nb)
+    deg = 0
+    if coeffs is not None:
+        deg = coeffs.shape[1] - 1
+        if coeffs.shape[0] != n or coeffs.dtype != torch.float64 or not coeffs.is_contiguous():
+            raise ValueError("coeffs must be a contiguous (nb, deg+1) float64 tensor")
     o = out if out is not None else torch.empty_like(x, memory_format=torch.contiguous_format)
-    os_ = o.stride(0) if layout == nat.LAYOUT_PLANAR else 0
-    nat.check(lib.hsr_poly_apply(_ptr(x), xs, _ptr(mask), _ptr(coeffs), nb, deg, npix, _ptr(lohi),
-                                 1 if clip else 0, layout, _ptr(o), os_, _stream(torch)), "hsr_poly_apply")
+    obs, ops, _, _ = _img(o, layout, n)
+    nat.check(lib.hsr_poly_apply(_ptr(x), xbs, xps, _ptr(mask), _ptr(coeffs), n, deg, npix, _ptr(lohi),
+                                 1 if clip else 0, _ptr(o), obs, ops, _stream(torch)), "hsr_poly_apply")
     return o
 
 
-def poly_apply_stretch_only(x, lohi, layout=nat.LAYOUT_PLANAR, out=None):
+def poly_apply_stretch_only(x, lohi, layout: str = PLANAR, out=None, nb: Optional[int] = None):
     """float32(clip((x - lo)/(hi - lo + 1e-12), 0, 1)) per channel: K3 without a polynomial."""
-    torch = nat.require_gpu()
-    lib = nat.load()
-    if layout == nat.LAYOUT_PLANAR:
-        nb, npix = x.shape
-        xs = x.stride(0)
-    else:
-        npix, nb = x.shape
-        xs = 0
-    o = out if out is not None else torch.empty_like(x, memory_format=torch.contiguous_format)
-    os_ = o.stride(0) if layout == nat.LAYOUT_PLANAR else 0
-    nat.check(lib.hsr_poly_apply(_ptr(x), xs, None, None, nb, 0, npix, _ptr(lohi), 1, layout, _ptr(o), os_,
-                                 _stream(torch)), "hsr_poly_apply(stretch)")
-    return o
+    return poly_apply(x, None, None, lohi, True, layout, out, nb)
 
 
-def percentile_limits(x, mask=None, pmin=2.0, pmax=98.0, layout=nat.LAYOUT_PLANAR):
+def percentile_limits(x, mask=None, pmin=2.0, pmax=98.0, layout: str = PLANAR, nb: Optional[int] = None):
     """Exact np.percentile(vals[mask], [pmin, pmax]) per channel -> (nb, 2) float64 on the device."""
     torch = nat.require_gpu()
     lib = nat.load()
-    if layout == nat.LAYOUT_PLANAR:
-        nb, npix = x.shape
-        xs = x.stride(0)
-    else:
-        npix, nb = x.shape
-        xs = 0
-    work = torch.empty(lib.hsr_percentile_work_bytes(nb) // 8 + 1, dtype=torch.int64, device=x.device)
-    lohi = torch.empty((nb, 2), dtype=torch.float64, device=x.device)
-    nat.check(lib.hsr_percentile_limits(_ptr(x), xs, layout, _ptr(mask), npix, nb, float(pmin), float(pmax),
+    xbs, xps, n, npix = _img(x, layout, nb)
+    work = torch.empty(lib.hsr_percentile_work_bytes(n) // 8 + 1, dtype=torch.int64, device=x.device)
+    lohi = torch.empty((n, 2), dtype=torch.float64, device=x.device)
+    nat.check(lib.hsr_percentile_limits(_ptr(x), xbs, xps, _ptr(mask), npix, n, float(pmin), float(pmax),
                                         _ptr(work), _ptr(lohi), _stream(torch)), "hsr_percentile_limits")
     return lohi
 
 
-def valid_mask(x, pos_band: int = -1, y=None, mask_in=None):
+def valid_mask(x, pos_band: int = -1, y=None, mask_in=None, layout: str = PLANAR, nbx: Optional[int] = None,
+               nby: Optional[int] = None):
     """mask[p] = all x bands finite && x[pos_band] > 0 && all y bands finite (poly_regression.py:106,118)."""
     torch = nat.require_gpu()
     lib = nat.load()
-    nbx, npix = x.shape
+    xbs, xps, nx, npix = _img(x, layout, nbx)
+    ybs = yps = ny = 0
+    if y is not None:
+        ybs, yps, ny, _ = _img(y, layout, nby)
     out = torch.empty(npix, dtype=torch.uint8, device=x.device)
-    nat.check(lib.hsr_valid_mask(_ptr(x), x.stride(0), nbx, pos_band, _ptr(y), y.stride(0) if y is not None else 0,
-                                 y.shape[0] if y is not None else 0, _ptr(mask_in), npix, _ptr(out),
-                                 _stream(torch)), "hsr_valid_mask")
+    nat.check(lib.hsr_valid_mask(_ptr(x), xbs, xps, nx, pos_band, _ptr(y), ybs, yps, ny, _ptr(mask_in), npix,
+                                 _ptr(out), _stream(torch)), "hsr_valid_mask")
     return out
 
 

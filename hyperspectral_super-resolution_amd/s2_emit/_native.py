@@ -20,8 +20,8 @@ HSR_MAX_APPLY_DEG = 8
 HSR_MAX_SPECTRAL = 560
 HSR_TILE_PIXELS = 64
 HSR_MAX_PARTIALS = 2048
-LAYOUT_PLANAR = 0
-LAYOUT_INTERLEAVED = 1
+PLANAR = "planar"        # band-major planes: tensor (nb, npix), unit pixel stride
+PIXMAJOR = "pixmajor"    # pixel-major / band-last: tensor (npix, row) with row >= nb, unit band stride
 
 
 class HsrUnavailable(RuntimeError):
@@ -42,19 +42,22 @@ SIGNATURES = {
     "hsr_moment_count": (C.c_int, [_i32]),
     "hsr_partial_slots": (C.c_int, [_i64]),
     "hsr_partials_bytes": (C.c_size_t, [_i32, _i32]),
-    "hsr_srf_integrate": (C.c_int, [_vp, _i64, _i32, _vp, _pi32, _pi32, _i32, _vp, _i64, _vp]),
-    "hsr_srf_integrate_moments": (C.c_int, [_vp, _i64, _i32, _vp, _pi32, _pi32, _i32, _vp, _i64,
-                                            _vp, _i64, _vp, _f32, _f32, _i32, _vp, _pi32, _vp]),
-    "hsr_poly_moments": (C.c_int, [_vp, _i64, _vp, _i64, _vp, _i64, _i32, _i32, _f32, _f32, _vp, _vp,
+    "hsr_srf_integrate": (C.c_int, [_vp, _i64, _i32, _vp, _pi32, _pi32, _i32, _vp, _i64, _i64, _vp]),
+    "hsr_srf_integrate_moments": (C.c_int, [_vp, _i64, _i32, _vp, _pi32, _pi32, _i32, _vp, _i64, _i64,
+                                            _vp, _i64, _i64, _vp, _f32, _f32, _i32, _vp, _pi32, _vp]),
+    "hsr_poly_moments": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i32, _i32, _f32, _f32, _vp, _vp,
                                    _vp, _pi32, _vp]),
     "hsr_poly_moments_f64": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _pi32, _vp]),
     "hsr_moments_reduce": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "hsr_poly_solve": (C.c_int, [_vp, _i32, _i32, _i64, _vp, _vp]),
+    "hsr_moments_reduce_solve": (C.c_int, [_vp, _i32, _i32, _i32, _i64, _vp, _vp, _vp]),
     "hsr_poly_solve_host": (C.c_int, [C.POINTER(_f64), _i32, _i32, _i64, C.POINTER(_f64)]),
-    "hsr_poly_apply": (C.c_int, [_vp, _i64, _vp, _vp, _i32, _i32, _i64, _vp, _i32, _i32, _vp, _i64, _vp]),
+    "hsr_poly_apply": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i32, _i32, _i64, _vp, _i32, _vp, _i64, _i64, _vp]),
     "hsr_percentile_work_bytes": (C.c_size_t, [_i32]),
-    "hsr_percentile_limits": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _f64, _f64, _vp, _vp, _vp]),
-    "hsr_valid_mask": (C.c_int, [_vp, _i64, _i32, _i32, _vp, _i64, _i32, _vp, _i64, _vp, _vp]),
+    "hsr_percentile_limits": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i32, _f64, _f64, _vp, _vp, _vp]),
+    "hsr_valid_mask": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp]),
+    "hsr_set_srf_tile": (C.c_int, [_i32]),
+    "hsr_get_srf_tile": (C.c_int, []),
     "hsr_probe_read": (C.c_int, [_vp, _i64, _vp, _vp]),
 }
 

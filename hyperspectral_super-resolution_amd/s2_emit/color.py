@@ -42,12 +42,12 @@ def robust_norm_rgb(img: np.ndarray, mask: np.ndarray, pmin: float = 2, pmax: fl
     return y
 
 
-def device_percentile_stretch(x, mask=None, pmin=2, pmax=98, layout=nat.LAYOUT_INTERLEAVED, lohi=None):
-    """Device form: x float32 (npix, C) interleaved or (C, npix) planar, mask uint8 (npix,).
+def device_percentile_stretch(x, mask=None, pmin=2, pmax=98, layout=nat.PIXMAJOR, lohi=None, nb=None):
+    """Device form: x float32 (npix, C) pixel-major or (C, npix) planar, mask uint8 (npix,).
     Returns (stretched float32 tensor, lohi (C, 2) float64 tensor); no host synchronisation."""
     if lohi is None:
-        lohi = eng.percentile_limits(x, mask, pmin, pmax, layout)
-    return eng.poly_apply_stretch_only(x, lohi, layout), lohi
+        lohi = eng.percentile_limits(x, mask, pmin, pmax, layout, nb)
+    return eng.poly_apply_stretch_only(x, lohi, layout, nb=nb), lohi
 
 
 def apply_shared_percentile_stretch(img, mask, pmin: float = 2, pmax: float = 98):
@@ -75,7 +75,7 @@ def apply_shared_percentile_stretch(img, mask, pmin: float = 2, pmax: float = 98
         x3 = x[..., :3].contiguous().reshape(-1, 3)
     if int(m.numel()) != H * W:
         raise IndexError("boolean index did not match indexed array: mask must be (H,W)")
-    y3, _ = device_percentile_stretch(x3, m, pmin, pmax, nat.LAYOUT_INTERLEAVED)
+    y3, _ = device_percentile_stretch(x3, m, pmin, pmax, nat.PIXMAJOR)
     if Cc == 3:
         out = y3.reshape(H, W, 3)
     else:

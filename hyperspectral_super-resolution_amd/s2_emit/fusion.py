@@ -29,10 +29,23 @@ COEFF_SYNC_MODES = ("local", "allreduce", "broadcast")
 @dataclass
 class FusionOutput:
     names: List[str]           # supported bands, srf_dict order
-    pseudo: object             # (nb, H*W) float32 device tensor - pseudo-S2 planes (K1)
+    pseudo: object             # pseudo-S2 image (K1), float32 device tensor in ``layout``
     moments: object            # (nb, 3deg+2) float64 device tensor (after the exchange, if any)
     coeffs: object             # (nb, deg+1) float64 device tensor, highest power first
-    matched: object            # (nb, H*W) float32 device tensor (K3)
+    matched: object            # matched image (K3), float32 device tensor in ``layout``
+    layout: str = nat.PIXMAJOR  # PIXMAJOR: (npix, row>=nb) band-last;  PLANAR: (nb, npix)
+
+    def band(self, which, image="matched"):
+        """(npix,) view of one band of ``pseudo`` / ``matched`` (by name or index)."""
+        i = self.names.index(which) if isinstance(which, str) else int(which)
+        img = getattr(self, image)
+        return img[i] if self.layout == nat.PLANAR else img[:, i]
+
+    def planes(self, image="matched"):
+        """(nb, npix) band-major tensor of ``pseudo`` / ``matched`` (a view for PLANAR, a copy otherwise)."""
+        img = getattr(self, image)
+        nb = len(self.names)
+        return img if self.layout == nat.PLANAR else img[:, :nb].t().contiguous()
 
 
 def exchange_moments(moments, coeffs_solver, group=None, mode: str = "allreduce"):
@@ -66,7 +79,7 @@ class SpectralFusion:
 
     def __init__(self, emit_w, srf_dict, good_mask=None, deg: int = 3, min_valid: Optional[float] = 0.0,
                  min_count: int = 50, clip: bool = True, apply_mask: bool = False, device=None,
-                 group=None, coeff_sync: str = "allreduce"):
+                 group=None, coeff_sync: str = "allreduce", layout: str = nat.PIXMAJOR):
         torch = nat.require_gpu()
         if not 1 <= deg <= nat.HSR_MAX_DEG:
             raise ValueError(f"deg must be in [1, {nat.HSR_MAX_DEG}], got {deg}")
@@ -81,6 +94,9 @@ class SpectralFusion:
         self.deg, self.min_count, self.clip, self.apply_mask = deg, int(min_count), bool(clip), bool(apply_mask)
         self.min_valid = float("-inf") if min_valid is None else float(min_valid)
         self.group, self.coeff_sync = group, coeff_sync
+        if layout not in (nat.PIXMAJOR, nat.PLANAR):
+            raise ValueError(f"layout must be {nat.PIXMAJOR!r} or {nat.PLANAR!r}")
+        self.layout = layout
         self.ws = eng.MomentWorkspace(self.device, self.table.nb, deg)
         self.table.device_weights(self.device)
         self._buf: Dict[int, Tuple[object, object]] = {}
@@ -93,29 +109,56 @@ class SpectralFusion:
         torch = nat.require_gpu()
         if npix not in self._buf:
             nb = self.table.nb
-            self._buf[npix] = (torch.empty((nb, npix), dtype=torch.float32, device=self.device),
-                               torch.empty((nb, npix), dtype=torch.float32, device=self.device))
+            self._buf[npix] = (eng.alloc_image(torch, nb, npix, self.layout, self.device),
+                               eng.alloc_image(torch, nb, npix, self.layout, self.device))
         return self._buf[npix]
+
+    def _exchanges(self) -> bool:
+        import torch.distributed as dist
+        if self.coeff_sync == "local" or not (dist.is_available() and dist.is_initialized()):
+            return False
+        return dist.get_world_size(self.group) > 1
 
     def _solve(self, moments):
         return eng.poly_solve(moments, self.deg, self.min_count, out=self.ws.coeffs)
 
-    def step(self, cube, real_planes, mask=None, reuse_buffers: bool = True, k1_events=None) -> FusionOutput:
+    def _real_image(self, real, npix):
+        """Accept the real-S2 target as (H,W,C>=nb)/(npix,C) band-last or (nb,H,W)/(nb,npix) band-major."""
+        nb = self.table.nb
+        if real.dim() == 3:
+            if real.shape[0] * real.shape[1] == npix and real.shape[2] >= nb:
+                return real.reshape(npix, real.shape[2]), nat.PIXMAJOR
+            if real.shape[0] == nb and real.shape[1] * real.shape[2] == npix:
+                return real.reshape(nb, npix), nat.PLANAR
+        elif real.dim() == 2:
+            if real.shape[0] == npix and real.shape[1] >= nb and not (real.shape == (nb, npix) and self.layout == nat.PLANAR):
+                return real, nat.PIXMAJOR
+            if tuple(real.shape) == (nb, npix):
+                return real, nat.PLANAR
+        raise ValueError(f"real S2 target of shape {tuple(real.shape)} matches neither (npix,{nb}+) nor ({nb},npix)")
+
+    def step(self, cube, real, mask=None, reuse_buffers: bool = True, k1_events=None) -> FusionOutput:
         """One pass of the hot path over one tile.
-        cube (H,W,B) or (npix,B) float32 GPU tensor; real_planes (nb,H,W)/(nb,npix) float32;
-        mask optional uint8 (npix) validity (1 = use)."""
+        cube (H,W,B) or (npix,B) float32 GPU tensor; real: real-S2 target, band-last (H,W,C>=nb) /
+        (npix,C) [fast] or band-major (nb,H,W) / (nb,npix); mask optional uint8 (npix), 1 = use."""
         torch = nat.require_gpu()
         npix = cube.numel() // cube.shape[-1]
+        real, real_layout = self._real_image(real, npix)
         if reuse_buffers:
             pseudo, matched = self._buffers(npix)
         else:
             pseudo = matched = None
-        pseudo, moments = eng.srf_integrate_moments(cube, self.table, real_planes, self.deg, self.ws, mask,
-                                                    self.min_valid, self.min_valid, out=pseudo, events=k1_events)
-        moments, coeffs = exchange_moments(moments, self._solve, self.group, self.coeff_sync)
+        pseudo, _ = eng.srf_integrate_moments(cube, self.table, real, self.deg, self.ws, mask,
+                                              self.min_valid, self.min_valid, out=pseudo, events=k1_events,
+                                              reduce=False, layout=self.layout, real_layout=real_layout)
+        if self._exchanges():
+            moments = eng.moments_reduce(self.ws)
+            moments, coeffs = exchange_moments(moments, self._solve, self.group, self.coeff_sync)
+        else:                       # no exchange between reduce and solve: one fused launch
+            moments, coeffs = eng.moments_reduce_solve(self.ws, self.min_count)
         matched = eng.poly_apply(pseudo, coeffs, mask if self.apply_mask else None, None, self.clip,
-                                 nat.LAYOUT_PLANAR, out=matched)
-        return FusionOutput(self.names, pseudo, moments, coeffs, matched)
+                                 self.layout, out=matched, nb=self.table.nb)
+        return FusionOutput(self.names, pseudo, moments, coeffs, matched, self.layout)
 
 
 def fuse_pair(R, emit_w, srf_dict, good_mask, real_s2: Dict[str, np.ndarray], deg: int = 3,
@@ -129,7 +172,7 @@ def fuse_pair(R, emit_w, srf_dict, good_mask, real_s2: Dict[str, np.ndarray], de
     cube = torch.from_numpy(np.ascontiguousarray(R, dtype=np.float32)).to(plan.device)
     real = torch.from_numpy(np.stack([np.asarray(real_s2[b], dtype=np.float32) for b in plan.names])).to(plan.device)
     out = plan.step(cube, real.reshape(len(plan.names), -1), reuse_buffers=False)
-    ps, co, ma = out.pseudo.cpu().numpy(), out.coeffs.cpu().numpy(), out.matched.cpu().numpy()
+    ps, co, ma = out.planes("pseudo").cpu().numpy(), out.coeffs.cpu().numpy(), out.planes("matched").cpu().numpy()
     pseudo = {b: None for b in plan.table.names}
     coeffs = {b: None for b in plan.table.names}
     matched = {b: None for b in plan.table.names}
@@ -147,8 +190,8 @@ def calibrate_pseudo_to_real_linear(pseudo_stack, real_stack, valid_mask, min_va
     y = torch.from_numpy(np.ascontiguousarray(real_stack, dtype=np.float32)).cuda().reshape(nb, -1)
     m = torch.from_numpy(np.ascontiguousarray(valid_mask, dtype=np.bool_).view(np.uint8)).cuda().reshape(-1)
     ws = eng.MomentWorkspace(x.device, nb, 1)
-    mom = eng.poly_moments(x, y, 1, ws, m, float(min_valid), float(min_valid))
+    mom = eng.poly_moments(x, y, 1, ws, m, float(min_valid), float(min_valid), layout=nat.PLANAR)
     coeffs = eng.poly_solve(mom, 1, 50)
-    corrected = eng.poly_apply(x, coeffs, None, None, clip=False)
+    corrected = eng.poly_apply(x, coeffs, None, None, clip=False, layout=nat.PLANAR)
     params = [(float(a), float(b)) for a, b in coeffs.cpu().numpy()]
     return corrected.reshape(nb, H, W).cpu().numpy(), params

@@ -108,7 +108,7 @@ def apply_poly_rgb(rgb, coeffs, mask=None):
     if H * W == 0:
         out = x.clone()
     else:
-        out = eng.poly_apply(x.reshape(-1, Cc), cd, m, None, True, nat.LAYOUT_INTERLEAVED).reshape(H, W, Cc)
+        out = eng.poly_apply(x.reshape(-1, Cc), cd, m, None, True, nat.PIXMAJOR).reshape(H, W, Cc)
         if Cc != C_:
             out[..., C_:] = torch.clamp(x[..., C_:], 0.0, 1.0)
     return out if as_torch else out.cpu().numpy()

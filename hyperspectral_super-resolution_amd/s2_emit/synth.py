@@ -61,7 +61,7 @@ def pseudo_s2_srf_integral(
     if H * W == 0:
         planes = torch.empty((table.nb, 0), dtype=torch.float32, device=cube.device)
     else:
-        planes = eng.srf_integrate(cube, table)
+        planes = eng.srf_integrate(cube, table, layout=nat.PLANAR)
     planes = planes.reshape(table.nb, H, W)
     if as_torch:
         for i, band in enumerate(table.supported):

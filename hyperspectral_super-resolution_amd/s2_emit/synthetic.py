@@ -52,8 +52,9 @@ class DeviceProblem:
     good_mask: np.ndarray
     srf: Dict[str, Tuple[np.ndarray, np.ndarray]]
     cube: object        # (H, W, B) float32 on the GPU
-    real: object        # (nb, H, W) float32 on the GPU (supported bands, srf order)
+    real: object        # (H, W, row) float32 on the GPU, band-last, row = nb padded to a multiple of 4
     names: list
+    real_planes: object = None   # (nb, H, W) band-major copy (tests)
 
 
 def device_problem(H: int, W: int, B: int = 285, deg: int = 3, seed: int = 0, device="cuda") -> DeviceProblem:
@@ -76,7 +77,7 @@ def device_problem(H: int, W: int, B: int = 285, deg: int = 3, seed: int = 0, de
     cube.clamp_(-0.01, 0.6)
     cube = cube.reshape(H, W, B).contiguous()
     table = eng.build_srf_table(w, srf, good)
-    pseudo = eng.srf_integrate(cube, table)
+    pseudo = eng.srf_integrate(cube, table, layout=nat.PLANAR)
     nb = table.nb
     rs = np.random.default_rng(seed + 1)
     g = torch.from_numpy((0.8 + 0.4 * rs.random(nb)).astype(np.float32)).to(device)[:, None]
@@ -85,4 +86,8 @@ def device_problem(H: int, W: int, B: int = 285, deg: int = 3, seed: int = 0, de
     real = g * pseudo.clamp(min=1e-6) ** gam + o
     real.add_(torch.randn(real.shape, generator=gen, device=device, dtype=torch.float32), alpha=0.01)
     real.clamp_(0.0, 1.0)
-    return DeviceProblem(w, good, srf, cube, real.reshape(nb, H, W).contiguous(), list(table.supported))
+    row = eng.padded_row(nb)
+    real_bl = torch.zeros((H * W, row), dtype=torch.float32, device=device)
+    real_bl[:, :nb] = real.t()
+    return DeviceProblem(w, good, srf, cube, real_bl.reshape(H, W, row), list(table.supported),
+                         real.reshape(nb, H, W).contiguous())

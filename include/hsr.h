@@ -12,7 +12,7 @@
  *     synchronises the device, and is safe to capture in a hipGraph.
  *   - every call is stream ordered on `stream` (a hipStream_t passed as void*; NULL = default).
  *   - return value: HSR_OK or an error code; hsr_last_error() gives the thread-local message.
- *   - planes are band-major: plane b of pixel p lives at base[b * plane_stride + p].
+ *   - images use (band_stride, pixel_stride) addressing, see below; both layouts are accepted everywhere.
  *   - moments of band b for degree d: M = 3d+2 doubles, [S_0..S_2d | T_0..T_d] with
  *     S_k = sum x^k, T_j = sum x^j y over the valid pixels (S_0 = count).
  */
@@ -40,8 +40,12 @@ extern "C" {
 #define HSR_TILE_PIXELS 64     /* pixels staged per LDS tile                       */
 #define HSR_MAX_PARTIALS 2048  /* upper bound of per-launch partial-sum slots      */
 
-#define HSR_LAYOUT_PLANAR 0      /* (C, N): element (c, p) at c*stride + p         */
-#define HSR_LAYOUT_INTERLEAVED 1 /* (N, C): element (c, p) at p*C + c   (H,W,3)    */
+/* Image-like tensors (pseudo-S2, real S2, matched output) are addressed with two strides, in elements:
+ *   element (band b, pixel p) lives at base[b * band_stride + p * pixel_stride]
+ *   band-major planes (C, N):          band_stride = plane stride (>= N), pixel_stride = 1
+ *   pixel-major / band-last (N, C):    band_stride = 1, pixel_stride = row stride (>= C)
+ * Pixel-major is the layout of the cube itself and of the reference's (H, W, C) images, and the fast
+ * one on the fused path: K1 then writes one contiguous slab per tile instead of C scattered segments. */
 
 typedef void* hsr_stream_t;
 
@@ -64,25 +68,25 @@ size_t hsr_partials_bytes(int32_t nb, int32_t deg);
  *   wn_dev     (nb, B) float32 dense normalised trapezoid weights (host builds them in float64
  *              from np.interp exactly as synth.py:33-35,42-43 and rounds once)
  *   k0, klen   host arrays [nb]: support [k0, k0+klen) of each row of wn (zeros outside)
- *   planes_dev (nb, plane_stride) float32 out
+ *   out_dev    float32 out, element (b, p) at out_dev[b * out_bs + p * out_ps]
  */
 int hsr_srf_integrate(const float* cube_dev, int64_t npix, int32_t B,
                       const float* wn_dev, const int32_t* k0, const int32_t* klen, int32_t nb,
-                      float* planes_dev, int64_t plane_stride, hsr_stream_t stream);
+                      float* out_dev, int64_t out_bs, int64_t out_ps, hsr_stream_t stream);
 
 /* ---- K1+K2 fused: SRF integration and Vandermonde moments in one pass over the cube --------
  * K1 as above and, in the same pass, the per-band power sums that np.polyfit's normal equations
  * need (s2_emit/poly_regression.py:59-60; all-valid-pixel flavour of
  * calibrate_pseudo_to_real_linear, Pairs_EMIT_S2_demo-2.ipynb cell 72 raw lines 4484-4510):
  * pixel p counts for band b iff mask[p] (if given) && finite(x) && finite(y) && x > min_x && y > min_y,
- * with x = planes[b][p] (float32) and y = real_dev[b][p]; sums are float64.
+ * with x = out[b][p] (float32) and y = real_dev[b * real_bs + p * real_ps]; sums are float64.
  *   partials_dev  workspace of hsr_partials_bytes(nb, deg); slot layout [nb][3deg+2][slots]
- *   returns the slot count used in *slots_out (== hsr_partial_slots(npix)).
+ *   returns the slot count used in *slots_out (a function of npix and the tile setting only).
  */
 int hsr_srf_integrate_moments(const float* cube_dev, int64_t npix, int32_t B,
                               const float* wn_dev, const int32_t* k0, const int32_t* klen, int32_t nb,
-                              float* planes_dev, int64_t plane_stride,
-                              const float* real_dev, int64_t real_stride, const uint8_t* mask_dev,
+                              float* out_dev, int64_t out_bs, int64_t out_ps,
+                              const float* real_dev, int64_t real_bs, int64_t real_ps, const uint8_t* mask_dev,
                               float min_x, float min_y, int32_t deg,
                               double* partials_dev, int32_t* slots_out, hsr_stream_t stream);
 
@@ -92,7 +96,7 @@ int hsr_srf_integrate_moments(const float* cube_dev, int64_t npix, int32_t B,
  * (nb x 2 doubles: lo, hi) is given, the value is first stretched as color.py:33 does:
  * float32(clip((v - lo) / (hi - lo + 1e-12), 0, 1)) and validity is tested on the raw value.
  */
-int hsr_poly_moments(const float* x_dev, int64_t x_stride, const float* y_dev, int64_t y_stride,
+int hsr_poly_moments(const float* x_dev, int64_t x_bs, int64_t x_ps, const float* y_dev, int64_t y_bs, int64_t y_ps,
                      const uint8_t* mask_dev, int64_t npix, int32_t nb, int32_t deg,
                      float min_x, float min_y, const double* lohi_x_dev, const double* lohi_y_dev,
                      double* partials_dev, int32_t* slots_out, hsr_stream_t stream);
@@ -116,6 +120,11 @@ int hsr_moments_reduce(const double* partials_dev, int32_t slots, int32_t nb, in
  */
 int hsr_poly_solve(const double* moments_dev, int32_t nb, int32_t deg, int64_t min_count,
                    double* coeffs_dev, hsr_stream_t stream);
+/* hsr_moments_reduce + hsr_poly_solve in one launch (single-GPU fast path: no exchange between them);
+ * bit-identical to the two separate calls. */
+int hsr_moments_reduce_solve(const double* partials_dev, int32_t slots, int32_t nb, int32_t deg,
+                             int64_t min_count, double* moments_dev, double* coeffs_dev,
+                             hsr_stream_t stream);
 /* Host twin (same code compiled for the CPU) for callers that hold the moments on the host. */
 int hsr_poly_solve_host(const double* moments, int32_t nb, int32_t deg, int64_t min_count,
                         double* coeffs);
@@ -126,12 +135,11 @@ int hsr_poly_solve_host(const double* moments, int32_t nb, int32_t deg, int64_t 
  * (NaN stays NaN).  Optional stretch first (lohi_dev: nb x 2 doubles, color.py:33).
  * coeffs_dev == NULL: no polynomial (stretch and/or clip only = apply_shared_percentile_stretch).
  * deg in [0, HSR_MAX_APPLY_DEG].
- * layout: HSR_LAYOUT_PLANAR (stride = plane stride) or HSR_LAYOUT_INTERLEAVED ((N, nb), stride ignored).
  */
-int hsr_poly_apply(const float* x_dev, int64_t x_stride, const uint8_t* mask_dev,
+int hsr_poly_apply(const float* x_dev, int64_t x_bs, int64_t x_ps, const uint8_t* mask_dev,
                    const double* coeffs_dev, int32_t nb, int32_t deg, int64_t npix,
-                   const double* lohi_dev, int32_t clip, int32_t layout,
-                   float* out_dev, int64_t out_stride, hsr_stream_t stream);
+                   const double* lohi_dev, int32_t clip,
+                   float* out_dev, int64_t out_bs, int64_t out_ps, hsr_stream_t stream);
 
 /* ---- a4: exact masked percentiles (np.percentile, linear interpolation) ------------------------
  * color.py:31-32: per channel the (pmin, pmax) percentiles of the masked values, exact order
@@ -139,7 +147,7 @@ int hsr_poly_apply(const float* x_dev, int64_t x_stride, const uint8_t* mask_dev
  *   work_dev: workspace of hsr_percentile_work_bytes(nb) bytes;  lohi_dev: (nb, 2) doubles out.
  */
 size_t hsr_percentile_work_bytes(int32_t nb);
-int hsr_percentile_limits(const float* x_dev, int64_t x_stride, int32_t layout,
+int hsr_percentile_limits(const float* x_dev, int64_t x_bs, int64_t x_ps,
                           const uint8_t* mask_dev, int64_t npix, int32_t nb,
                           double pmin, double pmax, void* work_dev, double* lohi_dev,
                           hsr_stream_t stream);
@@ -147,10 +155,16 @@ int hsr_percentile_limits(const float* x_dev, int64_t x_stride, int32_t layout,
 /* Validity mask of the pipeline (poly_regression.py:106,118): mask[p] = all bands of x finite
  * && x[pos_band][p] > 0 (pos_band < 0: skip) && all bands of y finite (y_dev may be NULL),
  * optionally AND-ed with mask_in_dev. */
-int hsr_valid_mask(const float* x_dev, int64_t x_stride, int32_t nbx, int32_t pos_band,
-                   const float* y_dev, int64_t y_stride, int32_t nby,
+int hsr_valid_mask(const float* x_dev, int64_t x_bs, int64_t x_ps, int32_t nbx, int32_t pos_band,
+                   const float* y_dev, int64_t y_bs, int64_t y_ps, int32_t nby,
                    const uint8_t* mask_in_dev, int64_t npix, uint8_t* mask_out_dev,
                    hsr_stream_t stream);
+
+/* ---- tuning --------------------------------------------------------------------------------------
+ * LDS tile of K1: 64 pixels (512-thread workgroups, 2 per CU) or 32 pixels (256-thread workgroups,
+ * 4 per CU).  Process-wide; results are identical up to the summation tree of the moments. */
+int hsr_set_srf_tile(int32_t pixels);
+int hsr_get_srf_tile(void);
 
 /* ---- diagnostics -------------------------------------------------------------------------------
  * Pure streaming read of `bytes` bytes (16 B per lane, coalesced) folded into sink_dev[64]: the

@@ -89,6 +89,7 @@ def test_k1_edge_semantics_golden_g2(torch_gpu):
 def test_k1_vs_oracle_shapes(torch_gpu, H, W, B, offset):
     torch = torch_gpu
     from s2_emit import _engine as eng
+    from s2_emit import _native as nat
     rng = np.random.default_rng(H * 1000 + W + B)
     w = np.linspace(381.0, 2493.0, B).astype(np.float32)
     good = np.ones(B, bool)
@@ -106,6 +107,16 @@ def test_k1_vs_oracle_shapes(torch_gpu, H, W, B, offset):
     assert [k for k, v in ref.items() if v is not None] == table.supported
     for i, k in enumerate(table.supported):
         assert _rel_err(planes[i], ref[k]) < 2e-6, (k, H, W, B)
+    # pixel-major (band-last) output: the LDS-staged slab path must give the same bits as the planes
+    pm = eng.srf_integrate(cube, table, layout=nat.PIXMAJOR)
+    assert pm.shape == (H * W, eng.padded_row(table.nb))
+    assert torch.equal(pm[:, :table.nb].t().contiguous().view(torch.int32),
+                       torch.from_numpy(planes.reshape(table.nb, -1)).cuda().view(torch.int32))
+    for tile in (32, 64):      # both tile geometries
+        nat.load().hsr_set_srf_tile(tile)
+        p2 = eng.srf_integrate(cube, table).cpu().numpy().reshape(table.nb, H, W)
+        assert np.array_equal(p2.view(np.int32), planes.view(np.int32))
+    nat.load().hsr_set_srf_tile(64)
 
 
 def test_k1_torch_input_zero_copy_and_many_bands(torch_gpu):
@@ -220,6 +231,62 @@ def test_k3_planar_vec_and_scalar_paths(torch_gpu):
         np.testing.assert_array_equal(got2, ref2)
 
 
+def test_pixel_major_paths_match_planar_bits(torch_gpu):
+    """K2 / K3 / mask / percentiles on band-last rows (incl. 13 bands padded to 16) == band-major results."""
+    torch = torch_gpu
+    from s2_emit import _engine as eng
+    from s2_emit import _native as nat
+    rng = np.random.default_rng(31)
+    for nb, npix in ((13, 5000), (12, 4099), (3, 777), (1, 100)):
+        row = eng.padded_row(nb)
+        x = (rng.random((nb, npix)) * 1.2 - 0.1).astype(np.float32)
+        y = np.clip(x * 0.9 + 0.05 + 0.01 * rng.standard_normal(x.shape), 0, 1).astype(np.float32)
+        x[0, 3] = np.nan
+        m = rng.random(npix) > 0.3
+        xd, yd = torch.from_numpy(x).cuda(), torch.from_numpy(y).cuda()
+        md = torch.from_numpy(m.view(np.uint8)).cuda()
+        xr = torch.full((npix, row), 7.0, dtype=torch.float32, device="cuda")
+        yr = torch.full((npix, row), 7.0, dtype=torch.float32, device="cuda")
+        xr[:, :nb], yr[:, :nb] = xd.t(), yd.t()
+        co = torch.from_numpy(rng.standard_normal((nb, 4)) * 0.3).cuda()
+        a = eng.poly_apply(xd, co, md, None, True, nat.PLANAR)
+        b = eng.poly_apply(xr, co, md, None, True, nat.PIXMAJOR, nb=nb)
+        assert torch.equal(a.view(torch.int32), b[:, :nb].t().contiguous().view(torch.int32))
+        assert bool((b[:, nb:] == 7.0).all())                       # padding passes through
+        ws = eng.MomentWorkspace("cuda", nb, 3)
+        m1 = eng.poly_moments(xd, yd, 3, ws, md, 0.0, 0.0, layout=nat.PLANAR).clone()
+        m2 = eng.poly_moments(xr, yr, 3, ws, md, 0.0, 0.0, layout=nat.PIXMAJOR, nb=nb).clone()
+        assert torch.equal(m1, m2)
+        l1 = eng.percentile_limits(xd[1:], md, 2, 98, nat.PLANAR) if nb > 1 else None
+        l2 = eng.percentile_limits(xr[:, 1:], md, 2, 98, nat.PIXMAJOR, nb=nb - 1) if nb > 1 else None
+        if nb > 1:
+            assert torch.equal(l1, l2)
+        v1 = eng.valid_mask(xd, 0, yd, md, nat.PLANAR)
+        v2 = eng.valid_mask(xr, 0, yr, md, nat.PIXMAJOR, nbx=nb, nby=nb)
+        ref = m & np.isfinite(x).all(0) & (x[0] > 0) & np.isfinite(y).all(0)
+        assert torch.equal(v1, v2) and np.array_equal(v1.cpu().numpy().astype(bool), ref)
+
+
+def test_fused_13_bands_padded_rows(torch_gpu):
+    """No good_mask -> all 13 S2 bands supported -> band-last rows of 16 floats (3 padding columns)."""
+    torch = torch_gpu
+    from s2_emit import SpectralFusion
+    srf = onp.synthetic_srf()
+    w, _ = onp.synthetic_wavelengths()
+    R = onp.synthetic_cube(48, 40, seed=4)
+    ps_ref = onp.pseudo_s2_srf_integral(R, w, srf, None)
+    names = list(ps_ref)
+    assert len(names) == 13 and all(v is not None for v in ps_ref.values())
+    real = onp.synthetic_real_planes(np.stack([ps_ref[k] for k in names]).astype(np.float32), seed=8)
+    pseudo_o, coeffs_o, matched_o, _ = onp.fuse_lsq_reference(R, w, srf, None, real, 2)
+    plan = SpectralFusion(w, srf, None, deg=2)
+    out = plan.step(torch.from_numpy(R).cuda(), torch.from_numpy(real).cuda())
+    assert out.pseudo.shape == (48 * 40, 16)
+    assert _rel_err(out.planes("pseudo").cpu().numpy().reshape(pseudo_o.shape), pseudo_o) < 2e-6
+    assert _rel_err(out.planes("matched").cpu().numpy().reshape(matched_o.shape), matched_o) < 1e-4
+    assert _rel_err(out.band("B8A").cpu().numpy().reshape(48, 40), matched_o[names.index("B8A")]) < 1e-4
+
+
 def test_percentile_stretch_golden_g5(torch_gpu):
     torch = torch_gpu
     import s2_emit
@@ -228,7 +295,7 @@ def test_percentile_stretch_golden_g5(torch_gpu):
     g = load_golden("g5_stretch")
     x = torch.from_numpy(g["img"]).cuda().reshape(-1, 3)
     m = torch.from_numpy(g["mask"].view(np.uint8)).cuda().reshape(-1)
-    lohi = eng.percentile_limits(x, m, 2, 98, nat.LAYOUT_INTERLEAVED).cpu().numpy()
+    lohi = eng.percentile_limits(x, m, 2, 98, nat.PIXMAJOR).cpu().numpy()
     np.testing.assert_array_equal(lohi, g["lohi"])                      # exact order statistics + NumPy lerp
     np.testing.assert_array_equal(s2_emit.apply_shared_percentile_stretch(g["img"], g["mask"]), g["out_f32"])
     np.testing.assert_array_equal(s2_emit.apply_shared_percentile_stretch(g["img"], g["mask"], 5, 95), g["out_5_95"])
@@ -242,7 +309,7 @@ def test_percentile_stretch_golden_g5(torch_gpu):
     mb = rng.random((300, 257)) > 0.5
     xb = torch.from_numpy(big).cuda().reshape(-1, 3)
     lohi_b = eng.percentile_limits(xb, torch.from_numpy(mb.view(np.uint8)).cuda().reshape(-1), 2, 98,
-                                   nat.LAYOUT_INTERLEAVED).cpu().numpy()
+                                   nat.PIXMAJOR).cpu().numpy()
     np.testing.assert_array_equal(lohi_b, g["big_lohi"])
     assert s2_emit.apply_shared_percentile_stretch(big, mb).astype(np.float64).sum() == float(g["big_out_checksum"])
 
@@ -289,15 +356,24 @@ def test_fused_pipeline_vs_oracle(torch_gpu, H, W, deg):
     pseudo_o, coeffs_o, matched_o, names_o = onp.fuse_lsq_reference(R, w, srf, good, real, deg, 0.0, 50, True)
     plan = SpectralFusion(w, srf, good, deg=deg, min_valid=0.0, min_count=50, clip=True)
     assert plan.names == names_o
-    out = plan.step(torch.from_numpy(R).cuda(), torch.from_numpy(real).cuda())
-    assert _rel_err(out.pseudo.cpu().numpy().reshape(pseudo_o.shape), pseudo_o) < 2e-6
+    out = plan.step(torch.from_numpy(R).cuda(), torch.from_numpy(real).cuda())     # band-major target
+    assert out.layout == "pixmajor" and out.pseudo.shape == (H * W, 12)
+    # band-last target + planar internal layout must give the same bits
+    real_bl = torch.from_numpy(np.ascontiguousarray(np.moveaxis(real, 0, -1))).cuda()
+    out_b = plan.step(torch.from_numpy(R).cuda(), real_bl, reuse_buffers=False)
+    assert torch.equal(out_b.coeffs, out.coeffs) and torch.equal(out_b.matched.view(torch.int32), out.matched.view(torch.int32))
+    plan_p = SpectralFusion(w, srf, good, deg=deg, min_valid=0.0, min_count=50, clip=True, layout="planar")
+    out_p = plan_p.step(torch.from_numpy(R).cuda(), torch.from_numpy(real).cuda())
+    assert torch.equal(out_p.coeffs, out.coeffs)
+    assert torch.equal(out_p.matched.view(torch.int32), out.planes("matched").view(torch.int32))
+    assert _rel_err(out.planes("pseudo").cpu().numpy().reshape(pseudo_o.shape), pseudo_o) < 2e-6
     # the fit sees float32 planes that differ by <= 1 ulp from the reference's: coefficients move by
     # cond * 6e-8; compare the fitted CURVES (what the 1e-4 target is about) and the coefficients loosely
     co = out.coeffs.cpu().numpy()
     xs = np.linspace(pseudo_o.min(), pseudo_o.max(), 50)
     for b in range(len(names)):
         np.testing.assert_allclose(np.polyval(co[b], xs), np.polyval(coeffs_o[b], xs), rtol=1e-5, atol=1e-6)
-    assert _rel_err(out.matched.cpu().numpy().reshape(matched_o.shape), matched_o) < 1e-4
+    assert _rel_err(out.planes("matched").cpu().numpy().reshape(matched_o.shape), matched_o) < 1e-4
     ok0 = onp.per_band_valid(pseudo_o[0], real[0], np.ones((H, W), bool), 0.0)
     assert out.moments.cpu().numpy()[0, 0] == ok0.sum() == H * W - 1
 
@@ -329,7 +405,10 @@ def test_full_size_properties_c3(torch_gpu):
     plan = SpectralFusion(prob.emit_w, prob.srf, prob.good_mask, deg=3, min_valid=0.0)
     out = plan.step(prob.cube, prob.real)
     torch.cuda.synchronize()
-    pseudo = out.pseudo
+    assert out.layout == "pixmajor"
+    pseudo = out.planes("pseudo")
+    matched = out.planes("matched")
+    real_pl = prob.real_planes.reshape(plan.table.nb, -1)
     # (1) a sampled sub-block equals the oracle on the same data
     rows = slice(300, 316)
     sub = prob.cube[rows, :64].cpu().numpy()
@@ -346,7 +425,7 @@ def test_full_size_properties_c3(torch_gpu):
     assert float((pc - 0.37).abs().max()) < 1e-6
     # (4) moments: the count equals the number of valid pixels; device moments == float64 torch sums
     mom = out.moments.cpu().numpy()
-    x, y = pseudo.double(), prob.real.reshape(plan.table.nb, -1).double()
+    x, y = pseudo.double(), real_pl.double()
     ok = torch.isfinite(x) & torch.isfinite(y) & (x > 0) & (y > 0)
     assert np.array_equal(mom[:, 0], ok.sum(dim=1).cpu().numpy().astype(np.float64))
     s2 = torch.where(ok, x * x, torch.zeros_like(x)).sum(dim=1).cpu().numpy()
@@ -356,7 +435,7 @@ def test_full_size_properties_c3(torch_gpu):
     # (5) coefficients == np.polyfit on the device planes (host float64), one band checked in full
     b = 2
     xb = pseudo[b].cpu().numpy().astype(np.float64)
-    yb = prob.real.reshape(plan.table.nb, -1)[b].cpu().numpy().astype(np.float64)
+    yb = real_pl[b].cpu().numpy().astype(np.float64)
     okb = ok[b].cpu().numpy()
     ref_c = np.polyfit(xb[okb], yb[okb], 3)
     xs = np.linspace(xb[okb].min(), xb[okb].max(), 64)
@@ -364,7 +443,7 @@ def test_full_size_properties_c3(torch_gpu):
     # (6) apply is idempotent w.r.t. clipping and bit-exact vs the oracle on a slab
     slab = slice(0, 65536)
     ref_m = onp.apply_poly_planes(pseudo[:, slab].cpu().numpy().reshape(plan.table.nb, 1, -1), out.coeffs.cpu().numpy(), None)
-    assert np.array_equal(out.matched[:, slab].cpu().numpy(), ref_m.reshape(plan.table.nb, -1))
+    assert np.array_equal(matched[:, slab].cpu().numpy(), ref_m.reshape(plan.table.nb, -1))
     # (7) run-to-run determinism of the whole step (fixed summation tree, no float atomics)
     c1 = out.coeffs.clone()
     out2 = plan.step(prob.cube, prob.real)

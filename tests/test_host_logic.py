@@ -45,12 +45,17 @@ def test_sizing_helpers_and_error_strings():
     assert lib.hsr_percentile_work_bytes(3) > 3 * (2048 + 4 * 2048 + 4 * 1024) * 4
     # argument validation happens before any device work -> testable without a GPU
     k = (ctypes.c_int32 * 1)(0)
-    rc = lib.hsr_srf_integrate(None, 10, 285, None, k, k, 1, None, 10, None)
+    rc = lib.hsr_srf_integrate(None, 10, 285, None, k, k, 1, None, 10, 1, None)
     assert rc == 1 and b"NULL" in lib.hsr_last_error()
-    rc = lib.hsr_srf_integrate(ctypes.c_void_p(16), 10, 9999, ctypes.c_void_p(16), k, k, 1, ctypes.c_void_p(16), 10, None)
+    rc = lib.hsr_srf_integrate(ctypes.c_void_p(16), 10, 9999, ctypes.c_void_p(16), k, k, 1, ctypes.c_void_p(16), 10, 1, None)
     assert rc == 2 and b"B=9999" in lib.hsr_last_error()
     rc = lib.hsr_poly_solve(None, 3, 2, 50, None, None)
     assert rc == 1
+    # strides must describe band-major planes or pixel-major rows
+    rc = lib.hsr_srf_integrate(ctypes.c_void_p(16), 10, 285, ctypes.c_void_p(16), k, k, 1, ctypes.c_void_p(16), 3, 7, None)
+    assert rc == 1 and b"neither band-major nor pixel-major" in lib.hsr_last_error()
+    assert lib.hsr_set_srf_tile(48) == 1 and lib.hsr_get_srf_tile() == 64
+    assert lib.hsr_set_srf_tile(32) == 0 and lib.hsr_get_srf_tile() == 32 and lib.hsr_set_srf_tile(64) == 0
 
 
 def test_compute_fails_loudly_without_gpu():

@@ -51,6 +51,25 @@ __device__ __forceinline__ double wave_sum(double v) {
   return v;
 }
 
+// Streaming (non-temporal) accesses: everything on this path is touched exactly once, and letting
+// the 1.2 GB cube stream allocate in the 4 MB L2s evicts the dirty output lines early - measured on
+// K1: 0.2285 ms with plain loads, 0.2002 ms with `nt` on the LDS-DMA, 0.1957 ms with `nt` stores too.
+typedef float native_f32x4 __attribute__((ext_vector_type(4)));
+template <typename T>
+__device__ __forceinline__ T ld_stream(const T* p) { return __builtin_nontemporal_load(p); }
+template <typename T>
+__device__ __forceinline__ void st_stream(T* p, T v) { __builtin_nontemporal_store(v, p); }
+// HIP's float4 is a struct; the builtins want the native vector type (same size and alignment)
+__device__ __forceinline__ float4 ld_stream(const float4* p) {
+  const native_f32x4 v = __builtin_nontemporal_load(reinterpret_cast<const native_f32x4*>(p));
+  return make_float4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void st_stream(float4* p, float4 v) {
+  native_f32x4 n = {v.x, v.y, v.z, v.w};
+  __builtin_nontemporal_store(n, reinterpret_cast<native_f32x4*>(p));
+}
+constexpr int kGldsStream = 2;  // aux/cpol bits of global_load_lds: 2 = nt
+
 __device__ __forceinline__ bool finite_f32(float v) {
   return (__float_as_uint(v) & 0x7f800000u) != 0x7f800000u;
 }

@@ -16,18 +16,20 @@ void set_error(const char* fmt, ...) {
 }
 
 // Streams `n16` 16-byte words once and folds them into one float per workgroup (kept so the loads
-// cannot be eliminated).  Same access shape as the cube stream of K1: 16 B per lane, coalesced.
+// cannot be eliminated).  Same access shape and cache policy as the cube stream of K1: 16 B per lane,
+// coalesced, non-temporal.
 __global__ __launch_bounds__(256) void probe_read_kernel(const float4* __restrict__ src, int64_t n16,
                                                          float* __restrict__ sink) {
   float acc = 0.0f;
   const int64_t stride = (int64_t)gridDim.x * 256;
   int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
   for (; i + 3 * stride < n16; i += 4 * stride) {
-    const float4 a = src[i], b = src[i + stride], c = src[i + 2 * stride], d = src[i + 3 * stride];
+    const float4 a = hsr::ld_stream(src + i), b = hsr::ld_stream(src + i + stride), c = hsr::ld_stream(src + i + 2 * stride),
+                 d = hsr::ld_stream(src + i + 3 * stride);
     acc += (a.x + a.y + a.z + a.w) + (b.x + b.y + b.z + b.w) + (c.x + c.y + c.z + c.w) + (d.x + d.y + d.z + d.w);
   }
   for (; i < n16; i += stride) {
-    const float4 a = src[i];
+    const float4 a = hsr::ld_stream(src + i);
     acc += a.x + a.y + a.z + a.w;
   }
   acc += __shfl_xor(acc, 32, 64);

@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void moments_kernel(const MomArgs a) {
   int64_t end = beg + per;
   if (end > a.npix) end = a.npix;
   for (int64_t p = beg + threadIdx.x; p < end; p += 256) {
-    float xv = x[p * a.x_ps], yv = y[p * a.y_ps];
+    float xv = ld_stream(x + p * a.x_ps), yv = ld_stream(y + p * a.y_ps);
     const bool m = a.mask ? a.mask[p] != 0 : true;
     const bool ok = m && finite_f32(xv) && finite_f32(yv) && xv > a.min_x && yv > a.min_y;
     if (ok) {
@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256) void apply_planar_kernel(const ApplyArgs a) {
   if (VEC4) {
     const int64_t nv = a.npix >> 2;
     for (int64_t i = tid; i < nv; i += nthreads) {
-      float4 v = reinterpret_cast<const float4*>(x)[i];
+      float4 v = ld_stream(reinterpret_cast<const float4*>(x) + i);
       uint32_t m = 0x01010101u;
       if (a.mask) m = reinterpret_cast<const uint32_t*>(a.mask)[i];
       float r[4] = {v.x, v.y, v.z, v.w};
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) void apply_planar_kernel(const ApplyArgs a) {
         if (has_poly && ((m >> (8 * j)) & 0xffu)) xv = poly_eval(xv, c, n);
         r[j] = a.clip ? clip01(xv) : xv;
       }
-      reinterpret_cast<float4*>(o)[i] = make_float4(r[0], r[1], r[2], r[3]);
+      st_stream(reinterpret_cast<float4*>(o) + i, make_float4(r[0], r[1], r[2], r[3]));
     }
     for (int64_t p = (nv << 2) + tid; p < a.npix; p += nthreads) {
       float xv = x[p];
@@ -411,7 +411,7 @@ __global__ __launch_bounds__(256) void apply_pixmajor_kernel(const ApplyArgs a) 
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const uint32_t i = i0 + u * (uint32_t)nthreads;
-        if (i < nv) v[u] = reinterpret_cast<const float4*>(a.x)[i];
+        if (i < nv) v[u] = ld_stream(reinterpret_cast<const float4*>(a.x) + i);
       }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
@@ -431,7 +431,7 @@ __global__ __launch_bounds__(256) void apply_pixmajor_kernel(const ApplyArgs a) 
             r[j] = a.clip ? clip01(xv) : xv;
           }
         }
-        reinterpret_cast<float4*>(a.out)[i] = make_float4(r[0], r[1], r[2], r[3]);
+        st_stream(reinterpret_cast<float4*>(a.out) + i, make_float4(r[0], r[1], r[2], r[3]));
       }
     }
   } else {

@@ -58,7 +58,7 @@ __global__ __launch_bounds__(256) void select_hist_kernel(const SelArgs a) {
   const float* x = a.x + (size_t)c * a.cs;
   for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < a.npix; p += (int64_t)gridDim.x * 256) {
     if (a.mask && a.mask[p] == 0) continue;
-    const float v = x[p * a.ps];
+    const float v = ld_stream(x + p * a.ps);
     const uint32_t k = f32_key(v);
     if (PASS == 1) {
       atomicAdd(&h[k >> 21], 1u);

@@ -6,7 +6,9 @@
 // Data flow per workgroup (512 threads = 8 waves, 2 workgroups resident per CU):
 //   1. a tile of 64 consecutive pixels (64*B*4 bytes, one linear 16-byte-aligned slab because the
 //      cube is pixel-major) goes HBM -> LDS with global_load_lds_dwordx4 (no VGPR round trip,
-//      1 KiB per wave instruction, fully coalesced).  ~73 KB in flight per workgroup.
+//      1 KiB per wave instruction, fully coalesced), marked non-temporal: the cube is read once,
+//      and without the hint the stream thrashes L2 against the output lines (-12 % on the kernel).
+//      ~73 KB in flight per workgroup.
 //   2. one linear ds_read_b128 sweep flags pixels holding a non-finite sample.
 //   3. lane = pixel, wave = band group: each band is a short dot product over its SRF support read
 //      from LDS with a row stride of B words (B odd -> bank-conflict free).  The weight taps of all
@@ -109,7 +111,7 @@ __device__ __forceinline__ void flush_stage(const float* ostage, float* out, int
   const int n4 = (npx * ops) >> 2;  // ops is a multiple of 4
   float4* dst = reinterpret_cast<float4*>(out + pix0 * ops);
   const float4* src = reinterpret_cast<const float4*>(ostage);
-  for (int i = t; i < n4; i += T) dst[i] = src[i];
+  for (int i = t; i < n4; i += T) st_stream(dst + i, src[i]);
 }
 
 template <int DEG, bool FAST, bool WLDS, int P, bool OUTV>
@@ -180,7 +182,13 @@ __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
     if (DEG > 0) {
 #pragma unroll
       for (int j = 0; j < kBandSlots; ++j)
-        yv[j] = (bval[j] && pvalid) ? a.real[(grp + kGroups * j) * a.real_bs + (pix0 + pl) * a.real_ps] : 0.0f;
+      {
+        // band-major target: each element is read once, coalesced -> streaming load.  Pixel-major
+        // target: the 8 waves of the workgroup share the tile's ~3 KB slab at a 4-byte granularity
+        // -> it must stay cacheable (an `nt` load here re-fetches every line from HBM: +25 us).
+        const float* yp = a.real + (grp + kGroups * j) * a.real_bs + (pix0 + pl) * a.real_ps;
+        yv[j] = (bval[j] && pvalid) ? (a.real_ps == 1 ? ld_stream(yp) : *yp) : 0.0f;
+      }
       if (a.mask != nullptr) mv = pvalid && a.mask[pix0 + pl] != 0;
     }
 
@@ -194,7 +202,7 @@ __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
         const int c = c0 + lane;
         if (c < nchunk)
           __builtin_amdgcn_global_load_lds((gptr_t)(srcb + (size_t)c * 16), (lptr_t)(smem + (size_t)c0 * 16),
-                                           16, 0, 0);
+                                           16, 0, kGldsStream);
       }
       if (OUTV) flush_stage<8 * P>(ostage, a.out, prev_pix0, prev_npx, ops, t);
       HSR_STAMP(st1);
@@ -237,7 +245,7 @@ __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
       for (int pp = wave; pp < npx; pp += NW) {
         bool bad = false;
         for (int k = lane; k < B; k += 64) {
-          const float v = src[(size_t)pp * B + k];
+          const float v = ld_stream(src + (size_t)pp * B + k);
           bad |= !finite_f32(v);
           tile[pp * ldsB + k] = v;
         }
@@ -298,7 +306,7 @@ __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
       if (bval[j]) {
         const float acc = accv[j];
         if (OUTV) ostage[pl * ops + grp + kGroups * j] = acc;
-        else if (pvalid) a.out[(grp + kGroups * j) * a.out_bs + (pix0 + pl) * a.out_ps] = acc;
+        else if (pvalid) st_stream(a.out + (grp + kGroups * j) * a.out_bs + (pix0 + pl) * a.out_ps, acc);
         if (DEG > 0) {
           const float y = yv[j];
           const bool ok = pvalid && mv && finite_f32(acc) && finite_f32(y) && acc > a.min_x && y > a.min_y;

@@ -15,6 +15,7 @@ from .color import (
 )
 from .poly_regression import fit_ot_poly_rgb, apply_poly_rgb
 from .fusion import SpectralFusion, fuse_pair, calibrate_pseudo_to_real_linear
+from .ridge import PolyRidge, predict_cube_logit, flatten_pixels, subsample_bands_evenly
 from ._native import HsrUnavailable, HsrError
 
 # the reference's __all__ (s2_emit/__init__.py:10-24), verbatim order ...
@@ -38,4 +39,8 @@ __all__ = [
     "SpectralFusion",
     "fuse_pair",
     "calibrate_pseudo_to_real_linear",
+    "PolyRidge",
+    "predict_cube_logit",
+    "flatten_pixels",
+    "subsample_bands_evenly",
 ]

@@ -56,6 +56,14 @@ SIGNATURES = {
     "hsr_percentile_work_bytes": (C.c_size_t, [_i32]),
     "hsr_percentile_limits": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i32, _f64, _f64, _vp, _vp, _vp]),
     "hsr_valid_mask": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp]),
+    "hsr_polyfeat_count": (C.c_int, [_i32, _i32]),
+    "hsr_polyfeat_table": (C.c_int, [_i32, _i32, _vp]),
+    "hsr_polyfeat_prepare": (C.c_int, [_i32, _i32]),
+    "hsr_polyfeat_expand_f64": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, _i32, _i32, _vp, _i64, _i32, _vp]),
+    "hsr_gram_work_bytes": (C.c_size_t, [_i32, _i32, _i64]),
+    "hsr_gram_f64": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _i64, _vp, _vp, _i64, _vp]),
+    "hsr_polyfeat_predict": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _i32, _i32,
+                                       _vp, _i64, _vp]),
     "hsr_set_srf_tile": (C.c_int, [_i32]),
     "hsr_get_srf_tile": (C.c_int, []),
     "hsr_probe_read": (C.c_int, [_vp, _i64, _vp, _vp]),

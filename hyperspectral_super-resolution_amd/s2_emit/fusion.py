@@ -61,8 +61,8 @@ def exchange_moments(moments, coeffs_solver, group=None, mode: str = "allreduce"
     import torch.distributed as dist
     if mode not in COEFF_SYNC_MODES:
         raise ValueError(f"mode must be one of {COEFF_SYNC_MODES}, got {mode!r}")
-    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 1
-    if mode == "local" or world == 1:
+    world = dist.get_world_size(group) if (dist.is_available() and dist.is_initialized()) else 0
+    if mode == "local" or world == 0:
         return moments, coeffs_solver(moments)
     if mode == "allreduce":
         dist.all_reduce(moments, op=dist.ReduceOp.SUM, group=group)
@@ -79,7 +79,8 @@ class SpectralFusion:
 
     def __init__(self, emit_w, srf_dict, good_mask=None, deg: int = 3, min_valid: Optional[float] = 0.0,
                  min_count: int = 50, clip: bool = True, apply_mask: bool = False, device=None,
-                 group=None, coeff_sync: str = "allreduce", layout: str = nat.PIXMAJOR):
+                 group=None, coeff_sync: str = "allreduce", layout: str = nat.PIXMAJOR,
+                 force_exchange: bool = False):
         torch = nat.require_gpu()
         if not 1 <= deg <= nat.HSR_MAX_DEG:
             raise ValueError(f"deg must be in [1, {nat.HSR_MAX_DEG}], got {deg}")
@@ -97,6 +98,7 @@ class SpectralFusion:
         if layout not in (nat.PIXMAJOR, nat.PLANAR):
             raise ValueError(f"layout must be {nat.PIXMAJOR!r} or {nat.PLANAR!r}")
         self.layout = layout
+        self.force_exchange = bool(force_exchange)   # run the collective path even with one rank (tests)
         self.ws = eng.MomentWorkspace(self.device, self.table.nb, deg)
         self.table.device_weights(self.device)
         self._buf: Dict[int, Tuple[object, object]] = {}
@@ -117,7 +119,7 @@ class SpectralFusion:
         import torch.distributed as dist
         if self.coeff_sync == "local" or not (dist.is_available() and dist.is_initialized()):
             return False
-        return dist.get_world_size(self.group) > 1
+        return self.force_exchange or dist.get_world_size(self.group) > 1
 
     def _solve(self, moments):
         return eng.poly_solve(moments, self.deg, self.min_count, out=self.ws.coeffs)

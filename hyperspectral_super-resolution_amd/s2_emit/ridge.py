@@ -1,0 +1,163 @@
+"""Multivariate polynomial-ridge fusion S2 -> EMIT on MI355X (variant a9 of the path).
+
+Mirrors the notebook-resident pipeline of the reference, legacy_notebooks/Spectral_matching.ipynb:
+``flatten_pixels`` (raw lines 108-126), ``logit`` / ``sigmoid`` (174-181), the scikit-learn pipeline
+``StandardScaler -> PolynomialFeatures(degree, include_bias=False) -> Ridge(alpha)`` (475-490) and
+``predict_cube_logit`` (192-213).  The fit is the float64 normal-equation form of that pipeline
+(centre features and targets, solve (Phi^T Phi + alpha I) W = Phi^T Y): the Gram contraction runs on the
+float64 matrix cores (``hsr_gram_f64``), the small Cholesky solve through torch.linalg on the device, and
+the prediction is one fused expand + float32-MFMA + sigmoid kernel (``hsr_polyfeat_predict``).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import numpy as np
+
+from . import _native as nat
+from ._engine import _ptr, _stream
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.startswith("torch")
+
+
+def subsample_bands_evenly(num_bands_total: int, num_keep: int = 32) -> np.ndarray:
+    """Evenly spaced band indices in [0, num_bands_total) (notebook raw lines 83-97)."""
+    idx = np.unique(np.linspace(0, num_bands_total - 1, num_keep).round().astype(int))
+    while len(idx) < num_keep:
+        missing = num_keep - len(idx)
+        add = []
+        for i in range(len(idx) - 1):
+            if len(add) >= missing:
+                break
+            add.append(int((idx[i] + idx[i + 1]) // 2))
+        idx = np.unique(np.concatenate([idx, np.array(add, dtype=int)]))
+    return idx[:num_keep]
+
+
+def flatten_pixels(X_bhw, Y_bhw, x_nodata=None, y_nodata=None):
+    """(Bx,H,W), (By,H,W) -> X (N,Bx), Y (N,By) keeping pixels finite in both (and not nodata)."""
+    Bx, H, W = X_bhw.shape
+    By, Hy, Wy = Y_bhw.shape
+    assert (H, W) == (Hy, Wy)
+    X = X_bhw.reshape(Bx, -1).T
+    Y = Y_bhw.reshape(By, -1).T
+    mask = np.isfinite(X).all(axis=1) & np.isfinite(Y).all(axis=1)
+    if x_nodata is not None:
+        mask &= ~(np.isclose(X, x_nodata).any(axis=1))
+    if y_nodata is not None:
+        mask &= ~(np.isclose(Y, y_nodata).any(axis=1))
+    return X[mask], Y[mask]
+
+
+def logit(x, eps: float = 1e-4):
+    x = np.clip(x, eps, 1.0 - eps)
+    return np.log(x / (1.0 - x))
+
+
+def sigmoid(z):
+    z = np.clip(z, -50, 50)
+    return 1.0 / (1.0 + np.exp(-z))
+
+
+class PolyRidge:
+    """StandardScaler -> PolynomialFeatures(degree, no bias) -> Ridge(alpha, intercept) on the GPU."""
+
+    def __init__(self, degree: int = 3, alpha: float = 1.0):
+        self.degree, self.alpha = int(degree), float(alpha)
+        self.n_in = self.n_feat = self.n_targets = 0
+        self.mean_ = self.scale_ = self.coef_ = self.intercept_ = None     # float64 host copies (sklearn names)
+        self._dev = {}
+
+    # ---- fit --------------------------------------------------------------------------------------
+    def fit(self, X, Y):
+        """X (N, n_in), Y (N, T) - NumPy or GPU tensors; rows must be finite (see flatten_pixels)."""
+        torch = nat.require_gpu()
+        lib = nat.load()
+        Xd = (X if _is_torch(X) else torch.from_numpy(np.ascontiguousarray(X, dtype=np.float32))).to("cuda", torch.float32).contiguous()
+        Yd = (Y if _is_torch(Y) else torch.from_numpy(np.ascontiguousarray(Y))).to("cuda", torch.float64).contiguous()
+        if Yd.dim() == 1:
+            Yd = Yd[:, None]
+        n, n_in = Xd.shape
+        T = Yd.shape[1]
+        nf = lib.hsr_polyfeat_count(n_in, self.degree)
+        if nf <= 0:
+            raise ValueError(f"unsupported polynomial features: n_in={n_in}, degree={self.degree}")
+        nat.check(lib.hsr_polyfeat_prepare(n_in, self.degree), "hsr_polyfeat_prepare")
+        X64 = Xd.double()
+        mean = X64.mean(dim=0)
+        scale = X64.var(dim=0, unbiased=False).sqrt()
+        scale = torch.where(scale == 0, torch.ones_like(scale), scale)          # StandardScaler: zero variance -> 1
+        na = (nf + 1 + 15) // 16 * 16                                          # [1 | features] padded
+        tp = (T + 15) // 16 * 16
+        Q = torch.zeros((n, na + tp), dtype=torch.float64, device=Xd.device)    # [P | Y | 0]
+        Q[:, na:na + T] = Yd
+        nat.check(lib.hsr_polyfeat_expand_f64(_ptr(Xd), Xd.stride(0), Xd.stride(1) if n_in > 1 else 1, _ptr(mean),
+                                              _ptr(scale), n, n_in, self.degree, _ptr(Q), Q.stride(0), na,
+                                              _stream(torch)), "hsr_polyfeat_expand_f64")
+        work = torch.empty(max(1, lib.hsr_gram_work_bytes(na, na + tp, n) // 8), dtype=torch.float64, device=Xd.device)
+        G = torch.empty((na, na + tp), dtype=torch.float64, device=Xd.device)
+        nat.check(lib.hsr_gram_f64(_ptr(Q), Q.stride(0), na, _ptr(Q), Q.stride(0), na + tp, n, _ptr(work), _ptr(G),
+                                   G.stride(0), _stream(torch)), "hsr_gram_f64")
+        cnt = G[0, 0]
+        s = G[0, 1:nf + 1]                               # column sums of the features
+        ybar = G[0, na:na + T] / cnt
+        Gc = G[1:nf + 1, 1:nf + 1] - torch.outer(s, s) / cnt
+        rhs = G[1:nf + 1, na:na + T] - torch.outer(s, ybar)
+        Gc = Gc + self.alpha * torch.eye(nf, dtype=torch.float64, device=Xd.device)
+        L = torch.linalg.cholesky(Gc)
+        Wm = torch.cholesky_solve(rhs, L)               # (nf, T)
+        b = ybar - (s / cnt) @ Wm
+        self.n_in, self.n_feat, self.n_targets = n_in, nf, T
+        self.mean_, self.scale_ = mean.cpu().numpy(), scale.cpu().numpy()
+        self.coef_, self.intercept_ = Wm.t().contiguous().cpu().numpy(), b.cpu().numpy()
+        kpad = (nf + 1) // 2 * 2
+        Wf = torch.zeros((kpad, T), dtype=torch.float32, device=Xd.device)
+        Wf[:nf] = Wm.float()
+        self._dev = dict(W=Wf, b=b.float().contiguous(), mean=mean.float().contiguous(),
+                         inv=(1.0 / scale).float().contiguous())
+        return self
+
+    # ---- predict ------------------------------------------------------------------------------------
+    def _predict_dev(self, x, x_ps: int, x_cs: int, npix: int, activation: int):
+        torch = nat.require_gpu()
+        lib = nat.load()
+        if not self._dev:
+            raise RuntimeError("PolyRidge is not fitted")
+        nat.check(lib.hsr_polyfeat_prepare(self.n_in, self.degree), "hsr_polyfeat_prepare")
+        d = self._dev
+        out = torch.empty((self.n_targets, npix), dtype=torch.float32, device=x.device)
+        nat.check(lib.hsr_polyfeat_predict(_ptr(x), x_ps, x_cs, _ptr(d["mean"]), _ptr(d["inv"]), npix, self.n_in,
+                                           self.degree, _ptr(d["W"]), d["W"].stride(0), _ptr(d["b"]), self.n_targets,
+                                           activation, _ptr(out), out.stride(0), _stream(torch)), "hsr_polyfeat_predict")
+        return out
+
+    def predict(self, X):
+        """X (N, n_in) -> (N, T) float32 raw model output (logit space in the notebook's use)."""
+        torch = nat.require_gpu()
+        Xd = (X if _is_torch(X) else torch.from_numpy(np.ascontiguousarray(X, dtype=np.float32))).to("cuda", torch.float32).contiguous()
+        out = self._predict_dev(Xd, Xd.stride(0), 1, Xd.shape[0], 0).t()
+        return out if _is_torch(X) else out.cpu().numpy()
+
+    def predict_cube(self, X_bhw, nodata=None):
+        """(n_in, H, W) S2 cube -> (T, H, W) float32 = sigmoid(clip(model, +-50)); pixels with a non-finite
+        (or nodata) input come out NaN, as predict_cube_logit leaves them (notebook raw lines 197-203)."""
+        torch = nat.require_gpu()
+        Xd = (X_bhw if _is_torch(X_bhw) else torch.from_numpy(np.ascontiguousarray(X_bhw, dtype=np.float32)))
+        Xd = Xd.to("cuda", torch.float32).contiguous()
+        Cc, H, W = Xd.shape
+        out = self._predict_dev(Xd, 1, H * W, H * W, 1)
+        x2 = Xd.reshape(Cc, -1)
+        bad = ~torch.isfinite(x2).all(dim=0)
+        if nodata is not None:
+            bad |= torch.isclose(x2, torch.tensor(float(nodata), device=x2.device)).any(dim=0)
+        out[:, bad] = float("nan")
+        out = out.reshape(self.n_targets, H, W)
+        return out if _is_torch(X_bhw) else out.cpu().numpy()
+
+
+def predict_cube_logit(model: PolyRidge, X_bhw, nodata=None, batch_pixels: int = 200_000):
+    """Notebook signature (raw lines 192-213); ``batch_pixels`` is accepted and ignored (one fused launch)."""
+    return model.predict_cube(X_bhw, nodata=nodata)

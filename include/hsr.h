@@ -160,6 +160,33 @@ int hsr_valid_mask(const float* x_dev, int64_t x_bs, int64_t x_ps, int32_t nbx, 
                    const uint8_t* mask_in_dev, int64_t npix, uint8_t* mask_out_dev,
                    hsr_stream_t stream);
 
+/* ---- K4 (variant a9): multivariate polynomial-ridge fusion ---------------------------------------
+ * legacy_notebooks/Spectral_matching.ipynb: Pipeline(StandardScaler, PolynomialFeatures(3, no bias),
+ * Ridge(alpha)) on logit(EMIT) (raw lines 475-490), applied by predict_cube_logit (raw lines 192-213).
+ * Monomial order = sklearn's (degree-major, combinations_with_replacement); n_in <= 16, degree <= 3. */
+int hsr_polyfeat_count(int32_t n_in, int32_t degree);                 /* 285 for (10, 3); -1 if unsupported */
+int hsr_polyfeat_table(int32_t n_in, int32_t degree, uint8_t* idx_out /* [count][3], index n_in = constant 1 */);
+/* Uploads the monomial table for (n_in, degree); NOT a launch-path call (allocates). */
+int hsr_polyfeat_prepare(int32_t n_in, int32_t degree);
+/* First ncols columns of the rows of P (n, ldp) float64 = [1 | monomials of (x - mean)/scale | 0 pad];
+ * x element (row r, band c) at x_dev[r * x_rs + c * x_cs]; mean/scale: device doubles [n_in]. */
+int hsr_polyfeat_expand_f64(const float* x_dev, int64_t x_rs, int64_t x_cs, const double* mean_dev,
+                            const double* scale_dev, int64_t n, int32_t n_in, int32_t degree,
+                            double* p_dev, int64_t ldp, int32_t ncols, hsr_stream_t stream);
+/* C (na x nb, ldc) = A^T B over the n rows of A (n, lda) and B (n, ldb), float64 on
+ * v_mfma_f64_16x16x4_f64; na, nb multiples of 16; row chunks reduced in a fixed order.
+ * work_dev: hsr_gram_work_bytes(na, nb, n) bytes. */
+size_t hsr_gram_work_bytes(int32_t na, int32_t nb, int64_t n);
+int hsr_gram_f64(const double* a_dev, int64_t lda, int32_t na, const double* b_dev, int64_t ldb, int32_t nb,
+                 int64_t n, double* work_dev, double* c_dev, int64_t ldc, hsr_stream_t stream);
+/* out[t * out_stride + p] = act(sum_f W[f][t] * phi_f((x_p - mean) * inv_scale) + bias[t]) with the features
+ * expanded on chip (v_mfma_f32_32x32x2_f32); W (count rounded up to even rows, ldw) float32 with zero rows past
+ * count; activation 1 = sigmoid(clip(z, -50, 50)) (notebook raw lines 178-181), 0 = identity. */
+int hsr_polyfeat_predict(const float* x_dev, int64_t x_ps, int64_t x_cs, const float* mean_dev,
+                         const float* inv_scale_dev, int64_t npix, int32_t n_in, int32_t degree,
+                         const float* w_dev, int64_t ldw, const float* bias_dev, int32_t T, int32_t activation,
+                         float* out_dev, int64_t out_stride, hsr_stream_t stream);
+
 /* ---- tuning --------------------------------------------------------------------------------------
  * LDS tile of K1: 64 pixels (512-thread workgroups, 2 per CU) or 32 pixels (256-thread workgroups,
  * 4 per CU).  Process-wide; results are identical up to the summation tree of the moments. */

@@ -448,3 +448,101 @@ def test_full_size_properties_c3(torch_gpu):
     c1 = out.coeffs.clone()
     out2 = plan.step(prob.cube, prob.real)
     assert torch.equal(out2.coeffs, c1)
+
+
+def test_rccl_exchange_path_single_rank(torch_gpu):
+    """One-rank RCCL group on the GPU: the multi-GPU step (reduce -> all-reduce / reduce+broadcast -> solve ->
+    apply) must give bit-identical coefficients and output to the fused single-GPU launch."""
+    torch = torch_gpu
+    import os
+    import torch.distributed as dist
+    from s2_emit import SpectralFusion
+    srf = onp.synthetic_srf()
+    w, good = onp.synthetic_wavelengths()
+    R = torch.from_numpy(onp.synthetic_cube(96, 80, seed=12)).cuda()
+    ps = onp.pseudo_s2_srf_integral(R.cpu().numpy(), w, srf, good)
+    names = [k for k, v in ps.items() if v is not None]
+    real = torch.from_numpy(onp.synthetic_real_planes(np.stack([ps[k] for k in names]).astype(np.float32))).cuda()
+    base = SpectralFusion(w, srf, good, deg=3, coeff_sync="local").step(R, real, reuse_buffers=False)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    created = False
+    if not dist.is_initialized():
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29517", rank=0, world_size=1,
+                                device_id=torch.device("cuda", 0))
+        created = True
+    try:
+        for mode in ("allreduce", "broadcast"):
+            plan = SpectralFusion(w, srf, good, deg=3, coeff_sync=mode, force_exchange=True)
+            out = plan.step(R, real, reuse_buffers=False)
+            torch.cuda.synchronize()
+            assert torch.equal(out.coeffs, base.coeffs), mode
+            assert torch.equal(out.moments, base.moments), mode
+            assert torch.equal(out.matched.view(torch.int32), base.matched.view(torch.int32)), mode
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
+# ---------------------------------------------------------------------------------------------
+# variant a9: multivariate polynomial ridge on the matrix cores
+# ---------------------------------------------------------------------------------------------
+def test_gram_f64_mfma_layout_exact(torch_gpu):
+    """A^T B with small-integer data is exact in float64: catches any row/col or k-order slip of the
+    v_mfma_f64_16x16x4_f64 lane maps (asymmetric B on purpose)."""
+    torch = torch_gpu
+    import ctypes as C
+    from s2_emit import _native as nat
+    from s2_emit._engine import _ptr, _stream
+    lib = nat.load()
+    rng = np.random.default_rng(3)
+    for n in (4, 37, 1024, 5003):
+        A = rng.integers(-4, 5, (n, 32)).astype(np.float64)
+        B = rng.integers(-4, 5, (n, 48)).astype(np.float64)
+        Ad, Bd = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()
+        work = torch.empty(max(1, lib.hsr_gram_work_bytes(32, 48, n) // 8), dtype=torch.float64, device="cuda")
+        Cd = torch.full((32, 48), -1.0, dtype=torch.float64, device="cuda")
+        nat.check(lib.hsr_gram_f64(_ptr(Ad), 32, 32, _ptr(Bd), 48, 48, n, _ptr(work), _ptr(Cd), 48, _stream(torch)))
+        np.testing.assert_array_equal(Cd.cpu().numpy(), A.T @ B)
+
+
+def test_poly_ridge_golden_g7(torch_gpu):
+    """Fit + predict vs the scikit-learn float64 pipeline frozen in g7 (the notebook's own composition)."""
+    import s2_emit
+    g = load_golden("g7_ridge")
+    X = g["X"].astype(np.float32)
+    model = s2_emit.PolyRidge(degree=3, alpha=1.0).fit(X, g["Ylogit"])
+    assert model.n_feat == 285 and model.coef_.shape == (6, 285)
+    np.testing.assert_allclose(model.mean_, g["mean"], rtol=1e-12)
+    np.testing.assert_allclose(model.scale_, g["scale"], rtol=1e-12)
+    np.testing.assert_allclose(model.intercept_, g["intercept"], rtol=1e-6, atol=1e-7)
+    # coefficients of an alpha-regularised ill-conditioned system: compare through their effect
+    Xte = g["Xtest"].reshape(-1, 10).astype(np.float32)
+    pl = model.predict(Xte)
+    assert pl.dtype == np.float32 and pl.shape == (256, 6)
+    np.testing.assert_allclose(pl, g["pred_logit"], rtol=0, atol=2e-4)          # float32 features + f32 MFMA
+    cube = np.ascontiguousarray(np.moveaxis(g["Xtest"].astype(np.float32), -1, 0))   # (10, 16, 16)
+    pc = s2_emit.predict_cube_logit(model, cube)
+    assert pc.shape == (6, 16, 16) and pc.dtype == np.float32
+    np.testing.assert_allclose(pc.reshape(6, -1).T, g["pred"], rtol=0, atol=1e-4)   # the 1e-4 reflectance target
+    cube[3, 2, 5] = np.nan
+    cube[0, 7, 7] = 600.0
+    pn = s2_emit.predict_cube_logit(model, cube, nodata=600.0)
+    assert np.isnan(pn[:, 2, 5]).all() and np.isnan(pn[:, 7, 7]).all() and np.isfinite(pn[:, 0, 0]).all()
+    np.testing.assert_array_equal(s2_emit.subsample_bands_evenly(285, 32), g["subsample_285_32"])
+
+
+def test_poly_ridge_many_targets_vs_oracle(torch_gpu):
+    """T = 70 targets (3 MFMA target tiles), degree 2, odd pixel count: the generalised a9 configuration."""
+    import s2_emit
+    rng = np.random.default_rng(17)
+    N, Cin, T = 3001, 10, 70
+    base = rng.random((N, 4))
+    X = (600 + 4000 * np.clip(base @ rng.random((4, Cin)) / 2, 0, 1)).astype(np.float32)
+    Y = onp.logit(np.clip(base @ rng.random((4, T)) / 3 + 0.01 * rng.standard_normal((N, T)), 0, 0.6))
+    ref = onp.ridge_poly_fit(X.astype(np.float64), Y, 2, 1.0)
+    model = s2_emit.PolyRidge(degree=2, alpha=1.0).fit(X, Y)
+    Xt = (600 + 4000 * rng.random((777, Cin))).astype(np.float32)
+    np.testing.assert_allclose(model.predict(Xt), onp.ridge_poly_predict(ref, Xt.astype(np.float64)), rtol=0, atol=3e-4)
+    pc = model.predict_cube(np.ascontiguousarray(Xt[:770].T.reshape(Cin, 22, 35)))
+    np.testing.assert_allclose(pc.reshape(T, -1).T, onp.sigmoid(onp.ridge_poly_predict(ref, Xt[:770].astype(np.float64))),
+                               rtol=0, atol=1e-4)

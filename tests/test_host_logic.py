@@ -58,6 +58,21 @@ def test_sizing_helpers_and_error_strings():
     assert lib.hsr_set_srf_tile(32) == 0 and lib.hsr_get_srf_tile() == 32 and lib.hsr_set_srf_tile(64) == 0
 
 
+def test_polyfeat_table_matches_sklearn_order():
+    lib = nat.load()
+    assert lib.hsr_polyfeat_count(10, 3) == 285 and lib.hsr_polyfeat_count(10, 2) == 65
+    assert lib.hsr_polyfeat_count(17, 3) == -1 and lib.hsr_polyfeat_count(10, 4) == -1
+    buf = (ctypes.c_uint8 * (285 * 3))()
+    assert lib.hsr_polyfeat_table(10, 3, buf) == 0
+    idx = np.frombuffer(buf, dtype=np.uint8).reshape(285, 3)
+    expo = np.zeros((285, 10), int)
+    for f in range(285):
+        for k in idx[f]:
+            if k < 10:
+                expo[f, k] += 1
+    np.testing.assert_array_equal(expo, load_golden("g7_ridge")["powers"])     # sklearn's powers_
+
+
 def test_compute_fails_loudly_without_gpu():
     import torch
     if torch.cuda.is_available():

@@ -24,7 +24,7 @@ struct Bands { int k0[NBMAX]; int klen[NBMAX]; int woff[NBMAX]; int wtaps; };
 
 // ---------------------------------------------------------------- V_lds<P, MODE>: LDS-staged, lane = pixel
 // MODE 0 = full, 1 = load only (ceiling of the staging structure), 2 = load + scan
-template <int P, int THREADS, int MINW, int MODE, bool RAWBAR = false, int ASSIGN = 0, bool NT = false>
+template <int P, int THREADS, int MINW, int MODE, bool RAWBAR = false, int ASSIGN = 0, bool NT = false, int AUX = 0, bool SMALLW = false>
 __global__ __launch_bounds__(THREADS, MINW) void k_lds(const float* __restrict__ cube, int64_t npix, const float* __restrict__ wn,
                                                  Bands bands, int nb, float* __restrict__ planes, int64_t stride) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -51,7 +51,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_lds(const float* __restrict__
     for (int c0 = wave * 64; c0 < nchunk; c0 += THREADS) {
       const int c = c0 + lane;
       if (c < nchunk)
-        __builtin_amdgcn_global_load_lds((gptr_t)(srcb + (size_t)c * 16), (lptr_t)(smem + (size_t)c0 * 16), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(srcb + (size_t)c * 16), (lptr_t)(smem + (size_t)c0 * 16), 16, 0, AUX);
     }
     __syncthreads();
     if (MODE != 1) {
@@ -92,7 +92,7 @@ __global__ __launch_bounds__(THREADS, MINW) void k_lds(const float* __restrict__
           } else {
             for (int k = 0; k < B; ++k) acc = fmaf(w[k], v[k], acc);
           }
-          if (MODE == 0) { if (NT) __builtin_nontemporal_store(acc, &planes[b * stride + pix0 + p]); else planes[b * stride + pix0 + p] = acc; } else sink += acc;
+          if (MODE == 0) { const int64_t po = SMALLW ? ((pix0 + p) & 16383) : (pix0 + p); if (NT) __builtin_nontemporal_store(acc, &planes[b * stride + po]); else planes[b * stride + po] = acc; } else sink += acc;
         }
       }
     } else if (MODE == 4) {
@@ -213,7 +213,7 @@ __device__ __forceinline__ void wait_vm_n(int n) {
 // LDS-DMA issued from inline asm: the compiler's waitcnt pass then does not know a DMA is pending and
 // does not force vmcnt(0) in front of every ds_read; all vmcnt accounting for the DMA is done by hand.
 __device__ __forceinline__ void glds16_asm(const void* gaddr, uint32_t lds_base) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gaddr), "s"(lds_base) : "memory");
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" ::"v"(gaddr), "s"(lds_base) : "memory");
 }
 template <int T, int MINW>
 __global__ __launch_bounds__(T, MINW) void k_ring(const float* __restrict__ cube, int64_t npix, const float* __restrict__ wn,
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(T, MINW) void k_ring(const float* __restrict__ cube
         for (int u = 0; u < 4; ++u) { acc = fmaf(ww[u].x, xv[4*u], acc); acc = fmaf(ww[u].y, xv[4*u+1], acc); acc = fmaf(ww[u].z, xv[4*u+2], acc); acc = fmaf(ww[u].w, xv[4*u+3], acc); }
       }
       if (slow && bval[j]) { const float* w = wn + (size_t)(wave + NG * j) * B; acc = 0.f; for (int k = 0; k < B; ++k) acc = fmaf(w[k], v[k], acc); }
-      if (bval[j]) planes[(wave + NG * j) * stride + pix0 + lane] = acc;
+      if (bval[j]) __builtin_nontemporal_store(acc, &planes[(wave + NG * j) * stride + pix0 + lane]);
     }
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   }
@@ -449,6 +449,13 @@ int main(int argc, char** argv) {
   SETLDS((k_lds<16, 64, 2, 0>), lds_bytes(16)); SETLDS((k_lds<16, 64, 2, 1>), lds_bytes(16));
   SETLDS((k_lds<64, 256, 2, 0, true, 1, false>), lds_bytes(64)); SETLDS((k_lds<64, 256, 2, 0, true, 1, true>), lds_bytes(64)); SETLDS((k_lds<64, 256, 2, 0, true, 0, true>), lds_bytes(64));
   SETLDS((k_lds<64, 256, 2, 1, true, 1, false>), lds_bytes(64));
+  SETLDS((k_lds<64, 256, 2, 0, true, 0, false, 2, false>), lds_bytes(64));
+  SETLDS((k_lds<64, 256, 2, 0, true, 0, false, 16, false>), lds_bytes(64));
+  SETLDS((k_lds<64, 256, 2, 0, true, 0, false, 1, false>), lds_bytes(64));
+  SETLDS((k_lds<64, 256, 2, 0, true, 0, true, 2, false>), lds_bytes(64));
+  SETLDS((k_lds<64, 256, 2, 0, true, 0, false, 17, false>), lds_bytes(64));
+  SETLDS((k_lds<64, 256, 2, 0, true, 0, false, 0, true>), lds_bytes(64));
+  SETLDS((k_lds<64, 256, 2, 1, true, 0, false, 2, false>), lds_bytes(64));
   SETLDS((k_lds<64, 256, 2, 3>), lds_bytes(64)); SETLDS((k_lds<64, 256, 2, 4>), lds_bytes(64));
   SETLDS((k_lds<64, 256, 2, 0, true>), lds_bytes(64)); SETLDS((k_lds<32, 256, 4, 0, true>), lds_bytes(32));
   SETLDS((k_lds<32, 128, 2, 0, true>), lds_bytes(32)); SETLDS((k_lds<16, 64, 2, 0, true>), lds_bytes(16));
@@ -464,6 +471,13 @@ int main(int argc, char** argv) {
   add("lds P64 T256 2/CU full CONTIG+NT", [&] { hipLaunchKernelGGL((k_lds<64, 256, 2, 0, true, 1, true>), dim3(512), dim3(256), lds_bytes(64), 0, d_cube, npix, d_wn, bands, nb, d_planes, stride); }, true);
   add("lds P64 T256 2/CU full strided+NT", [&] { hipLaunchKernelGGL((k_lds<64, 256, 2, 0, true, 0, true>), dim3(512), dim3(256), lds_bytes(64), 0, d_cube, npix, d_wn, bands, nb, d_planes, stride); }, true);
   add("lds P64 T256 2/CU load-only CONTIG", [&] { hipLaunchKernelGGL((k_lds<64, 256, 2, 1, true, 1, false>), dim3(512), dim3(256), lds_bytes(64), 0, d_cube, npix, d_wn, bands, nb, d_planes, stride); }, false);
+  add("lds P64 T256 full aux nt(2)", [&] { hipLaunchKernelGGL((k_lds<64, 256, 2, 0, true, 0, false, 2, false>), dim3(512), dim3(256), lds_bytes(64), 0, d_cube, npix, d_wn, bands, nb, d_planes, stride); }, false);
+  add("lds P64 T256 full aux sc1(16)", [&] { hipLaunchKernelGGL((k_lds<64, 256, 2, 0, true, 0, false, 16, false>), dim3(512), dim3(256), lds_bytes(64), 0, d_cube, npix, d_wn, bands, nb, d_planes, stride); }, false);
+  add("lds P64 T256 full aux sc0(1)", [&] { hipLaunchKernelGGL((k_lds<64, 256, 2, 0, true, 0, false, 1, false>), dim3(512), dim3(256), lds_bytes(64), 0, d_cube, npix, d_wn, bands, nb, d_planes, stride); }, false);
+  add("lds P64 T256 full aux nt + NT stores", [&] { hipLaunchKernelGGL((k_lds<64, 256, 2, 0, true, 0, true, 2, false>), dim3(512), dim3(256), lds_bytes(64), 0, d_cube, npix, d_wn, bands, nb, d_planes, stride); }, false);
+  add("lds P64 T256 full aux sc0sc1(17)", [&] { hipLaunchKernelGGL((k_lds<64, 256, 2, 0, true, 0, false, 17, false>), dim3(512), dim3(256), lds_bytes(64), 0, d_cube, npix, d_wn, bands, nb, d_planes, stride); }, false);
+  add("lds P64 T256 full stores to 64KB/plane region", [&] { hipLaunchKernelGGL((k_lds<64, 256, 2, 0, true, 0, false, 0, true>), dim3(512), dim3(256), lds_bytes(64), 0, d_cube, npix, d_wn, bands, nb, d_planes, stride); }, false);
+  add("lds P64 T256 load-only aux nt(2)", [&] { hipLaunchKernelGGL((k_lds<64, 256, 2, 1, true, 0, false, 2, false>), dim3(512), dim3(256), lds_bytes(64), 0, d_cube, npix, d_wn, bands, nb, d_planes, stride); }, false);
   add("lds P64 T256 2/CU compute NO stores", [&] { hipLaunchKernelGGL((k_lds<64, 256, 2, 3>), dim3(512), dim3(256), lds_bytes(64), 0, d_cube, npix, d_wn, bands, nb, d_planes, stride); }, false);
   add("lds P64 T256 2/CU load-only + stores", [&] { hipLaunchKernelGGL((k_lds<64, 256, 2, 4>), dim3(512), dim3(256), lds_bytes(64), 0, d_cube, npix, d_wn, bands, nb, d_planes, stride); }, false);
   add("lds P64 T256 2/CU load-only", [&] { hipLaunchKernelGGL((k_lds<64, 256, 2, 1>), dim3(512), dim3(256), lds_bytes(64), 0, d_cube, npix, d_wn, bands, nb, d_planes, stride); }, false);

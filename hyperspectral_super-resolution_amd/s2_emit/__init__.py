@@ -14,7 +14,7 @@ from .color import (
     histogram_match_rgb, ot_match_rgb_sinkhorn_pot
 )
 from .poly_regression import fit_ot_poly_rgb, apply_poly_rgb
-from .fusion import SpectralFusion, fuse_pair, calibrate_pseudo_to_real_linear
+from .fusion import SpectralFusion, fuse_pair, match_pair, calibrate_pseudo_to_real_linear
 from .ridge import PolyRidge, predict_cube_logit, flatten_pixels, subsample_bands_evenly
 from ._native import HsrUnavailable, HsrError
 
@@ -38,6 +38,7 @@ __all__ = [
     "apply_poly_rgb",
     "SpectralFusion",
     "fuse_pair",
+    "match_pair",
     "calibrate_pseudo_to_real_linear",
     "PolyRidge",
     "predict_cube_logit",

@@ -349,6 +349,42 @@ def valid_mask(x, pos_band: int = -1, y=None, mask_in=None, layout: str = PLANAR
     return out
 
 
+def block_mean(fine, Hc: int, Wc: int, factor: int, scale: float = 1.0, layout: str = PLANAR,
+               out_layout: Optional[str] = None, nb: Optional[int] = None):
+    """'average' downsampling of an exactly aligned fine image (Hc*f x Wc*f pixels) by an integer factor.
+    fine: float32 / uint8 / uint16 image tensor in ``layout``; returns float32 image in ``out_layout``."""
+    torch = nat.require_gpu()
+    lib = nat.load()
+    dt = {torch.float32: 0, torch.uint8: 1, torch.uint16: 2}.get(fine.dtype)
+    if dt is None:
+        raise ValueError(f"block_mean: unsupported dtype {fine.dtype}")
+    ibs, ips, n, npf = _img(fine, layout, nb)
+    if npf != Hc * factor * Wc * factor:
+        raise ValueError(f"block_mean: fine image has {npf} pixels, expected {Hc * factor}x{Wc * factor}")
+    ol = out_layout or layout
+    out = alloc_image(torch, n, Hc * Wc, ol, fine.device)
+    obs, ops, _, _ = _img(out, ol, n)
+    nat.check(lib.hsr_block_mean(_ptr(fine), dt, ibs, ips, n, Hc, Wc, factor, float(scale), _ptr(out), obs, ops,
+                                 _stream(torch)), "hsr_block_mean")
+    return out
+
+
+def bilinear_upsample(coarse, Hc: int, Wc: int, factor: int, layout: str = PLANAR,
+                      out_layout: Optional[str] = None, nb: Optional[int] = None):
+    """Pixel-centre aligned bilinear upsampling by an integer factor (edge clamp)."""
+    torch = nat.require_gpu()
+    lib = nat.load()
+    ibs, ips, n, npc = _img(coarse, layout, nb)
+    if npc != Hc * Wc or coarse.dtype != torch.float32:
+        raise ValueError("bilinear_upsample: coarse must be a float32 image with Hc*Wc pixels")
+    ol = out_layout or layout
+    out = alloc_image(torch, n, Hc * factor * Wc * factor, ol, coarse.device)
+    obs, ops, _, _ = _img(out, ol, n)
+    nat.check(lib.hsr_bilinear_upsample(_ptr(coarse), ibs, ips, n, Hc, Wc, factor, _ptr(out), obs, ops,
+                                        _stream(torch)), "hsr_bilinear_upsample")
+    return out
+
+
 def probe_read_bandwidth(nbytes: int = 1 << 30, iters: int = 10, device="cuda:0") -> float:
     """Measured pure-read HBM rate of this box in bytes/s (diagnostic for the roofline report)."""
     torch = nat.require_gpu()

@@ -197,3 +197,76 @@ def calibrate_pseudo_to_real_linear(pseudo_stack, real_stack, valid_mask, min_va
     corrected = eng.poly_apply(x, coeffs, None, None, clip=False, layout=nat.PLANAR)
     params = [(float(a), float(b)) for a, b in coeffs.cpu().numpy()]
     return corrected.reshape(nb, H, W).cpu().numpy(), params
+
+
+def match_pair(R, emit_w, srf_dict, good_mask, s2_rgb_hi, factor: int = 6, deg: int = 4, use_ot: bool = True,
+               n_samples: int = 5000, reg: float = 0.05, numItermax: int = 300, stopThr: float = 1e-6, seed: int = 0,
+               src_scale: float = 1.0 / 255.0, rgb_bands=("B4", "B3", "B2"), positive_band: str = "B2",
+               as_numpy: bool = True):
+    """The reference driver (s2_emit/poly_regression.py:96-172 == notebook cell 81) on in-memory,
+    grid-aligned arrays, device resident:
+
+      phase 1  SRF integration of the three RGB bands (K1), valid60 = finite & (B2 > 0)        :101-106
+      phase 2  real S2 RGB (Hh,Wh,3) uint8/float -> 60 m by an f x f block mean, * src_scale   :110-118
+      phase 3  shared 2/98 percentile stretch of both, fit, apply at 60 m                      :122-139
+               use_ot=True : fit_ot_poly_rgb (Sinkhorn targets, host PCG64 sampling -> one sync)
+               use_ot=False: per-channel least squares over all valid pixels (no sync)
+      phase 4  bilinear x f to the S2 grid, stretch inside the finite mask, apply at 10 m      :150-162
+
+    R (H,W,B) float32 (NumPy or GPU tensor); s2_rgb_hi (H*f, W*f, 3).  Returns a dict with
+    ``coeffs`` (3, deg+1), ``emit_rgb_matched_60m`` (H,W,3), ``s2_rgb_60m_n`` (H,W,3), ``valid60`` (H,W),
+    ``emit_rgb_10m_matched`` (H*f, W*f, 3), ``mask10`` - NumPy arrays, or GPU tensors if as_numpy=False.
+    The two resampling steps replace GDAL's reproject for aligned grids (parity unpinned, see hsr.h).
+    """
+    torch = nat.require_gpu()
+    from .poly_regression import fit_ot_poly_rgb
+    dev = torch.device("cuda", torch.cuda.current_device())
+    sub = {}
+    for b in rgb_bands:
+        if b not in srf_dict:
+            raise ValueError(f"Band {b} is None/missing in pseudo_s2.")
+        sub[b] = srf_dict[b]
+    table = eng.build_srf_table(emit_w, sub, good_mask)
+    if table.supported != list(rgb_bands):
+        missing = [b for b in rgb_bands if b not in table.supported][0]
+        raise ValueError(f"Band {missing} is None/missing in pseudo_s2.")
+    cube = R if type(R).__module__.startswith("torch") else torch.from_numpy(np.ascontiguousarray(R, dtype=np.float32))
+    cube = cube.to(dev, torch.float32).contiguous()
+    H, W = int(cube.shape[0]), int(cube.shape[1])
+    s2 = s2_rgb_hi if type(s2_rgb_hi).__module__.startswith("torch") else torch.from_numpy(np.ascontiguousarray(s2_rgb_hi))
+    s2 = s2.to(dev).contiguous()
+    if s2.dtype not in (torch.uint8, torch.uint16, torch.float32):
+        s2 = s2.to(torch.float32)
+    if tuple(s2.shape) != (H * factor, W * factor, 3):
+        raise ValueError(f"s2_rgb_hi must be ({H * factor},{W * factor},3) for factor {factor}; got {tuple(s2.shape)}")
+    PM = nat.PIXMAJOR
+    emit_rgb = eng.srf_integrate(cube, table, layout=PM)                                   # (npix, 4): R,G,B,pad
+    s2_60 = eng.block_mean(s2.reshape(-1, 3), H, W, factor, src_scale, layout=PM, nb=3)     # (npix, 4)
+    pos = list(rgb_bands).index(positive_band)
+    valid60 = eng.valid_mask(emit_rgb, pos, s2_60, None, PM, nbx=3, nby=3)
+    lohi_e = eng.percentile_limits(emit_rgb, valid60, 2, 98, PM, nb=3)
+    lohi_s = eng.percentile_limits(s2_60, valid60, 2, 98, PM, nb=3)
+    s2_n = eng.poly_apply_stretch_only(s2_60, lohi_s, PM, nb=3)
+    if use_ot:
+        emit_n = eng.poly_apply_stretch_only(emit_rgb, lohi_e, PM, nb=3)
+        co = fit_ot_poly_rgb(emit_n[:, :3].reshape(H, W, 3).cpu().numpy(), s2_n[:, :3].reshape(H, W, 3).cpu().numpy(),
+                             valid60.reshape(H, W).cpu().numpy().astype(bool), deg=deg, n_samples=n_samples, reg=reg,
+                             numItermax=numItermax, stopThr=stopThr, seed=seed)
+        coeffs = torch.from_numpy(np.ascontiguousarray(co)).to(dev)
+    else:
+        ws = eng.MomentWorkspace(dev, 3, deg)
+        mom = eng.poly_moments(emit_rgb, s2_60, deg, ws, valid60, lohi_x=lohi_e, lohi_y=lohi_s, layout=PM, nb=3)
+        coeffs = eng.poly_solve(mom, deg, 200).clone()
+    matched60 = eng.poly_apply(emit_rgb, coeffs, valid60, lohi_e, True, PM, nb=3)
+    emit_rgb_10 = eng.bilinear_upsample(emit_rgb, H, W, factor, layout=PM, nb=3)
+    mask10 = eng.valid_mask(emit_rgb_10, -1, None, None, PM, nbx=3)
+    lohi10 = eng.percentile_limits(emit_rgb_10, mask10, 2, 98, PM, nb=3)
+    matched10 = eng.poly_apply(emit_rgb_10, coeffs, mask10, lohi10, True, PM, nb=3)
+    Hh, Wh = H * factor, W * factor
+    res = dict(coeffs=coeffs, emit_rgb_matched_60m=matched60[:, :3].reshape(H, W, 3),
+               s2_rgb_60m_n=s2_n[:, :3].reshape(H, W, 3), valid60=valid60.reshape(H, W).bool(),
+               emit_rgb_10m_matched=matched10[:, :3].reshape(Hh, Wh, 3), mask10=mask10.reshape(Hh, Wh).bool(),
+               lohi_emit_60m=lohi_e, lohi_s2_60m=lohi_s, lohi_emit_10m=lohi10)
+    if as_numpy:
+        res = {k: v.cpu().numpy() for k, v in res.items()}
+    return res

@@ -187,6 +187,18 @@ int hsr_polyfeat_predict(const float* x_dev, int64_t x_ps, int64_t x_cs, const f
                          const float* w_dev, int64_t ldw, const float* bias_dev, int32_t T, int32_t activation,
                          float* out_dev, int64_t out_stride, hsr_stream_t stream);
 
+/* ---- f1: grid-aligned resamplers between the phases -----------------------------------------------
+ * downsample_s2_to_grid ('average') and reproject_stack_to_grid ('bilinear') of the notebook
+ * (Pairs_EMIT_S2_demo-2.ipynb cell 73, raw lines 4538-4599) for exactly aligned integer-factor grids:
+ * an f x f block mean (double accumulate, float32 store, then `* scale` in float32) and a pixel-centre
+ * aligned separable bilinear upsampling with edge clamp.  GDAL parity unpinned (rasterio absent).
+ * in_dtype: 0 float32, 1 uint8, 2 uint16.  Fine grid is (Hc*f, Wc*f); images use (band, pixel) strides. */
+int hsr_block_mean(const void* in_dev, int32_t in_dtype, int64_t in_bs, int64_t in_ps, int32_t nb,
+                   int32_t Hc, int32_t Wc, int32_t factor, float scale,
+                   float* out_dev, int64_t out_bs, int64_t out_ps, hsr_stream_t stream);
+int hsr_bilinear_upsample(const float* in_dev, int64_t in_bs, int64_t in_ps, int32_t nb, int32_t Hc, int32_t Wc,
+                          int32_t factor, float* out_dev, int64_t out_bs, int64_t out_ps, hsr_stream_t stream);
+
 /* ---- tuning --------------------------------------------------------------------------------------
  * LDS tile of K1: 64 pixels (512-thread workgroups, 2 per CU) or 32 pixels (256-thread workgroups,
  * 4 per CU).  Process-wide; results are identical up to the summation tree of the moments. */

@@ -434,6 +434,45 @@ def bilinear_upsample(planes, factor: int):
     return (top * (1 - tr)[None, :, None] + bot * tr[None, :, None]).astype(np.float32)
 
 
+def match_pair_reference(R, emit_w, srf_dict, good_mask, s2_rgb_hi, factor=6, deg=4, use_ot=True,
+                         n_samples=5000, reg=0.05, numItermax=300, stopThr=1e-6, seed=0, src_scale=1.0 / 255.0):
+    """poly_regression.py:96-172 on in-memory aligned arrays, statement by statement; the two GDAL warps
+    are the aligned-grid restatements above (unpinned)."""
+    pseudo = pseudo_s2_srf_integral(R, emit_w, srf_dict, good_mask)                                   # :101
+    emit_sim_60m = np.stack([pseudo[b] for b in ("B2", "B3", "B4")], axis=0).astype(np.float32)       # :103-104
+    with np.errstate(invalid="ignore"):
+        valid60 = np.isfinite(emit_sim_60m).all(axis=0) & (emit_sim_60m[0] > 0)                       # :106
+    s2_planes = np.ascontiguousarray(np.moveaxis(np.asarray(s2_rgb_hi), -1, 0))
+    s2_real_60m = block_mean(s2_planes, factor)                                                        # :110-116
+    s2_real_60m *= float(src_scale)
+    valid60 = valid60 & np.isfinite(s2_real_60m).all(axis=0)                                           # :118
+    emit_rgb_60m = np.transpose(emit_sim_60m[[2, 1, 0], ...], (1, 2, 0))                               # :122
+    s2_rgb_60m = np.transpose(s2_real_60m[[0, 1, 2], ...], (1, 2, 0))                                  # :124
+    emit_rgb_n = apply_shared_percentile_stretch(emit_rgb_60m, valid60)                                # :126
+    s2_rgb_n = apply_shared_percentile_stretch(s2_rgb_60m, valid60)                                    # :127
+    if use_ot:
+        coeffs = fit_ot_poly_rgb(emit_rgb_n, s2_rgb_n, valid60, deg=deg, n_samples=n_samples, reg=reg,
+                                 numItermax=numItermax, stopThr=stopThr, seed=seed)                    # :129-137
+    else:
+        x = np.moveaxis(emit_rgb_n, -1, 0)
+        y = np.moveaxis(s2_rgb_n, -1, 0)
+        coeffs = np.zeros((3, deg + 1))
+        for c in range(3):
+            xs, ys = x[c][valid60].astype(np.float64), y[c][valid60].astype(np.float64)
+            if xs.size < 200:
+                coeffs[c, -2] = 1.0
+            else:
+                coeffs[c] = np.polyfit(xs, ys, deg)
+    emit_rgb_matched_60m = apply_poly_rgb(emit_rgb_n, coeffs, mask=valid60)                            # :139
+    emit_sim_10m = bilinear_upsample(emit_sim_60m, factor)                                             # :150-155
+    emit_rgb_10m = np.transpose(emit_sim_10m[[2, 1, 0], ...], (1, 2, 0))                               # :157
+    mask10 = np.isfinite(emit_rgb_10m).all(axis=-1)                                                    # :159
+    emit_rgb_10m_n = apply_shared_percentile_stretch(emit_rgb_10m, mask10)                             # :161
+    emit_rgb_10m_matched = apply_poly_rgb(emit_rgb_10m_n, coeffs, mask=mask10)                         # :162
+    return dict(coeffs=coeffs, emit_rgb_matched_60m=emit_rgb_matched_60m, s2_rgb_60m_n=s2_rgb_n, valid60=valid60,
+                emit_rgb_10m_matched=emit_rgb_10m_matched, mask10=mask10)
+
+
 # ---------------------------------------------------------------------------------------------
 # Synthetic inputs of SURVEY.md 8(d) (NumPy, for the small parity cases and the CPU baseline)
 # ---------------------------------------------------------------------------------------------

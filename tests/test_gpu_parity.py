@@ -546,3 +546,60 @@ def test_poly_ridge_many_targets_vs_oracle(torch_gpu):
     pc = model.predict_cube(np.ascontiguousarray(Xt[:770].T.reshape(Cin, 22, 35)))
     np.testing.assert_allclose(pc.reshape(T, -1).T, onp.sigmoid(onp.ridge_poly_predict(ref, Xt[:770].astype(np.float64))),
                                rtol=0, atol=1e-4)
+
+
+# ---------------------------------------------------------------------------------------------
+# f1 resamplers and the reference-ordered driver (a7)
+# ---------------------------------------------------------------------------------------------
+def test_resamplers_vs_oracle(torch_gpu):
+    torch = torch_gpu
+    from s2_emit import _engine as eng
+    from s2_emit import _native as nat
+    rng = np.random.default_rng(41)
+    fine8 = rng.integers(0, 256, (3, 30, 42), dtype=np.uint8)
+    ref = onp.block_mean(fine8, 6)
+    ref = ref * np.float32(1.0 / 255.0)
+    got = eng.block_mean(torch.from_numpy(fine8).cuda().reshape(3, -1), 5, 7, 6, 1.0 / 255.0).cpu().numpy()
+    np.testing.assert_array_equal(got.reshape(3, 5, 7), ref)
+    fine32 = rng.random((2, 24, 16)).astype(np.float32)
+    got = eng.block_mean(torch.from_numpy(fine32).cuda().reshape(2, -1), 6, 4, 4).cpu().numpy()
+    np.testing.assert_allclose(got.reshape(2, 6, 4), onp.block_mean(fine32, 4), rtol=1e-7)
+    pm = torch.from_numpy(np.ascontiguousarray(np.moveaxis(fine8, 0, -1))).cuda().reshape(-1, 3)   # (npix, 3) uint8
+    got_pm = eng.block_mean(pm, 5, 7, 6, 1.0 / 255.0, layout=nat.PIXMAJOR, nb=3)
+    np.testing.assert_array_equal(got_pm[:, :3].t().cpu().numpy().reshape(3, 5, 7), ref)
+    coarse = rng.random((3, 9, 11)).astype(np.float32)
+    coarse[1, 4, 4] = np.nan
+    up = eng.bilinear_upsample(torch.from_numpy(coarse).cuda().reshape(3, -1), 9, 11, 6).cpu().numpy().reshape(3, 54, 66)
+    refu = onp.bilinear_upsample(coarse, 6)
+    assert np.array_equal(np.isnan(up), np.isnan(refu))
+    np.testing.assert_allclose(up[~np.isnan(refu)], refu[~np.isnan(refu)], rtol=2e-7, atol=1e-7)
+
+
+@pytest.mark.parametrize("use_ot", [False, True])
+def test_match_pair_reference_driver(torch_gpu, use_ot):
+    """The whole reference driver (poly_regression.py:96-172) on a synthetic aligned pair vs the oracle."""
+    import s2_emit
+    srf = onp.synthetic_srf()
+    w, good = onp.synthetic_wavelengths()
+    H, W, f = 40, 36, 6
+    R = onp.synthetic_cube(H, W, seed=21)
+    R[3, 4, :] = -0.01                       # B2 <= 0 -> invalid at 60 m
+    R[10, 10, 50] = np.nan                   # non-finite spectrum
+    rng = np.random.default_rng(5)
+    ps = onp.pseudo_s2_srf_integral(R, w, srf, good)
+    rgb60 = np.stack([ps["B4"], ps["B3"], ps["B2"]], -1)
+    hi = np.repeat(np.repeat(np.nan_to_num(rgb60, nan=0.1), f, 0), f, 1)
+    s2_hi = np.clip((hi / 0.45) ** 0.8 * 255 + rng.normal(0, 6, hi.shape), 0, 255).astype(np.uint8)
+    ref = onp.match_pair_reference(R, w, srf, good, s2_hi, f, deg=4 if use_ot else 3, use_ot=use_ot, n_samples=600)
+    got = s2_emit.match_pair(R, w, srf, good, s2_hi, f, deg=4 if use_ot else 3, use_ot=use_ot, n_samples=600)
+    assert np.array_equal(got["valid60"], ref["valid60"]) and not ref["valid60"][3, 4] and not ref["valid60"][10, 10]
+    assert np.array_equal(got["mask10"], ref["mask10"])
+    np.testing.assert_allclose(got["s2_rgb_60m_n"], ref["s2_rgb_60m_n"], rtol=0, atol=2e-6)
+    xs = np.linspace(0, 1, 33)
+    for c in range(3):
+        np.testing.assert_allclose(np.polyval(got["coeffs"][c], xs), np.polyval(ref["coeffs"][c], xs), rtol=0, atol=2e-4)
+    m = ref["valid60"]
+    np.testing.assert_allclose(got["emit_rgb_matched_60m"][m], ref["emit_rgb_matched_60m"][m], rtol=0, atol=3e-4)
+    m10 = ref["mask10"]
+    np.testing.assert_allclose(got["emit_rgb_10m_matched"][m10], ref["emit_rgb_10m_matched"][m10], rtol=0, atol=3e-4)
+    assert np.array_equal(np.isnan(got["emit_rgb_10m_matched"]), np.isnan(ref["emit_rgb_10m_matched"]))

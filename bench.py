@@ -45,6 +45,11 @@ def parse_args():
     ap.add_argument("--cpu-rows", type=int, default=1024, help="rows of the cube the CPU baseline processes")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="torch.distributed backend for N > 1: nccl (= RCCL over xGMI; the measured configuration) or gloo "
+                         "(CPU-side rehearsal of the multi-rank control flow)")
+    ap.add_argument("--same-device", action="store_true",
+                    help="rehearsal only: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--event-every", type=int, default=4,
                     help="bracket the K1+K2 kernel with HIP events on every n-th timed step (each pair of event "
                          "records costs ~12 us of launch gap, so not on every step)")
@@ -87,11 +92,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
+    if args.same_device:
+        if args.backend != "gloo":
+            raise SystemExit("--same-device is a rehearsal mode and needs --backend gloo (RCCL wants one GPU per rank)")
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=device)     # "nccl" is RCCL on ROCm
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=device)     # "nccl" is RCCL on ROCm
+        else:
+            dist.init_process_group("gloo")
 
     H, W, B = args.height, args.width, args.bands
     prob = device_problem(H, W, B, deg=args.deg, seed=rank, device=device)
@@ -148,7 +160,8 @@ def main():
                 "config": {"workload": f"{H}x{W}x{B} EMIT-like cube + {len(prob.names)} real-S2 planes per GPU, "
                                        f"deg-{args.deg} per-band least squares over all valid pixels "
                                        f"(BASELINE.json configs[2]; one tile per GPU for N>1)",
-                           "tiles_per_gpu": 1, "coeff_sync": args.coeff_sync if world > 1 else "none"},
+                           "tiles_per_gpu": 1, "coeff_sync": args.coeff_sync if world > 1 else "none",
+                           "backend": (args.backend if world > 1 else "none") + (" (rehearsal: all ranks on cuda:0)" if args.same_device else "")},
                 "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args)

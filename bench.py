@@ -50,6 +50,8 @@ def parse_args():
                          "(CPU-side rehearsal of the multi-rank control flow)")
     ap.add_argument("--same-device", action="store_true",
                     help="rehearsal only: every rank uses cuda:0 (needs --backend gloo)")
+    ap.add_argument("--pipeline", default="auto", choices=["auto", "on", "off"],
+                    help="one-tile-deep software pipeline (exchange of tile i under K1 of tile i+1); auto = on for N > 1")
     ap.add_argument("--event-every", type=int, default=4,
                     help="bracket the K1+K2 kernel with HIP events on every n-th timed step (each pair of event "
                          "records costs ~12 us of launch gap, so not on every step)")
@@ -116,15 +118,30 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    pipelined = args.pipeline == "on" or (args.pipeline == "auto" and world > 1)
+    if pipelined:      # keep one CU free of persistent K1 workgroups for the side-stream fit kernels / RCCL
+        from s2_emit import _native as nat
+        nat.check(nat.load().hsr_set_srf_reserved_cus(1))
+
+    def run_step(k1_events=None):
+        if pipelined:
+            plan.submit(prob.cube, real, k1_events=k1_events)
+        else:
+            plan.step(prob.cube, real, k1_events=k1_events)
+
     for _ in range(args.warmup):
-        plan.step(prob.cube, real)
+        run_step()
+    if pipelined:
+        plan.flush()
     barrier()
     every = max(1, args.event_every)
     ev = {i: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for i in range(0, args.steps, every)}
     t0 = time.perf_counter()
     for i in range(args.steps):
-        plan.step(prob.cube, real, k1_events=ev.get(i))
+        run_step(ev.get(i))
+    if pipelined:
+        plan.flush()            # the last tile's apply belongs to the timed region
     barrier()
     dt = time.perf_counter() - t0
 
@@ -161,6 +178,7 @@ def main():
                                        f"deg-{args.deg} per-band least squares over all valid pixels "
                                        f"(BASELINE.json configs[2]; one tile per GPU for N>1)",
                            "tiles_per_gpu": 1, "coeff_sync": args.coeff_sync if world > 1 else "none",
+                           "pipeline": "one tile deep" if pipelined else "off",
                            "backend": (args.backend if world > 1 else "none") + (" (rehearsal: all ranks on cuda:0)" if args.same_device else "")},
                 "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:

@@ -86,6 +86,9 @@ constexpr int kScanBatch = 5;                       // ds_read_b128 in flight pe
 // Both keep 16 waves (4 per SIMD, <= 128 VGPRs) and ~146 KB of LDS tiles per CU; the smaller tile
 // gives the CU's memory pipe four queued customers instead of two (see DESIGN.md, K1 tuning).
 static int g_tile_pixels = 64;
+// CUs left without a persistent K1 workgroup so that small kernels on another stream (slot reduction,
+// RCCL exchange, solve) can run while K1 of the next tile owns the rest of the chip.
+static int g_reserved_cus = 0;
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -406,7 +409,7 @@ int srf_partial_slots(int64_t npix) {
   const int P = g_tile_pixels;
   int64_t tiles = (npix + P - 1) / P;
   if (tiles < 1) tiles = 1;
-  const int64_t cap = P == 64 ? 512 : 1024;  // 256 CUs x (2 | 4) resident workgroups
+  const int64_t cap = (int64_t)(256 - g_reserved_cus) * (P == 64 ? 2 : 4);  // CUs x resident workgroups
   return (int)(tiles < cap ? tiles : cap);
 }
 
@@ -476,6 +479,12 @@ extern "C" int hsr_set_srf_tile(int32_t pixels) {
 }
 
 extern "C" int hsr_get_srf_tile(void) { return hsr::g_tile_pixels; }
+
+extern "C" int hsr_set_srf_reserved_cus(int32_t cus) {
+  HSR_REQUIRE(cus >= 0 && cus <= 128, HSR_ERR_INVALID, "hsr_set_srf_reserved_cus: %d outside [0,128]", cus);
+  hsr::g_reserved_cus = cus;
+  return HSR_OK;
+}
 
 extern "C" int hsr_srf_integrate(const float* cube_dev, int64_t npix, int32_t B, const float* wn_dev,
                                  const int32_t* k0, const int32_t* klen, int32_t nb, float* out_dev,

@@ -68,6 +68,7 @@ SIGNATURES = {
     "hsr_bilinear_upsample": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _i64, _vp]),
     "hsr_set_srf_tile": (C.c_int, [_i32]),
     "hsr_get_srf_tile": (C.c_int, []),
+    "hsr_set_srf_reserved_cus": (C.c_int, [_i32]),
     "hsr_probe_read": (C.c_int, [_vp, _i64, _vp, _vp]),
 }
 

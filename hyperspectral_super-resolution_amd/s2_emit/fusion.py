@@ -99,6 +99,7 @@ class SpectralFusion:
             raise ValueError(f"layout must be {nat.PIXMAJOR!r} or {nat.PLANAR!r}")
         self.layout = layout
         self.force_exchange = bool(force_exchange)   # run the collective path even with one rank (tests)
+        self._pipe = None                            # state of submit()/flush(), created on first use
         self.ws = eng.MomentWorkspace(self.device, self.table.nb, deg)
         self.table.device_weights(self.device)
         self._buf: Dict[int, Tuple[object, object]] = {}
@@ -161,6 +162,72 @@ class SpectralFusion:
         matched = eng.poly_apply(pseudo, coeffs, mask if self.apply_mask else None, None, self.clip,
                                  self.layout, out=matched, nb=self.table.nb)
         return FusionOutput(self.names, pseudo, moments, coeffs, matched, self.layout)
+
+
+    # ---- one-tile-deep software pipeline -----------------------------------------------------------
+    # submit(i) enqueues K1+K2 of tile i on the caller's stream, the fit of tile i (slot reduction ->
+    # RCCL exchange -> solve) on a side stream, and K3 of tile i-1 on the caller's stream.  The exchange
+    # of tile i therefore runs underneath K1 of tile i+1 ("overlap the collective of tile i
+    # with K1 of tile i+1").  Outputs live in two alternating buffer sets: the FusionOutput returned for
+    # tile i is valid until the second submit() after it.
+    def _pipe_state(self, npix: int):
+        torch = nat.require_gpu()
+        if self._pipe is None or self._pipe["npix"] != npix:
+            nb = self.table.nb
+            slots = []
+            for _ in range(2):
+                slots.append(dict(pseudo=eng.alloc_image(torch, nb, npix, self.layout, self.device),
+                                  matched=eng.alloc_image(torch, nb, npix, self.layout, self.device),
+                                  ws=eng.MomentWorkspace(self.device, nb, self.deg),
+                                  ev_k1=torch.cuda.Event(), ev_fit=torch.cuda.Event(), mask=None))
+            self._pipe = dict(npix=npix, slots=slots, n=0, pending=None, side=torch.cuda.Stream(device=self.device))
+        return self._pipe
+
+    def _pipe_apply(self, slot) -> FusionOutput:
+        torch = nat.require_gpu()
+        torch.cuda.current_stream().wait_event(slot["ev_fit"])
+        ws = slot["ws"]
+        matched = eng.poly_apply(slot["pseudo"], ws.coeffs, slot["mask"] if self.apply_mask else None, None, self.clip,
+                                 self.layout, out=slot["matched"], nb=self.table.nb)
+        return FusionOutput(self.names, slot["pseudo"], ws.moments, ws.coeffs, matched, self.layout)
+
+    def submit(self, cube, real, mask=None, k1_events=None) -> Optional[FusionOutput]:
+        """Pipelined step: start tile i, finish tile i-1.  Returns tile i-1's output (None on the first call)."""
+        torch = nat.require_gpu()
+        npix = cube.numel() // cube.shape[-1]
+        real, real_layout = self._real_image(real, npix)
+        st = self._pipe_state(npix)
+        slot = st["slots"][st["n"] % 2]
+        ws = slot["ws"]
+        main = torch.cuda.current_stream()
+        eng.srf_integrate_moments(cube, self.table, real, self.deg, ws, mask, self.min_valid, self.min_valid,
+                                  out=slot["pseudo"], events=k1_events, reduce=False, layout=self.layout,
+                                  real_layout=real_layout)
+        slot["mask"] = mask
+        slot["ev_k1"].record(main)
+        with torch.cuda.stream(st["side"]):
+            st["side"].wait_event(slot["ev_k1"])
+            if self._exchanges():
+                moments = eng.moments_reduce(ws)
+                exchange_moments(moments, lambda m, _ws=ws: eng.poly_solve(m, self.deg, self.min_count, out=_ws.coeffs),
+                                 self.group, self.coeff_sync)
+            else:
+                eng.moments_reduce_solve(ws, self.min_count)
+            slot["ev_fit"].record(st["side"])
+        prev = st["pending"]
+        out = self._pipe_apply(prev) if prev is not None else None
+        st["pending"] = slot
+        st["n"] += 1
+        return out
+
+    def flush(self) -> Optional[FusionOutput]:
+        """Finish the tile left in the pipeline by the last submit()."""
+        st = self._pipe
+        if st is None or st["pending"] is None:
+            return None
+        out = self._pipe_apply(st["pending"])
+        st["pending"] = None
+        return out
 
 
 def fuse_pair(R, emit_w, srf_dict, good_mask, real_s2: Dict[str, np.ndarray], deg: int = 3,

@@ -204,6 +204,10 @@ int hsr_bilinear_upsample(const float* in_dev, int64_t in_bs, int64_t in_ps, int
  * 4 per CU).  Process-wide; results are identical up to the summation tree of the moments. */
 int hsr_set_srf_tile(int32_t pixels);
 int hsr_get_srf_tile(void);
+/* Leave `cus` compute units without a persistent K1 workgroup (default 0): lets the small kernels of the
+ * previous tile's fit (slot reduction, RCCL exchange, solve) run on another stream while K1 streams the next
+ * tile.  Changes the slot count, hence only the summation tree of the moments. */
+int hsr_set_srf_reserved_cus(int32_t cus);
 
 /* ---- diagnostics -------------------------------------------------------------------------------
  * Pure streaming read of `bytes` bytes (16 B per lane, coalesced) folded into sink_dev[64]: the

@@ -603,3 +603,41 @@ def test_match_pair_reference_driver(torch_gpu, use_ot):
     m10 = ref["mask10"]
     np.testing.assert_allclose(got["emit_rgb_10m_matched"][m10], ref["emit_rgb_10m_matched"][m10], rtol=0, atol=3e-4)
     assert np.array_equal(np.isnan(got["emit_rgb_10m_matched"]), np.isnan(ref["emit_rgb_10m_matched"]))
+
+
+def test_pipelined_submit_flush_matches_step(torch_gpu):
+    """submit()/flush() (one tile in flight on a side stream) must reproduce step() bit for bit, tile by tile."""
+    torch = torch_gpu
+    from s2_emit import SpectralFusion
+    from s2_emit import _native as nat
+    srf = onp.synthetic_srf()
+    w, good = onp.synthetic_wavelengths()
+    tiles = []
+    for seed in range(4):
+        R = torch.from_numpy(onp.synthetic_cube(64, 48, seed=30 + seed)).cuda()
+        ps = onp.pseudo_s2_srf_integral(R.cpu().numpy(), w, srf, good)
+        names = [k for k, v in ps.items() if v is not None]
+        real = torch.from_numpy(onp.synthetic_real_planes(np.stack([ps[k] for k in names]).astype(np.float32), seed=seed)).cuda()
+        tiles.append((R, real))
+    try:
+        nat.check(nat.load().hsr_set_srf_reserved_cus(1))
+        ref_plan = SpectralFusion(w, srf, good, deg=3)
+        refs = []
+        for R, real in tiles:
+            o = ref_plan.step(R, real, reuse_buffers=False)
+            refs.append((o.coeffs.clone(), o.matched.clone()))
+        plan = SpectralFusion(w, srf, good, deg=3)
+        outs = []
+        for R, real in tiles:
+            o = plan.submit(R, real)
+            if o is not None:
+                outs.append((o.coeffs.clone(), o.matched.clone()))
+        o = plan.flush()
+        outs.append((o.coeffs.clone(), o.matched.clone()))
+        assert plan.flush() is None
+        torch.cuda.synchronize()
+        assert len(outs) == len(refs) == 4
+        for (c, m), (rc, rm) in zip(outs, refs):
+            assert torch.equal(c, rc) and torch.equal(m.view(torch.int32), rm.view(torch.int32))
+    finally:
+        nat.check(nat.load().hsr_set_srf_reserved_cus(0))

@@ -588,7 +588,10 @@ extern "C" int hsr_poly_apply(const float* x_dev, int64_t x_bs, int64_t x_ps, co
   if (x_bs == 1 && out_bs == 1 && x_ps == out_ps && !(x_ps == 1 && nb > 1)) {  // pixel-major in and out, same rows
     const int64_t q = x_ps >> 2;
     if (aligned && (x_ps & 3) == 0 && q >= 1 && q <= 4 && npix * q < ((int64_t)1 << 31)) {
-      const dim3 grid(stream_grid(npix * q, 256 * 4));
+      // one pass when it fits (4 x 16 B per thread): no grid-stride tail imbalance on a ~20 us kernel
+      int64_t gb = (npix * q + 256 * 4 - 1) / (256 * 4);
+      if (gb > 8192) gb = 2048;
+      const dim3 grid((unsigned)(gb < 1 ? 1 : gb));
       switch (q) {
         case 1: hipLaunchKernelGGL(apply_pixmajor_kernel<1>, grid, dim3(256), 0, s, a); break;
         case 2: hipLaunchKernelGGL(apply_pixmajor_kernel<2>, grid, dim3(256), 0, s, a); break;

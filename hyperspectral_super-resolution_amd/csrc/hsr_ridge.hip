@@ -220,6 +220,181 @@ __global__ __launch_bounds__(kPredThreads) void predict_kernel(const PredArgs a)
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// predict, specialised for the notebook's shape (10 inputs, degree 3 -> 285 monomials): MFMA-bound
+// ------------------------------------------------------------------------------------------------
+// The generic kernel above stages a 64 x 286 feature tile in LDS (73 KB -> one workgroup per CU) and fetches
+// W from global memory per MFMA: 10-12 % of the f32 matrix peak.  Here every lane keeps the 10 standardised
+// inputs of its pixel in registers and the monomials are generated by fully unrolled code from a
+// compile-time table (2-5 VALU ops per MFMA, hidden under the 64-cycle v_mfma_f32_32x32x2_f32), W lives in
+// LDS (whole when it fits, otherwise double-buffered 32-row chunks), and a workgroup covers 128 pixels with
+// all four waves busy.  Targets sit on the M axis so each accumulator register is 32 consecutive pixels of
+// one target: coalesced band-major stores.
+struct Tab103 {
+  uint8_t v[286][3];
+};
+constexpr Tab103 make_tab103() {
+  Tab103 t{};
+  int f = 0;
+  for (int d = 1; d <= 3; ++d) {
+    int c[3] = {0, 0, 0};
+    while (true) {
+      for (int k = 0; k < 3; ++k) t.v[f][k] = (uint8_t)(k < d ? c[k] : 10);
+      ++f;
+      int pos = d - 1;
+      while (pos >= 0 && c[pos] == 9) --pos;
+      if (pos < 0) break;
+      const int nv = c[pos] + 1;
+      for (int k = pos; k < d; ++k) c[k] = nv;
+    }
+  }
+  t.v[285][0] = t.v[285][1] = t.v[285][2] = 10;   // padding monomial (its W row is zero)
+  return t;
+}
+constexpr Tab103 kTab103 = make_tab103();
+constexpr int kSteps103 = 143;      // 286 / 2
+constexpr int kChunkRows = 32;      // W rows per LDS chunk (16 MFMA steps)
+
+template <int S0, int S1, int TT>
+__device__ __forceinline__ void mfma_steps103(const float (&z)[11], int kh, const float* __restrict__ wl, int ldwl,
+                                              int row0, int j, f32x16 (&acc)[TT]) {
+  // Hand-pipelined: the W operands of step s+1 are read from LDS before the MFMAs of step s, and a
+  // scheduling barrier per step stops hipcc from hoisting all 286 monomial products ahead of the MFMA
+  // chain (which cost 230-256 VGPRs and spills).  Per step: 2-4 v_mul + 1 v_cndmask + TT ds_read_b32 under
+  // TT x 64 cycles of MFMA.
+  float wc[TT], wn[TT];
+  {
+    const float* wr = wl + (2 * S0 + kh - row0) * ldwl + j;   // A[i = target][k] = W[k][target]
+#pragma unroll
+    for (int q = 0; q < TT; ++q) wc[q] = wr[q * 32];
+  }
+#pragma unroll
+  for (int s = S0; s < S1; ++s) {
+    const float p0 = z[kTab103.v[2 * s][0]] * z[kTab103.v[2 * s][1]] * z[kTab103.v[2 * s][2]];
+    const float p1 = z[kTab103.v[2 * s + 1][0]] * z[kTab103.v[2 * s + 1][1]] * z[kTab103.v[2 * s + 1][2]];
+    const float bv = kh ? p1 : p0;                            // B[k = 2s + kh][pixel j]
+    if (s + 1 < S1) {
+      const float* wr = wl + (2 * (s + 1) + kh - row0) * ldwl + j;
+#pragma unroll
+      for (int q = 0; q < TT; ++q) wn[q] = wr[q * 32];
+    }
+#pragma unroll
+    for (int q = 0; q < TT; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[q], bv, acc[q], 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < TT; ++q) wc[q] = wn[q];
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int TT, bool WHOLE>
+__global__ __launch_bounds__(256, 2) void predict103_kernel(const PredArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* wl = reinterpret_cast<float*>(smem);
+  constexpr int Tp = TT * 32;                       // padded target count held by every wave
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int j = lane & 31, kh = lane >> 5;
+  if (WHOLE) {                                      // W (286 x Tp) resident for the whole launch
+    for (int i = t; i < 286 * Tp; i += 256) {
+      const int r = i / Tp, c = i % Tp;
+      wl[i] = c < a.T ? a.W[(size_t)r * a.ldw + c] : 0.0f;
+    }
+    __syncthreads();
+  }
+  for (int64_t tile = blockIdx.x; tile * 128 < a.npix; tile += gridDim.x) {
+    const int64_t p = tile * 128 + wave * 32 + j;
+    const int64_t pc = p < a.npix ? p : a.npix - 1;
+    float z[11];
+#pragma unroll
+    for (int c = 0; c < 10; ++c) z[c] = (a.x[pc * a.x_ps + c * a.x_cs] - a.mean[c]) * a.inv[c];
+    z[10] = 1.0f;
+    f32x16 acc[TT];
+#pragma unroll
+    for (int q = 0; q < TT; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
+    if (WHOLE) {
+      mfma_steps103<0, kSteps103, TT>(z, kh, wl, Tp, 0, j, acc);
+    } else {
+      // 9 chunks of 32 W rows (the last has 30), double-buffered: chunk c+1 is copied while chunk c is used
+      auto stage = [&](int c, int buf) {
+        float* dst = wl + buf * kChunkRows * Tp;
+        const int rows = c == 8 ? 286 - 8 * kChunkRows : kChunkRows;
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll 2
+        for (int i = t; i < rows * Tp; i += 256) {
+          const int r = i / Tp, col = i % Tp;
+          dst[i] = col < a.T ? a.W[(size_t)(c * kChunkRows + r) * a.ldw + col] : 0.0f;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      stage(0, 0);
+      __syncthreads();
+#define HSR_CHUNK(C)                                                                                   \
+  do {                                                                                                 \
+    if (C < 8) stage(C + 1, (C + 1) & 1);                                                              \
+    mfma_steps103<C * 16, (C == 8 ? kSteps103 : C * 16 + 16), TT>(z, kh, wl + (C & 1) * kChunkRows * Tp, Tp, \
+                                                                  C * kChunkRows, j, acc);               \
+    __syncthreads();                                                                                   \
+  } while (0)
+      HSR_CHUNK(0); HSR_CHUNK(1); HSR_CHUNK(2); HSR_CHUNK(3); HSR_CHUNK(4);
+      HSR_CHUNK(5); HSR_CHUNK(6); HSR_CHUNK(7); HSR_CHUNK(8);
+#undef HSR_CHUNK
+    }
+    if (p < a.npix) {
+      // keep the epilogue's addressing inside the tile loop: hoisted out of it (LICM) the 64-bit offsets of
+      // all 16*TT accumulator rows cost up to 288 VGPRs and spilled the accumulators
+      int64_t ostride = a.out_stride;
+      int tmax = a.T;
+      asm volatile("" : "+s"(ostride), "+s"(tmax));
+      float* orow = a.out + (size_t)(4 * kh) * ostride + p;
+#pragma unroll
+      for (int q = 0; q < TT; ++q) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int tu = q * 32 + (r & 3) + 8 * (r >> 2);      // wave-uniform part of the target index
+          const int trg = tu + 4 * kh;
+          if (trg < tmax) {
+            float v = acc[q][r] + a.bias[trg];
+            if (a.act) {
+              v = v < -50.0f ? -50.0f : (v > 50.0f ? 50.0f : v);
+              v = 1.0f / (1.0f + __expf(-v));
+            }
+            orow[(size_t)tu * ostride] = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+template <int TT, bool WHOLE>
+static void launch_predict103(const PredArgs& a, hipStream_t s) {
+  const size_t lds = WHOLE ? (size_t)286 * TT * 32 * 4 : (size_t)2 * kChunkRows * TT * 32 * 4;
+  static thread_local bool configured = false;
+  if (!configured) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(predict103_kernel<TT, WHOLE>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipGetLastError();
+    configured = true;
+  }
+  int64_t tiles = (a.npix + 127) / 128;
+  const int grid = (int)(tiles < 512 ? tiles : 512);
+  hipLaunchKernelGGL((predict103_kernel<TT, WHOLE>), dim3(grid), dim3(256), lds, s, a);
+}
+
+// returns false when the shape is not covered (caller falls back to the generic kernel)
+static bool try_predict103(const PredArgs& a, hipStream_t s) {
+  if (a.n_in != 10 || a.nfeat != 285) return false;
+  const int tt = a.ttiles;
+  if (tt == 1) launch_predict103<1, true>(a, s);          // T <= 32: W resident (36.6 KB)
+  else if (tt == 2) launch_predict103<2, false>(a, s);
+  else if (tt <= 3) launch_predict103<3, false>(a, s);
+  else if (tt <= 5) launch_predict103<5, false>(a, s);
+  else if (tt <= 9) launch_predict103<9, false>(a, s);     // T <= 288 (EMIT's 285 bands)
+  else return false;
+  return true;
+}
+
 static int ensure_table(int n_in, int degree) {
   if (g_table_nin == n_in && g_table_deg == degree && g_table_dev) return g_table_nfeat;
   const int nf = build_table(n_in, degree);
@@ -336,6 +511,10 @@ extern "C" int hsr_polyfeat_predict(const float* x_dev, int64_t x_ps, int64_t x_
   a.act = activation;
   a.out = out_dev;
   a.out_stride = out_stride;
+  if (degree == 3 && try_predict103(a, (hipStream_t)stream)) {
+    HSR_LAUNCH_CHECK("predict103_kernel");
+    return HSR_OK;
+  }
   const size_t lds = ((size_t)kPredPix * (a.kpad + 1) + (size_t)kPredPix * (n_in + 1)) * sizeof(float);
   HSR_REQUIRE(lds <= 150 * 1024, HSR_ERR_UNSUPPORTED, "hsr_polyfeat_predict: %zu bytes of LDS needed", lds);
   int64_t tiles = (npix + kPredPix - 1) / kPredPix;

@@ -505,6 +505,8 @@ int main(int argc, char** argv) {
   add("LIB K1 PIXMAJOR out", [&] { if (hsr_srf_integrate(d_cube, npix, B, d_wn, raw.k0, raw.klen, nb, d_planes, 1, 12, 0)) { printf("%s\n", hsr_last_error()); exit(1);} }, false);
   add("LIB K1+K2 deg3 PIXMAJOR in/out", [&] { if (hsr_srf_integrate_moments(d_cube, npix, B, d_wn, raw.k0, raw.klen, nb, d_planes, 1, 12, d_real, 1, 12, nullptr, 0.f, 0.f, 3, d_part, &slots, 0)) { printf("%s\n", hsr_last_error()); exit(1);} }, false);
   add("LIB K1+K2 deg3 PIXMAJOR out, PLANAR real", [&] { if (hsr_srf_integrate_moments(d_cube, npix, B, d_wn, raw.k0, raw.klen, nb, d_planes, 1, 12, d_real, npix, 1, nullptr, 0.f, 0.f, 3, d_part, &slots, 0)) { printf("%s\n", hsr_last_error()); exit(1);} }, false);
+  add("LIB K1 tile32 PIXMAJOR out", [&] { hsr_set_srf_tile(32); if (hsr_srf_integrate(d_cube, npix, B, d_wn, raw.k0, raw.klen, nb, d_planes, 1, 12, 0)) { printf("%s\n", hsr_last_error()); exit(1);} hsr_set_srf_tile(64); }, false);
+  add("LIB K1+K2 deg3 tile32 PIXMAJOR", [&] { hsr_set_srf_tile(32); if (hsr_srf_integrate_moments(d_cube, npix, B, d_wn, raw.k0, raw.klen, nb, d_planes, 1, 12, d_real, 1, 12, nullptr, 0.f, 0.f, 3, d_part, &slots, 0)) { printf("%s\n", hsr_last_error()); exit(1);} hsr_set_srf_tile(64); }, false);
   add("LIB K1 tile32", [&] { hsr_set_srf_tile(32); if (hsr_srf_integrate(d_cube, npix, B, d_wn, raw.k0, raw.klen, nb, d_planes, stride, 1, 0)) { printf("%s\n", hsr_last_error()); exit(1);} hsr_set_srf_tile(64); }, true);
   add("LIB K1+K2 deg3 tile32", [&] { hsr_set_srf_tile(32); if (hsr_srf_integrate_moments(d_cube, npix, B, d_wn, raw.k0, raw.klen, nb, d_planes, stride, 1, d_real, npix, 1, nullptr, 0.f, 0.f, 3, d_part, &slots, 0)) { printf("%s\n", hsr_last_error()); exit(1);} hsr_set_srf_tile(64); }, true);
   add("LIB hsr_srf_integrate (K1)", [&] { if (hsr_srf_integrate(d_cube, npix, B, d_wn, raw.k0, raw.klen, nb, d_planes, stride, 1, 0)) { printf("%s\n", hsr_last_error()); exit(1);} }, true);

@@ -399,7 +399,6 @@ __global__ __launch_bounds__(256) void apply_pixmajor_kernel(const ApplyArgs a) 
   if (st)
     for (int i = threadIdx.x; i < a.nb * 2; i += 256) lh[i] = a.lohi[i];
   __syncthreads();
-  const int ps = (int)a.x_ps;
   const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t nthreads = (int64_t)gridDim.x * 256;
   if (VEC4) {

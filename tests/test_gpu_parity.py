@@ -641,3 +641,93 @@ def test_pipelined_submit_flush_matches_step(torch_gpu):
             assert torch.equal(c, rc) and torch.equal(m.view(torch.int32), rm.view(torch.int32))
     finally:
         nat.check(nat.load().hsr_set_srf_reserved_cus(0))
+
+
+# ---------------------------------------------------------------------------------------------
+# edge cases: degenerate fits, limits, error paths
+# ---------------------------------------------------------------------------------------------
+def test_fused_degenerate_fits(torch_gpu):
+    """All-masked / too-few / constant inputs: the reference's soft fallbacks, no NaNs, no crashes."""
+    torch = torch_gpu
+    from s2_emit import SpectralFusion
+    srf = onp.synthetic_srf()
+    w, good = onp.synthetic_wavelengths()
+    R = onp.synthetic_cube(16, 16, seed=2)
+    ps = onp.pseudo_s2_srf_integral(R, w, srf, good)
+    names = [k for k, v in ps.items() if v is not None]
+    pseudo = np.stack([ps[k] for k in names]).astype(np.float32)
+    real = onp.synthetic_real_planes(pseudo)
+    Rd, reald = torch.from_numpy(R).cuda(), torch.from_numpy(real).cuda()
+    ident = np.array([0.0, 0.0, 1.0, 0.0])
+    # (1) mask of zeros -> count 0 -> identity polynomial for every band (min_count = 50)
+    plan = SpectralFusion(w, srf, good, deg=3, min_count=50)
+    out = plan.step(Rd, reald, mask=torch.zeros(256, dtype=torch.uint8, device="cuda"), reuse_buffers=False)
+    assert np.array_equal(out.coeffs.cpu().numpy(), np.tile(ident, (12, 1))) and (out.moments.cpu().numpy() == 0).all()
+    np.testing.assert_array_equal(out.planes("matched").cpu().numpy(), np.clip(out.planes("pseudo").cpu().numpy(), 0, 1))
+    # (2) 49 valid pixels < 50 -> identity; 50 -> a fit
+    m = np.zeros(256, np.uint8)
+    m[:49] = 1
+    out = plan.step(Rd, reald, mask=torch.from_numpy(m).cuda(), reuse_buffers=False)
+    assert np.array_equal(out.coeffs.cpu().numpy(), np.tile(ident, (12, 1))) and (out.moments.cpu().numpy()[:, 0] == 49).all()
+    m[49] = 1
+    out = plan.step(Rd, reald, mask=torch.from_numpy(m).cuda(), reuse_buffers=False)
+    assert not np.array_equal(out.coeffs.cpu().numpy()[0], ident) and np.isfinite(out.coeffs.cpu().numpy()).all()
+    # (3) constant cube -> rank-1 Vandermonde -> minimum-norm fit like np.polyfit, finite everywhere
+    Rc = torch.full((16, 16, 285), 0.25, dtype=torch.float32, device="cuda")
+    out = SpectralFusion(w, srf, good, deg=2, min_count=10).step(Rc, reald, reuse_buffers=False)
+    assert torch.isfinite(out.coeffs).all() and torch.isfinite(out.matched[:, :12]).all()
+    x0 = float(out.planes("pseudo")[0, 0])
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        ref = np.polyfit(np.full(256, np.float64(np.float32(x0))), real[0].reshape(-1).astype(np.float64), 2)
+    np.testing.assert_allclose(np.polyval(out.coeffs[0].cpu().numpy(), x0), np.polyval(ref, x0), rtol=1e-6)
+    # (4) a single band and deg 4
+    one = {"B4": srf["B4"]}
+    r1 = torch.from_numpy(real[names.index("B4")][None]).cuda()
+    out = SpectralFusion(w, one, good, deg=4, min_count=50).step(Rd, r1, reuse_buffers=False)
+    xs = pseudo[names.index("B4")].reshape(-1).astype(np.float64)
+    ref = np.polyfit(xs, real[names.index("B4")].reshape(-1).astype(np.float64), 4)
+    np.testing.assert_allclose(np.polyval(out.coeffs[0].cpu().numpy(), xs), np.polyval(ref, xs), rtol=0, atol=2e-5)
+
+
+def test_limits_and_error_paths(torch_gpu):
+    torch = torch_gpu
+    import s2_emit
+    from s2_emit import _engine as eng
+    from s2_emit import _native as nat
+    lam = np.arange(300.0, 2600.0)
+    srf = {"A": (lam, np.exp(-0.5 * ((lam - 900) / 60) ** 2)), "Z": (lam, np.exp(-0.5 * ((lam - 2300) / 200) ** 2))}
+    # the largest supported spectrum (B = 560, even -> padded LDS rows, generic loader, 1 workgroup per CU)
+    B = nat.HSR_MAX_SPECTRAL
+    w = np.linspace(400, 2500, B).astype(np.float32)
+    R = (np.random.default_rng(1).random((9, 13, B)) * 0.5).astype(np.float32)
+    ref = onp.pseudo_s2_srf_integral(R, w, srf, None)
+    got = s2_emit.pseudo_s2_srf_integral(R, w, srf, None)
+    for k in srf:
+        assert _rel_err(got[k], ref[k]) < 3e-6
+    # wide supports: more taps than the LDS weight area holds -> weights read from global memory
+    wide = {f"W{i}": (lam, np.ones_like(lam)) for i in range(8)}
+    w285, _ = onp.synthetic_wavelengths()
+    R2 = onp.synthetic_cube(8, 8, seed=6)
+    ref = onp.pseudo_s2_srf_integral(R2, w285, wide, None)
+    got = s2_emit.pseudo_s2_srf_integral(R2, w285, wide, None)
+    for k in wide:
+        assert _rel_err(got[k], ref[k]) < 3e-6
+    # B beyond the limit is refused with a message, not silently mis-computed
+    big = torch.zeros((4, B + 1), dtype=torch.float32, device="cuda")
+    table = eng.build_srf_table(np.linspace(400, 2500, B + 1), srf, None)
+    with pytest.raises(nat.HsrError) as ei:
+        eng.srf_integrate(big, table)
+    assert "outside [1,560]" in str(ei.value)
+    with pytest.raises(ValueError):
+        eng.srf_integrate(torch.zeros((4, 285), dtype=torch.float64, device="cuda"), table)
+    with pytest.raises(ValueError):
+        s2_emit.SpectralFusion(w285, onp.synthetic_srf(), None, deg=5)
+    with pytest.raises(ValueError) as ei:
+        s2_emit.match_pair(R2, w285, {"B4": srf["A"]}, None, np.zeros((48, 48, 3), np.uint8))
+    assert "Band B3 is None/missing in pseudo_s2." in str(ei.value)
+    # apply_poly_rgb keeps channels beyond len(coeffs) untouched except for the clip, like the reference
+    rgb = (np.random.default_rng(2).random((5, 7, 4)) * 1.4 - 0.2).astype(np.float32)
+    co = np.array([[0.5, 0.2], [1.0, 0.0], [2.0, -0.1]])
+    np.testing.assert_array_equal(s2_emit.apply_poly_rgb(rgb, co), np.concatenate(
+        [onp.apply_poly_rgb(rgb[..., :3].copy(), co), np.clip(rgb[..., 3:], 0, 1)], axis=-1))

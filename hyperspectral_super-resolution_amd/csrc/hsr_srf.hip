@@ -18,8 +18,8 @@
 //      Flagged pixels take the dense product so that 0*Inf -> NaN poisons exactly the bands the
 //      reference poisons (synth.py:41 multiplies all B samples of every band).
 //   4. output.  Pixel-major (band-last) output is staged in LDS as the tile's contiguous
-//      [pixel][band] slab and flushed with 16-byte stores AFTER the next tile's DMA has been issued:
-//      one contiguous ~3 KB write per tile.  (Band-major planes are stored directly: nb scattered
+//      [pixel][band] slab and flushed with 16-byte stores in the next iteration, after that tile's
+//      DMA has been issued: one contiguous ~3 KB write per tile.  (Band-major planes are stored directly: nb scattered
 //      256-B segments per tile; measured 10 % slower on the whole kernel because of the write
 //      pattern, although the planes are only 4 % of the bytes.)  With DEG > 0 the same lane
 //      also accumulates the Vandermonde power sums of (x = plane value, y = real S2 value) in
@@ -97,6 +97,19 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 // the plane stores just issued are not waited for) + s_barrier.
 __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+// Loads the compiler's waitcnt pass does not see (see load_targets in the kernel): the caller must wait
+// (s_waitcnt vmcnt(0)) before the first use and pin the registers behind that wait.
+__device__ __forceinline__ float load_f32_async(const float* p) {
+  float v;
+  asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+  return v;
+}
+__device__ __forceinline__ uint32_t load_u8_async(const uint8_t* p) {
+  uint32_t v;
+  asm volatile("global_load_ubyte %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+  return v;
 }
 
 // x*0 is NaN exactly when x is NaN or +-Inf; four of them chained cost 4 VALU ops.
@@ -179,26 +192,42 @@ __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
     const float* src = a.cube + pix0 * B;
     const bool pvalid = pl < npx;
 
-    // operands of the fused fit: issue these loads before waiting for the tile
+    // operands of the fused fit (2 target values + 1 mask byte per thread).  hipcc drains vmcnt to 0
+    // whenever ordinary VGPR loads and LDS-DMA mix (before the DMA issue if the loads come first, before
+    // the loads if they come second), which exposed one extra HBM round trip per tile (+20 us on the
+    // kernel).  So these loads are issued from inline asm, invisible to the waitcnt pass, right after the
+    // DMA; they retire under the same wait as the tile (explicit vmcnt(0) after the barrier) and the
+    // registers are pinned there so that no use can be scheduled ahead of it.
     float yv[kBandSlots];
-    bool mv = true;
-    if (DEG > 0) {
+    uint32_t mraw = 1u;
+    auto load_targets = [&]() {
+      if (DEG > 0) {
+        const int64_t pc = pvalid ? pix0 + pl : a.npix - 1;   // clamped: always a valid address, no branch
 #pragma unroll
-      for (int j = 0; j < kBandSlots; ++j)
-      {
-        // band-major target: each element is read once, coalesced -> streaming load.  Pixel-major
-        // target: the 8 waves of the workgroup share the tile's ~3 KB slab at a 4-byte granularity
-        // -> it must stay cacheable (an `nt` load here re-fetches every line from HBM: +25 us).
-        const float* yp = a.real + (grp + kGroups * j) * a.real_bs + (pix0 + pl) * a.real_ps;
-        yv[j] = (bval[j] && pvalid) ? (a.real_ps == 1 ? ld_stream(yp) : *yp) : 0.0f;
+        for (int j = 0; j < kBandSlots; ++j) {
+          const int bb = bval[j] ? grp + kGroups * j : 0;
+          yv[j] = load_f32_async(a.real + bb * a.real_bs + pc * a.real_ps);
+        }
+        if (a.mask != nullptr) mraw = load_u8_async(a.mask + pc);
       }
-      if (a.mask != nullptr) mv = pvalid && a.mask[pix0 + pl] != 0;
-    }
+    };
+    auto wait_targets = [&]() {
+      if (DEG > 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        static_assert(kBandSlots == 2, "pin list below");
+        asm volatile("" : "+v"(yv[0]), "+v"(yv[1]), "+v"(mraw));
+      }
+    };
 
     HSR_STAMP(st0);
     if (t < P) flags[t] = 0u;
 
     const bool fast_tile = FAST && npx == P;
+    // Order matters (measured, and checked in the .s): the DMA is issued FIRST - anything ahead of it is
+    // dead time (flushing the previous slab first cost +12 us on the kernel); then the small target loads
+    // (inline asm, see above); then the flush of the previous slab, whose ds_reads see the pending LDS-DMA
+    // and make hipcc wait vmcnt(0) - i.e. it runs once the tile (and the targets) have landed, just ahead
+    // of the barrier that waits for the same thing.
     if (fast_tile) {
       const char* srcb = reinterpret_cast<const char*>(src);
       for (int c0 = wave * 64; c0 < nchunk; c0 += T) {  // c0 is wave-uniform
@@ -207,9 +236,11 @@ __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
           __builtin_amdgcn_global_load_lds((gptr_t)(srcb + (size_t)c * 16), (lptr_t)(smem + (size_t)c0 * 16),
                                            16, 0, kGldsStream);
       }
+      load_targets();
       if (OUTV) flush_stage<8 * P>(ostage, a.out, prev_pix0, prev_npx, ops, t);
       HSR_STAMP(st1);
       __syncthreads();
+      wait_targets();
       HSR_STAMP(st2);
       // non-finite sweep: kScanBatch independent ds_read_b128 in flight per thread (a serial
       // read->wait->test loop cost 3.7k cycles per tile; batched it is LDS-bandwidth bound).
@@ -243,8 +274,10 @@ __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
 #endif
     } else {
       // generic loader: any 4-byte alignment, any B, ragged last tile.  One pixel row per wave step.
+      load_targets();
       if (OUTV) flush_stage<8 * P>(ostage, a.out, prev_pix0, prev_npx, ops, t);
       __syncthreads();  // flags zeroed before anybody sets one
+      wait_targets();
       for (int pp = wave; pp < npx; pp += NW) {
         bool bad = false;
         for (int k = lane; k < B; k += 64) {
@@ -312,7 +345,7 @@ __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
         else if (pvalid) st_stream(a.out + (grp + kGroups * j) * a.out_bs + (pix0 + pl) * a.out_ps, acc);
         if (DEG > 0) {
           const float y = yv[j];
-          const bool ok = pvalid && mv && finite_f32(acc) && finite_f32(y) && acc > a.min_x && y > a.min_y;
+          const bool ok = pvalid && mraw != 0u && finite_f32(acc) && finite_f32(y) && acc > a.min_x && y > a.min_y;
           if (ok) {
             const double xd = (double)acc, yd = (double)y;
             acc_m[j][0] += 1.0;

@@ -54,11 +54,12 @@ def load_emit_wavelengths_from_nc(
 ) -> Tuple[np.ndarray, Optional[np.ndarray]]:
     """
     Returns (emit_wavelengths_nm, good_mask_bool_or_None)
+
+    EMIT L2A netCDF files are HDF5 containers: the band centres (float32, nm) and the per-band
+    ``good_wavelengths`` flag live in the ``sensor_band_parameters`` group (reference emit_io.py:18-31).
     """
-    import h5py
-    with h5py.File(nc_path, "r") as f:
-        emit_w = f[wavelengths_key][:].astype(np.float32)
-        good_mask = None
-        if good_key in f:
-            good_mask = f[good_key][:].astype(bool)
-    return emit_w, good_mask
+    import h5py                                    # lazy: only this loader needs it
+    with h5py.File(nc_path, "r") as nc:
+        wavelengths = np.asarray(nc[wavelengths_key][:], dtype=np.float32)
+        flags = nc[good_key][:] if good_key in nc else None
+    return wavelengths, (None if flags is None else np.asarray(flags).astype(bool))

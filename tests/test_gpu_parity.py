@@ -731,3 +731,44 @@ def test_limits_and_error_paths(torch_gpu):
     co = np.array([[0.5, 0.2], [1.0, 0.0], [2.0, -0.1]])
     np.testing.assert_array_equal(s2_emit.apply_poly_rgb(rgb, co), np.concatenate(
         [onp.apply_poly_rgb(rgb[..., :3].copy(), co), np.clip(rgb[..., 3:], 0, 1)], axis=-1))
+
+
+@pytest.mark.parametrize("B", [1, 2, 3, 7, 15, 16, 17, 33, 64, 129, 286, 559])
+def test_k1_spectral_size_sweep(torch_gpu, B):
+    """Every loader / weight-staging branch: tiny B (weights from global memory: the 16-tap chunks do not fit
+    the row), even B (padded LDS rows, generic loader), odd B (LDS-DMA path), both tile geometries, both layouts."""
+    torch = torch_gpu
+    from s2_emit import _engine as eng
+    from s2_emit import _native as nat
+    rng = np.random.default_rng(B)
+    w = np.linspace(400.0, 2400.0, B).astype(np.float32) if B > 1 else np.array([900.0], np.float32)
+    lam = np.arange(300.0, 2600.0)
+    srf = {f"S{i}": (lam, np.exp(-0.5 * ((lam - c) / s) ** 2) + 1e-12)
+           for i, (c, s) in enumerate(((450, 40), (900, 150), (1600, 90), (2200, 300), (1250, 700)))}
+    H, W = 5, 29                      # 145 pixels: two full 64-pixel tiles + a ragged one
+    R = (rng.random((H, W, B)) * 0.7 - 0.05).astype(np.float32)
+    if B > 2:
+        R[2, 3, B // 2] = np.nan
+        R[4, 28, B - 1] = -np.inf
+    ref = onp.pseudo_s2_srf_integral(R, w, srf, None)
+    table = eng.build_srf_table(w, srf, None)
+    names = [k for k, v in ref.items() if v is not None]
+    assert table.supported == names
+    if not names:
+        return
+    cube = torch.from_numpy(R).cuda()
+    base = None
+    for tile in (64, 32):
+        nat.check(nat.load().hsr_set_srf_tile(tile))
+        try:
+            pl = eng.srf_integrate(cube, table, layout=nat.PLANAR)
+            pm = eng.srf_integrate(cube, table, layout=nat.PIXMAJOR)
+        finally:
+            nat.check(nat.load().hsr_set_srf_tile(64))
+        got = pl.cpu().numpy().reshape(len(names), H, W)
+        for i, k in enumerate(names):
+            assert _rel_err(got[i], ref[k]) < 3e-6, (B, tile, k)
+        assert torch.equal(pm[:, :len(names)].t().contiguous().view(torch.int32), pl.view(torch.int32))
+        if base is None:
+            base = pl.clone()
+        assert torch.equal(base.view(torch.int32), pl.view(torch.int32))      # tile geometry does not change bits

@@ -393,25 +393,27 @@ __global__ __launch_bounds__(256) void apply_pixmajor_kernel(const ApplyArgs a) 
   __shared__ double lh[HSR_MAX_BANDS * 2];
   const int n = a.deg + 1;
   const bool has_poly = a.coeffs != nullptr;
+  const bool st = a.lohi != nullptr;
+  const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int64_t nthreads = (int64_t)gridDim.x * 256;
+  constexpr uint32_t q = VEC4 ? Q : 1;  // float4 per pixel row (compile-time: division by constant)
+  constexpr int U = 4;                  // independent 16-byte loads in flight per thread
+  const uint32_t nv = VEC4 ? (uint32_t)(a.npix * q) : 0u;   // host guarantees npix * q < 2^31
+  float4 v[U];
+  if (VEC4) {   // first batch of loads goes out BEFORE the coefficient staging and its barrier
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t i = (uint32_t)tid + u * (uint32_t)nthreads;
+      if (i < nv) v[u] = ld_stream(reinterpret_cast<const float4*>(a.x) + i);
+    }
+  }
   if (has_poly)
     for (int i = threadIdx.x; i < a.nb * n; i += 256) cs[i] = a.coeffs[i];
-  const bool st = a.lohi != nullptr;
   if (st)
     for (int i = threadIdx.x; i < a.nb * 2; i += 256) lh[i] = a.lohi[i];
   __syncthreads();
-  const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  const int64_t nthreads = (int64_t)gridDim.x * 256;
   if (VEC4) {
-    constexpr uint32_t q = VEC4 ? Q : 1;  // float4 per pixel row (compile-time: division by constant)
-    const uint32_t nv = (uint32_t)(a.npix * q);   // host guarantees npix * q < 2^31
-    constexpr int U = 4;    // independent 16-byte loads in flight per thread
     for (uint32_t i0 = (uint32_t)tid; i0 < nv; i0 += (uint32_t)nthreads * U) {
-      float4 v[U];
-#pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const uint32_t i = i0 + u * (uint32_t)nthreads;
-        if (i < nv) v[u] = ld_stream(reinterpret_cast<const float4*>(a.x) + i);
-      }
 #pragma unroll
       for (int u = 0; u < U; ++u) {
         const uint32_t i = i0 + u * (uint32_t)nthreads;
@@ -431,6 +433,15 @@ __global__ __launch_bounds__(256) void apply_pixmajor_kernel(const ApplyArgs a) 
           }
         }
         st_stream(reinterpret_cast<float4*>(a.out) + i, make_float4(r[0], r[1], r[2], r[3]));
+      }
+      // next batch (grid-stride; a single pass when the grid covers the image)
+      const uint32_t inext = i0 + (uint32_t)nthreads * U;
+      if (inext < nv) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const uint32_t i = inext + u * (uint32_t)nthreads;
+          if (i < nv) v[u] = ld_stream(reinterpret_cast<const float4*>(a.x) + i);
+        }
       }
     }
   } else {

@@ -88,31 +88,59 @@ __global__ __launch_bounds__(64) void gram_f64_kernel(const double* __restrict__
                                                       const double* __restrict__ B, int64_t ldb, int tiles_j,
                                                       int64_t n, int64_t rows_per_chunk,
                                                       double* __restrict__ partials) {
-  const int tile = blockIdx.x;
-  const int ti = tile / tiles_j, tj = tile % tiles_j;
+  // One wave = a 32 x 32 output block (2 x 2 MFMA tiles): two A and two B operands per k-step feed four
+  // MFMAs, half the operand loads per MFMA of the one-tile-per-wave version.
+  const int bj = (tiles_j + 1) / 2;
+  const int blk = blockIdx.x;
+  const int ti0 = (blk / bj) * 2, tj0 = (blk % bj) * 2;
+  const bool i1 = ti0 + 1 < tiles_i, j1 = tj0 + 1 < tiles_j;
   const int lane = threadIdx.x;
   const int col = lane & 15, kk = lane >> 4;
   const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
   int64_t r1 = r0 + rows_per_chunk;
   if (r1 > n) r1 = n;
-  f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-  const double* ap = A + ti * 16 + col;
-  const double* bp = B + tj * 16 + col;
-  int64_t r = r0;
-  for (; r + 4 <= r1; r += 4) {
-    const double a = ap[(r + kk) * lda];
-    const double b = bp[(r + kk) * ldb];
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-  }
-  if (r < r1) {   // ragged tail: rows beyond r1 contribute zeros
-    const bool ok = r + kk < r1;
-    const double a = ok ? ap[(r + kk) * lda] : 0.0;
-    const double b = ok ? bp[(r + kk) * ldb] : 0.0;
-    acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
-  }
-  double* out = partials + ((size_t)blockIdx.y * gridDim.x + tile) * 256;
+  f64x4 acc[2][2];
 #pragma unroll
-  for (int g = 0; g < 4; ++g) out[(kk + 4 * g) * 16 + col] = acc[g];
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y) acc[x][y] = f64x4{0.0, 0.0, 0.0, 0.0};
+  const double* ap = A + ti0 * 16 + col;
+  const double* bp = B + tj0 * 16 + col;
+  const int ao = i1 ? 16 : 0, bo = j1 ? 16 : 0;   // second tile aliases the first when it does not exist
+  constexpr int KU = 8;   // k-steps whose operand loads are in flight together (32 independent loads)
+  for (int64_t r = r0; r < r1; r += 4 * KU) {
+    double a0[KU], a1[KU], b0[KU], b1[KU];
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+      const int64_t rr = r + 4 * u + kk;
+      const bool ok = rr < r1;                    // ragged tail: rows beyond r1 contribute zeros
+      const int64_t rc = ok ? rr : r0;            // clamped address, value masked below
+      const double va0 = ap[rc * lda], va1 = ap[rc * lda + ao], vb0 = bp[rc * ldb], vb1 = bp[rc * ldb + bo];
+      a0[u] = ok ? va0 : 0.0;
+      a1[u] = ok ? va1 : 0.0;
+      b0[u] = ok ? vb0 : 0.0;
+      b1[u] = ok ? vb1 : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b0[u], acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b1[u], acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b0[u], acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b1[u], acc[1][1], 0, 0, 0);
+    }
+  }
+  const int ntiles = tiles_i * tiles_j;
+#pragma unroll
+  for (int x = 0; x < 2; ++x) {
+#pragma unroll
+    for (int y = 0; y < 2; ++y) {
+      if ((x == 1 && !i1) || (y == 1 && !j1)) continue;
+      const int tile = (ti0 + x) * tiles_j + (tj0 + y);
+      double* out = partials + ((size_t)blockIdx.y * ntiles + tile) * 256;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) out[(kk + 4 * g) * 16 + col] = acc[x][y][g];
+    }
+  }
 }
 
 // chunks summed in index order -> C[(ti*16 + r) * ldc + tj*16 + c]
@@ -476,8 +504,8 @@ extern "C" int hsr_gram_f64(const double* a_dev, int64_t lda, int32_t na, const 
   chunks = (n + rows - 1) / rows;
   const int ti = na / 16, tj = nb / 16;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(gram_f64_kernel, dim3(ti * tj, (unsigned)chunks), dim3(64), 0, s, a_dev, lda, ti, b_dev, ldb, tj, n,
-                     rows, work_dev);
+  hipLaunchKernelGGL(gram_f64_kernel, dim3(((ti + 1) / 2) * ((tj + 1) / 2), (unsigned)chunks), dim3(64), 0, s, a_dev, lda,
+                     ti, b_dev, ldb, tj, n, rows, work_dev);
   hipLaunchKernelGGL(gram_reduce_kernel, dim3(ti * tj), dim3(256), 0, s, work_dev, ti * tj, (int)chunks, tj, c_dev, ldc);
   HSR_LAUNCH_CHECK("gram_f64_kernel");
   return HSR_OK;

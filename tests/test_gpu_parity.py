@@ -772,3 +772,26 @@ def test_k1_spectral_size_sweep(torch_gpu, B):
         if base is None:
             base = pl.clone()
         assert torch.equal(base.view(torch.int32), pl.view(torch.int32))      # tile geometry does not change bits
+
+
+def test_envi_loader_device_path(torch_gpu, tmp_path):
+    """BSQ / BIL / BIP files -> pixel-major (H, W, B) float32 GPU tensor == the host loader, then K1 on it."""
+    torch = torch_gpu
+    import s2_emit
+    rng = np.random.default_rng(0)
+    cube = (rng.random((11, 13, 285)) * 0.5).astype(np.float32)
+    for inter, arr in (("bip", cube), ("bil", cube.transpose(0, 2, 1)), ("bsq", cube.transpose(2, 0, 1))):
+        np.ascontiguousarray(arr).tofile(tmp_path / f"c_{inter}.bin")
+        (tmp_path / f"c_{inter}.hdr").write_text(
+            f"ENVI\nsamples = 13\nlines = 11\nbands = 285\nheader offset = 0\ndata type = 4\n"
+            f"interleave = {inter}\nbyte order = 0\n")
+        Rh = s2_emit.load_emit_envi_rfl(str(tmp_path / f"c_{inter}.hdr"), str(tmp_path / f"c_{inter}.bin"))
+        Rd = s2_emit.load_emit_envi_rfl(str(tmp_path / f"c_{inter}.hdr"), str(tmp_path / f"c_{inter}.bin"), device="cuda")
+        assert Rd.is_cuda and Rd.dtype == torch.float32 and Rd.is_contiguous() and tuple(Rd.shape) == (11, 13, 285)
+        np.testing.assert_array_equal(Rd.cpu().numpy(), Rh)
+        np.testing.assert_array_equal(Rh, cube)
+    w, good = onp.synthetic_wavelengths()
+    srf = onp.synthetic_srf()
+    out = s2_emit.pseudo_s2_srf_integral(Rd, w, srf, good)
+    ref = onp.pseudo_s2_srf_integral(cube, w, srf, good)
+    assert _rel_err(out["B4"].cpu().numpy(), ref["B4"]) < 2e-6

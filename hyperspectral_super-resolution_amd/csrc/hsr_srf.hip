@@ -83,6 +83,8 @@ constexpr int kScanBatch = 5;                       // ds_read_b128 in flight pe
 // Tile geometry: P pixels per LDS tile, 8*P threads per workgroup.
 //   P = 64: 512 threads (8 waves), lane = pixel, wave = band group;      2 workgroups per CU
 //   P = 32: 256 threads (4 waves), lane&31 = pixel, each wave half = one band group; 4 per CU
+// (Measured and dropped: P = 8, one-wave workgroups with wave-local barriers, ~14 per CU: 0.2535 ms; P = 128,
+//  one 1024-thread workgroup per CU: 0.234 ms; P = 64: 0.2133 ms on the same box.)
 // Both keep 16 waves (4 per SIMD, <= 128 VGPRs) and ~146 KB of LDS tiles per CU; the smaller tile
 // gives the CU's memory pipe four queued customers instead of two (see DESIGN.md, K1 tuning).
 static int g_tile_pixels = 64;

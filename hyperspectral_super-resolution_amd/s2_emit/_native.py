@@ -19,7 +19,7 @@ HSR_MAX_DEG = 4
 HSR_MAX_APPLY_DEG = 8
 HSR_MAX_SPECTRAL = 560
 HSR_TILE_PIXELS = 64
-HSR_MAX_PARTIALS = 2048
+HSR_MAX_PARTIALS = 4096
 PLANAR = "planar"        # band-major planes: tensor (nb, npix), unit pixel stride
 PIXMAJOR = "pixmajor"    # pixel-major / band-last: tensor (npix, row) with row >= nb, unit band stride
 

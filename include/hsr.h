@@ -38,7 +38,7 @@ extern "C" {
 #define HSR_MAX_APPLY_DEG 8    /* polynomial degree K3 can evaluate                  */
 #define HSR_MAX_SPECTRAL 560   /* input bands B per pixel (EMIT: 285)              */
 #define HSR_TILE_PIXELS 64     /* pixels staged per LDS tile                       */
-#define HSR_MAX_PARTIALS 2048  /* upper bound of per-launch partial-sum slots      */
+#define HSR_MAX_PARTIALS 4096  /* upper bound of per-launch partial-sum slots      */
 
 /* Image-like tensors (pseudo-S2, real S2, matched output) are addressed with two strides, in elements:
  *   element (band b, pixel p) lives at base[b * band_stride + p * pixel_stride]

@@ -41,7 +41,7 @@ def test_sizing_helpers_and_error_strings():
     assert lib.hsr_moment_count(0) == -1 and lib.hsr_moment_count(5) == -1
     assert lib.hsr_partial_slots(1) == 1 and lib.hsr_partial_slots(64) == 1 and lib.hsr_partial_slots(65) == 2
     assert lib.hsr_partial_slots(1 << 20) == 512 and lib.hsr_partial_slots(1 << 30) == 512
-    assert lib.hsr_partials_bytes(12, 3) == 12 * 11 * 2048 * 8
+    assert lib.hsr_partials_bytes(12, 3) == 12 * 11 * 4096 * 8
     assert lib.hsr_percentile_work_bytes(3) > 3 * (2048 + 4 * 2048 + 4 * 1024) * 4
     # argument validation happens before any device work -> testable without a GPU
     k = (ctypes.c_int32 * 1)(0)

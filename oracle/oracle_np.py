@@ -220,6 +220,24 @@ def ot_barycentric_targets(X, Y, reg=0.05, numItermax=300, stopThr=1e-6):
     return (P @ Y) / (P.sum(axis=1, keepdims=True) + 1e-32)
 
 
+def ot_match_rgb_sinkhorn_pot(src_rgb, ref_rgb, mask, n_samples=5_000, reg=0.05, numItermax=300, stopThr=1e-6, seed=0):
+    """color.py:65-116: OT barycentric targets + affine least squares, applied inside the mask
+    (Sinkhorn sub-step parity unpinned, see module docstring)."""
+    s = _ot_samples(src_rgb, ref_rgb, mask, n_samples, seed, 2)
+    if s is None:                                                              # color.py:88-89
+        return src_rgb.copy()
+    X, Y = s
+    Ybar = ot_barycentric_targets(X, Y, reg, numItermax, stopThr)
+    X_aug = np.concatenate([X, np.ones((X.shape[0], 1))], axis=1)              # color.py:106-109
+    Wm, *_ = np.linalg.lstsq(X_aug, Ybar, rcond=None)
+    A, t = Wm[:3, :], Wm[3, :]
+    out = src_rgb.copy().astype(np.float32)                                    # color.py:111-116
+    Xm = out[mask].reshape(-1, 3).astype(np.float64)
+    Xm2 = np.clip(Xm @ A + t, 0.0, 1.0)
+    out[mask] = Xm2.reshape(out[mask].shape).astype(np.float32)
+    return out
+
+
 # ---------------------------------------------------------------------------------------------
 # a5 / a6: polynomial fit and apply  (s2_emit/poly_regression.py:16-84)
 # ---------------------------------------------------------------------------------------------

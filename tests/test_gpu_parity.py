@@ -795,3 +795,29 @@ def test_envi_loader_device_path(torch_gpu, tmp_path):
     out = s2_emit.pseudo_s2_srf_integral(Rd, w, srf, good)
     ref = onp.pseudo_s2_srf_integral(cube, w, srf, good)
     assert _rel_err(out["B4"].cpu().numpy(), ref["B4"]) < 2e-6
+
+
+def test_ot_color_transfer_and_ot_fit_vs_oracle(torch_gpu):
+    """ot_match_rgb_sinkhorn_pot (color.py:65-116) and fit_ot_poly_rgb (poly_regression.py:16-62): device
+    Sinkhorn vs the oracle's restatement of POT's documented algorithm (parity with POT itself unpinned)."""
+    import s2_emit
+    rng = np.random.default_rng(77)
+    H, W = 48, 40
+    src = rng.random((H, W, 3)) ** 1.5
+    ref = np.clip(0.8 * src[..., ::-1] + 0.1 + 0.03 * rng.standard_normal((H, W, 3)), 0, 1)
+    mask = rng.random((H, W)) > 0.15
+    src[2, 3, 1] = np.nan
+    got = s2_emit.ot_match_rgb_sinkhorn_pot(src, ref, mask, n_samples=700, seed=3)
+    want = onp.ot_match_rgb_sinkhorn_pot(src, ref, mask, n_samples=700, seed=3)
+    assert got.dtype == np.float32 and got.shape == src.shape
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    np.testing.assert_allclose(got[~np.isnan(want)], want[~np.isnan(want)], rtol=0, atol=5e-5)
+    c_got = s2_emit.fit_ot_poly_rgb(src, ref, mask, deg=3, n_samples=700, seed=3)
+    c_want = onp.fit_ot_poly_rgb(src, ref, mask, deg=3, n_samples=700, seed=3)
+    xs = np.linspace(0, 1, 41)
+    for c in range(3):
+        np.testing.assert_allclose(np.polyval(c_got[c], xs), np.polyval(c_want[c], xs), rtol=0, atol=5e-5)
+    # too few rows -> source returned unchanged (color.py:88-89)
+    tiny = np.zeros((H, W), bool)
+    tiny[0, 0] = True
+    np.testing.assert_array_equal(s2_emit.ot_match_rgb_sinkhorn_pot(src, ref, tiny), src)

@@ -52,6 +52,8 @@ def parse_args():
                     help="rehearsal only: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--pipeline", default="auto", choices=["auto", "on", "off"],
                     help="one-tile-deep software pipeline (exchange of tile i under K1 of tile i+1); auto = on for N > 1")
+    ap.add_argument("--reserve-cus", type=int, default=4,
+                    help="CUs left free of persistent K1 workgroups in pipelined mode (side-stream tail of the previous tile)")
     ap.add_argument("--event-every", type=int, default=4,
                     help="bracket the K1+K2 kernel with HIP events on every n-th timed step (each pair of event "
                          "records costs ~12 us of launch gap, so not on every step)")
@@ -119,9 +121,9 @@ def main():
         torch.cuda.synchronize()
 
     pipelined = args.pipeline == "on" or (args.pipeline == "auto" and world > 1)
-    if pipelined:      # keep one CU free of persistent K1 workgroups for the side-stream fit kernels / RCCL
+    if pipelined:      # keep a few CUs free of persistent K1 workgroups for the side stream (fit kernels, RCCL, K3)
         from s2_emit import _native as nat
-        nat.check(nat.load().hsr_set_srf_reserved_cus(1))
+        nat.check(nat.load().hsr_set_srf_reserved_cus(args.reserve_cus))
 
     def run_step(k1_events=None):
         if pipelined:
@@ -178,7 +180,7 @@ def main():
                                        f"deg-{args.deg} per-band least squares over all valid pixels "
                                        f"(BASELINE.json configs[2]; one tile per GPU for N>1)",
                            "tiles_per_gpu": 1, "coeff_sync": args.coeff_sync if world > 1 else "none",
-                           "pipeline": "one tile deep" if pipelined else "off",
+                           "pipeline": f"one tile deep, {args.reserve_cus} CUs reserved" if pipelined else "off",
                            "backend": (args.backend if world > 1 else "none") + (" (rehearsal: all ranks on cuda:0)" if args.same_device else "")},
                 "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:

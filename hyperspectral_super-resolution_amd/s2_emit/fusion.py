@@ -165,11 +165,15 @@ class SpectralFusion:
 
 
     # ---- one-tile-deep software pipeline -----------------------------------------------------------
-    # submit(i) enqueues K1+K2 of tile i on the caller's stream, the fit of tile i (slot reduction ->
-    # RCCL exchange -> solve) on a side stream, and K3 of tile i-1 on the caller's stream.  The exchange
-    # of tile i therefore runs underneath K1 of tile i+1 ("overlap the collective of tile i
-    # with K1 of tile i+1").  Outputs live in two alternating buffer sets: the FusionOutput returned for
-    # tile i is valid until the second submit() after it.
+    # submit(i) enqueues K1+K2 of tile i on the caller's stream and the whole tail of tile i (slot
+    # reduction -> RCCL exchange -> solve -> K3) on a side stream, so the tail of tile i runs underneath K1
+    # of tile i+1 ("overlap the collective of tile i with K1 of tile i+1").  K1's persistent
+    # workgroups own every CU they run on, so a few CUs are left free for the side stream
+    # (hsr_set_srf_reserved_cus; 4 is enough for the fit kernels and RCCL).  Measured on one GPU: K3 does NOT
+    # ride along for free - overlapped, K1 slows by more than K3 costs alone (0.265 ms/tile with 4-12 reserved
+    # CUs, 0.29 with 16-32, 0.256 sequential) - so the pipeline pays only where an exchange latency is to be
+    # hidden (N > 1).  Two alternating buffer sets: the FusionOutput returned
+    # for tile i is valid until the second submit() after it; the caller's stream is made to wait for it.
     def _pipe_state(self, npix: int):
         torch = nat.require_gpu()
         if self._pipe is None or self._pipe["npix"] != npix:
@@ -179,20 +183,18 @@ class SpectralFusion:
                 slots.append(dict(pseudo=eng.alloc_image(torch, nb, npix, self.layout, self.device),
                                   matched=eng.alloc_image(torch, nb, npix, self.layout, self.device),
                                   ws=eng.MomentWorkspace(self.device, nb, self.deg),
-                                  ev_k1=torch.cuda.Event(), ev_fit=torch.cuda.Event(), mask=None))
+                                  ev_k1=torch.cuda.Event(), ev_done=torch.cuda.Event(), used=False))
             self._pipe = dict(npix=npix, slots=slots, n=0, pending=None, side=torch.cuda.Stream(device=self.device))
         return self._pipe
 
-    def _pipe_apply(self, slot) -> FusionOutput:
+    def _pipe_output(self, slot) -> FusionOutput:
         torch = nat.require_gpu()
-        torch.cuda.current_stream().wait_event(slot["ev_fit"])
+        torch.cuda.current_stream().wait_event(slot["ev_done"])     # consumers on the caller's stream are ordered
         ws = slot["ws"]
-        matched = eng.poly_apply(slot["pseudo"], ws.coeffs, slot["mask"] if self.apply_mask else None, None, self.clip,
-                                 self.layout, out=slot["matched"], nb=self.table.nb)
-        return FusionOutput(self.names, slot["pseudo"], ws.moments, ws.coeffs, matched, self.layout)
+        return FusionOutput(self.names, slot["pseudo"], ws.moments, ws.coeffs, slot["matched"], self.layout)
 
     def submit(self, cube, real, mask=None, k1_events=None) -> Optional[FusionOutput]:
-        """Pipelined step: start tile i, finish tile i-1.  Returns tile i-1's output (None on the first call)."""
+        """Pipelined step: start tile i, return tile i-1 (None on the first call)."""
         torch = nat.require_gpu()
         npix = cube.numel() // cube.shape[-1]
         real, real_layout = self._real_image(real, npix)
@@ -200,10 +202,11 @@ class SpectralFusion:
         slot = st["slots"][st["n"] % 2]
         ws = slot["ws"]
         main = torch.cuda.current_stream()
+        if slot["used"]:
+            main.wait_event(slot["ev_done"])        # the tail that last read this buffer set (tile i-2)
         eng.srf_integrate_moments(cube, self.table, real, self.deg, ws, mask, self.min_valid, self.min_valid,
                                   out=slot["pseudo"], events=k1_events, reduce=False, layout=self.layout,
                                   real_layout=real_layout)
-        slot["mask"] = mask
         slot["ev_k1"].record(main)
         with torch.cuda.stream(st["side"]):
             st["side"].wait_event(slot["ev_k1"])
@@ -213,19 +216,22 @@ class SpectralFusion:
                                  self.group, self.coeff_sync)
             else:
                 eng.moments_reduce_solve(ws, self.min_count)
-            slot["ev_fit"].record(st["side"])
+            eng.poly_apply(slot["pseudo"], ws.coeffs, mask if self.apply_mask else None, None, self.clip,
+                           self.layout, out=slot["matched"], nb=self.table.nb)
+            slot["ev_done"].record(st["side"])
+        slot["used"] = True
         prev = st["pending"]
-        out = self._pipe_apply(prev) if prev is not None else None
+        out = self._pipe_output(prev) if prev is not None else None
         st["pending"] = slot
         st["n"] += 1
         return out
 
     def flush(self) -> Optional[FusionOutput]:
-        """Finish the tile left in the pipeline by the last submit()."""
+        """Wait (on the caller's stream) for the tile left in the pipeline by the last submit() and return it."""
         st = self._pipe
         if st is None or st["pending"] is None:
             return None
-        out = self._pipe_apply(st["pending"])
+        out = self._pipe_output(st["pending"])
         st["pending"] = None
         return out
 

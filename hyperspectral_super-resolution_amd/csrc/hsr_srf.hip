@@ -34,6 +34,7 @@ struct SrfBands {
   int32_t k0[HSR_MAX_BANDS];
   int32_t klen[HSR_MAX_BANDS];
   int32_t woff[HSR_MAX_BANDS];  // offset (floats, multiple of 4) of the band's taps in the LDS weight area
+  int8_t band_of[8][2];         // band handled by (group, slot), -1 = none: balanced over the 8 groups (srf_common)
 };
 
 constexpr int kWeightCap = 1024;  // floats of LDS reserved for compact weight taps (4 KiB)
@@ -155,13 +156,14 @@ __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
   const int nchunk = P * B / 4;  // 16-byte chunks of a full tile (P is a multiple of 4)
 
   // the (at most two) bands of this thread, fixed for the whole launch
-  int bk0[kBandSlots], bkl[kBandSlots], bwo[kBandSlots];
+  int bk0[kBandSlots], bkl[kBandSlots], bwo[kBandSlots], bidx[kBandSlots];
   bool bval[kBandSlots];
 #pragma unroll
   for (int j = 0; j < kBandSlots; ++j) {
-    const int b = grp + kGroups * j;
-    bval[j] = b < a.nb;
-    const int bb = bval[j] ? b : 0;
+    const int b = a.bands.band_of[grp][j];   // balanced assignment, not grp + 8*j
+    bval[j] = b >= 0;
+    bidx[j] = bval[j] ? b : 0;
+    const int bb = bidx[j];
     bk0[j] = a.bands.k0[bb];
     bkl[j] = bval[j] ? a.bands.klen[bb] : 0;
     bwo[j] = a.bands.woff[bb];
@@ -207,7 +209,7 @@ __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
         const int64_t pc = pvalid ? pix0 + pl : a.npix - 1;   // clamped: always a valid address, no branch
 #pragma unroll
         for (int j = 0; j < kBandSlots; ++j) {
-          const int bb = bval[j] ? grp + kGroups * j : 0;
+          const int bb = bidx[j];
           yv[j] = load_f32_async(a.real + bb * a.real_bs + pc * a.real_ps);
         }
         if (a.mask != nullptr) mraw = load_u8_async(a.mask + pc);
@@ -323,7 +325,7 @@ __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
           }
         }
       } else {
-        const float* ws = a.wn + (size_t)(grp + kGroups * j) * B + bk0[j];
+        const float* ws = a.wn + (size_t)bidx[j] * B + bk0[j];
         for (int i = 0; i < bkl[j]; ++i) acc = fmaf(ws[i], vs[i], acc);
       }
       accv[j] = acc;
@@ -332,7 +334,7 @@ __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
 #pragma unroll
       for (int j = 0; j < kBandSlots; ++j) {
         if (bval[j]) {
-          const float* w = a.wn + (size_t)(grp + kGroups * j) * B;
+          const float* w = a.wn + (size_t)bidx[j] * B;
           float acc = 0.0f;
           for (int k = 0; k < B; ++k) acc = fmaf(w[k], v[k], acc);
           accv[j] = acc;
@@ -343,8 +345,8 @@ __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
     for (int j = 0; j < kBandSlots; ++j) {
       if (bval[j]) {
         const float acc = accv[j];
-        if (OUTV) ostage[pl * ops + grp + kGroups * j] = acc;
-        else if (pvalid) st_stream(a.out + (grp + kGroups * j) * a.out_bs + (pix0 + pl) * a.out_ps, acc);
+        if (OUTV) ostage[pl * ops + bidx[j]] = acc;
+        else if (pvalid) st_stream(a.out + bidx[j] * a.out_bs + (pix0 + pl) * a.out_ps, acc);
         if (DEG > 0) {
           const float y = yv[j];
           const bool ok = pvalid && mraw != 0u && finite_f32(acc) && finite_f32(y) && acc > a.min_x && y > a.min_y;
@@ -392,7 +394,7 @@ __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
 #pragma unroll
         for (int off = (P < 64 ? P : 64) / 2; off >= 1; off >>= 1) sv += __shfl_xor(sv, off, 64);
         if (bval[j] && (lane % P) == 0)
-          a.partials[((size_t)(grp + kGroups * j) * M + m) * a.slots + blockIdx.x] = sv;
+          a.partials[((size_t)bidx[j] * M + m) * a.slots + blockIdx.x] = sv;
       }
     }
   }
@@ -492,6 +494,24 @@ static int srf_common(SrfArgs& a, const int32_t* k0, const int32_t* klen, int32_
       a.wtaps = total > 0 ? total : kTapChunk;
     } else {
       a.wtaps = 0;
+    }
+  }
+  // Band -> (group, slot): the slowest of the 8 groups sets the length of the dot-product phase, so deal the
+  // bands out longest first to the least loaded group (2 slots each).  Any assignment gives identical bits.
+  {
+    int order[HSR_MAX_BANDS], load[8] = {0, 0, 0, 0, 0, 0, 0, 0}, used[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int g = 0; g < 8; ++g) a.bands.band_of[g][0] = a.bands.band_of[g][1] = -1;
+    for (int b = 0; b < a.nb; ++b) order[b] = b;
+    for (int i = 1; i < a.nb; ++i)   // insertion sort by descending tap count (stable)
+      for (int k = i; k > 0 && a.bands.klen[order[k]] > a.bands.klen[order[k - 1]]; --k) {
+        const int t = order[k]; order[k] = order[k - 1]; order[k - 1] = t;
+      }
+    for (int i = 0; i < a.nb; ++i) {
+      int best = -1;
+      for (int g = 0; g < 8; ++g)
+        if (used[g] < 2 && (best < 0 || load[g] < load[best])) best = g;
+      a.bands.band_of[best][used[best]++] = (int8_t)order[i];
+      load[best] += a.bands.klen[order[i]] + 1;
     }
   }
   if (a.npix == 0) return HSR_OK;

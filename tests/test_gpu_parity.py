@@ -478,6 +478,14 @@ def test_rccl_exchange_path_single_rank(torch_gpu):
             assert torch.equal(out.coeffs, base.coeffs), mode
             assert torch.equal(out.moments, base.moments), mode
             assert torch.equal(out.matched.view(torch.int32), base.matched.view(torch.int32)), mode
+            # the pipelined path issues the RCCL collective from the side stream
+            plan = SpectralFusion(w, srf, good, deg=3, coeff_sync=mode, force_exchange=True)
+            assert plan.submit(R, real) is None
+            o1 = plan.submit(R, real)
+            o2 = plan.flush()
+            torch.cuda.synchronize()
+            for o in (o1, o2):
+                assert torch.equal(o.coeffs, base.coeffs) and torch.equal(o.matched.view(torch.int32), base.matched.view(torch.int32)), mode
     finally:
         if created:
             dist.destroy_process_group()

@@ -12,10 +12,11 @@
 namespace hsr {
 
 constexpr int kBins1 = 2048, kBins2 = 2048, kBins3 = 1024, kQ = 4;
+constexpr int kHist1 = kBins1 + 4;   // per channel: 2048 bins + [NaN count, pad, pad, pad]
 
 struct SelState {      // one per channel
   uint32_t n;          // masked sample count
-  uint32_t nan_count;  // masked NaNs
+  uint32_t nan_count;  // masked NaNs (copied from the pass-1 histogram tail by scan 1)
   uint32_t prefix[kQ]; // key prefix fixed so far, per rank query
   uint32_t rem[kQ];    // rank remaining inside that prefix
   double gamma[2];     // interpolation weights of (pmin, pmax)
@@ -27,7 +28,7 @@ struct SelArgs {
   const uint8_t* mask;
   int64_t npix;
   int32_t nb;
-  uint32_t* hist1;   // [nb][kBins1]
+  uint32_t* hist1;   // [nb][kHist1]
   uint32_t* hist2;   // [nb][kQ][kBins2]
   uint32_t* hist3;   // [nb][kQ][kBins3]
   SelState* state;   // [nb]
@@ -74,11 +75,11 @@ __global__ __launch_bounds__(256) void select_hist_kernel(const SelArgs a) {
     }
   }
   __syncthreads();
-  uint32_t* g = PASS == 1 ? a.hist1 + (size_t)c * kBins1
+  uint32_t* g = PASS == 1 ? a.hist1 + (size_t)c * kHist1
                           : (PASS == 2 ? a.hist2 + (size_t)c * kQ * kBins2 : a.hist3 + (size_t)c * kQ * kBins3);
   for (int i = threadIdx.x; i < NB; i += 256)
     if (h[i]) atomicAdd(&g[i], h[i]);
-  if (PASS == 1 && threadIdx.x == 0 && nanc) atomicAdd(&a.state[c].nan_count, nanc);
+  if (PASS == 1 && threadIdx.x == 0 && nanc) atomicAdd(&a.hist1[(size_t)c * kHist1 + kBins1], nanc);
 }
 
 // Locate, for one histogram of `nbins` (multiple of 256) bins, the bin holding 0-based rank r:
@@ -123,7 +124,7 @@ __global__ __launch_bounds__(256) void select_scan_kernel(const SelArgs a, doubl
   if (PASS == 1) {
     // total masked count, then the four ranks NumPy would index
     uint32_t local = 0;
-    for (int i = threadIdx.x; i < kBins1; i += 256) local += a.hist1[(size_t)c * kBins1 + i];
+    for (int i = threadIdx.x; i < kBins1; i += 256) local += a.hist1[(size_t)c * kHist1 + i];
     scratch[threadIdx.x] = local;
     __syncthreads();
     if (threadIdx.x == 0) {
@@ -131,6 +132,7 @@ __global__ __launch_bounds__(256) void select_scan_kernel(const SelArgs a, doubl
       for (int i = 0; i < 256; ++i) n += scratch[i];
       total = n;
       st->n = n;
+      st->nan_count = a.hist1[(size_t)c * kHist1 + kBins1];
       const double q[2] = {qlo, qhi};
       for (int j = 0; j < 2; ++j) {
         uint32_t prev = 0, next = 0;
@@ -158,7 +160,7 @@ __global__ __launch_bounds__(256) void select_scan_kernel(const SelArgs a, doubl
     __syncthreads();
     if (total == 0) return;
     for (int q = 0; q < kQ; ++q) {
-      block_locate(a.hist1 + (size_t)c * kBins1, kBins1, ranks[q], scratch, &bins[q], &rems[q]);
+      block_locate(a.hist1 + (size_t)c * kHist1, kBins1, ranks[q], scratch, &bins[q], &rems[q]);
       if (threadIdx.x == 0) {
         st->prefix[q] = bins[q];
         st->rem[q] = rems[q];
@@ -196,7 +198,7 @@ __global__ __launch_bounds__(256) void select_scan_kernel(const SelArgs a, doubl
   }
 }
 
-static size_t hist1_bytes(int nb) { return (size_t)nb * kBins1 * 4; }
+static size_t hist1_bytes(int nb) { return (size_t)nb * kHist1 * 4; }
 static size_t hist2_bytes(int nb) { return (size_t)nb * kQ * kBins2 * 4; }
 static size_t hist3_bytes(int nb) { return (size_t)nb * kQ * kBins3 * 4; }
 static size_t state_bytes(int nb) { return (size_t)nb * sizeof(SelState); }
@@ -210,21 +212,13 @@ extern "C" size_t hsr_percentile_work_bytes(int32_t nb) {
   return hist1_bytes(nb) + hist2_bytes(nb) + hist3_bytes(nb) + state_bytes(nb) + 64;
 }
 
-extern "C" int hsr_percentile_limits(const float* x_dev, int64_t x_bs, int64_t x_ps,
-                                     const uint8_t* mask_dev, int64_t npix, int32_t nb, double pmin, double pmax,
-                                     void* work_dev, double* lohi_dev, hsr_stream_t stream) {
-  HSR_REQUIRE(x_dev && work_dev && lohi_dev, HSR_ERR_INVALID, "hsr_percentile_limits: NULL pointer");
-  HSR_REQUIRE(nb >= 1 && nb <= HSR_MAX_BANDS, HSR_ERR_UNSUPPORTED, "hsr_percentile_limits: nb=%d", nb);
-  HSR_REQUIRE(npix >= 1 && npix < ((int64_t)1 << 31), HSR_ERR_UNSUPPORTED, "hsr_percentile_limits: npix=%lld",
-              (long long)npix);
-  HSR_REQUIRE(pmin >= 0.0 && pmin <= 100.0 && pmax >= 0.0 && pmax <= 100.0, HSR_ERR_INVALID,
-              "hsr_percentile_limits: percentiles must be in the range [0, 100]");
-  HSR_REQUIRE(((uintptr_t)work_dev & 7) == 0, HSR_ERR_INVALID, "hsr_percentile_limits: workspace not 8-byte aligned");
-  hipStream_t s = (hipStream_t)stream;
-  SelArgs a{};
+static int select_setup(SelArgs& a, const float* x_dev, int64_t x_bs, int64_t x_ps, const uint8_t* mask_dev,
+                        int64_t npix, int32_t nb, void* work_dev, const char* who) {
+  HSR_REQUIRE(work_dev, HSR_ERR_INVALID, "%s: NULL workspace", who);
+  HSR_REQUIRE(nb >= 1 && nb <= HSR_MAX_BANDS, HSR_ERR_UNSUPPORTED, "%s: nb=%d", who, nb);
+  HSR_REQUIRE(((uintptr_t)work_dev & 7) == 0, HSR_ERR_INVALID, "%s: workspace not 8-byte aligned", who);
+  a = SelArgs{};
   a.x = x_dev;
-  HSR_REQUIRE((x_ps == 1 && x_bs >= npix) || (x_bs == 1 && x_ps >= nb), HSR_ERR_INVALID,
-              "hsr_percentile_limits: strides are neither band-major nor pixel-major");
   a.cs = x_bs;
   a.ps = x_ps;
   a.mask = mask_dev;
@@ -238,18 +232,77 @@ extern "C" int hsr_percentile_limits(const float* x_dev, int64_t x_bs, int64_t x
   a.hist2 = (uint32_t*)w;
   w += hist2_bytes(nb);
   a.hist3 = (uint32_t*)w;
-  int rc = check_hip(hipMemsetAsync(work_dev, 0, hsr_percentile_work_bytes(nb), s), "hipMemsetAsync");
-  if (rc != HSR_OK) return rc;
+  return HSR_OK;
+}
+
+static dim3 select_grid(int64_t npix, int nb) {
   int64_t gx = (npix + 256 * 8 - 1) / (256 * 8);
   if (gx > 1024) gx = 1024;
-  const dim3 grid((unsigned)gx, nb), block(256);
-  const double qlo = pmin / 100.0, qhi = pmax / 100.0;
-  hipLaunchKernelGGL(select_hist_kernel<1>, grid, block, 0, s, a);
-  hipLaunchKernelGGL(select_scan_kernel<1>, dim3(nb), block, 0, s, a, qlo, qhi, lohi_dev);
-  hipLaunchKernelGGL(select_hist_kernel<2>, grid, block, 0, s, a);
-  hipLaunchKernelGGL(select_scan_kernel<2>, dim3(nb), block, 0, s, a, qlo, qhi, lohi_dev);
-  hipLaunchKernelGGL(select_hist_kernel<3>, grid, block, 0, s, a);
-  hipLaunchKernelGGL(select_scan_kernel<3>, dim3(nb), block, 0, s, a, qlo, qhi, lohi_dev);
-  HSR_LAUNCH_CHECK("select kernels");
+  return dim3((unsigned)gx, nb);
+}
+
+// ---- per-pass interface: lets ranks all-reduce(sum) the integer histogram of each pass in between, which
+// makes the order statistics exact over the union of the ranks' samples (global stretch limits).
+extern "C" int hsr_percentile_begin(void* work_dev, int32_t nb, hsr_stream_t stream) {
+  HSR_REQUIRE(work_dev && nb >= 1 && nb <= HSR_MAX_BANDS, HSR_ERR_INVALID, "hsr_percentile_begin: bad argument");
+  return check_hip(hipMemsetAsync(work_dev, 0, hsr_percentile_work_bytes(nb), (hipStream_t)stream), "hipMemsetAsync");
+}
+
+extern "C" int hsr_percentile_hist_region(int32_t pass, int32_t nb, int64_t* offset_bytes, int64_t* count_u32) {
+  HSR_REQUIRE(pass >= 1 && pass <= 3 && nb >= 1 && nb <= HSR_MAX_BANDS && offset_bytes && count_u32, HSR_ERR_INVALID,
+              "hsr_percentile_hist_region: bad argument");
+  const size_t o1 = (state_bytes(nb) + 7) & ~(size_t)7, o2 = o1 + hist1_bytes(nb), o3 = o2 + hist2_bytes(nb);
+  *offset_bytes = (int64_t)(pass == 1 ? o1 : (pass == 2 ? o2 : o3));
+  *count_u32 = (int64_t)((pass == 1 ? hist1_bytes(nb) : (pass == 2 ? hist2_bytes(nb) : hist3_bytes(nb))) / 4);
   return HSR_OK;
+}
+
+extern "C" int hsr_percentile_hist(int32_t pass, const float* x_dev, int64_t x_bs, int64_t x_ps,
+                                   const uint8_t* mask_dev, int64_t npix, int32_t nb, void* work_dev,
+                                   hsr_stream_t stream) {
+  HSR_REQUIRE(x_dev && pass >= 1 && pass <= 3, HSR_ERR_INVALID, "hsr_percentile_hist: bad argument");
+  HSR_REQUIRE(npix >= 0 && npix < ((int64_t)1 << 31), HSR_ERR_UNSUPPORTED, "hsr_percentile_hist: npix=%lld", (long long)npix);
+  HSR_REQUIRE((x_ps == 1 && x_bs >= npix) || (x_bs == 1 && x_ps >= nb), HSR_ERR_INVALID,
+              "hsr_percentile_hist: strides are neither band-major nor pixel-major");
+  SelArgs a;
+  int rc = select_setup(a, x_dev, x_bs, x_ps, mask_dev, npix, nb, work_dev, "hsr_percentile_hist");
+  if (rc != HSR_OK) return rc;
+  if (npix == 0) return HSR_OK;
+  hipStream_t s = (hipStream_t)stream;
+  const dim3 grid = select_grid(npix, nb), block(256);
+  if (pass == 1) hipLaunchKernelGGL(select_hist_kernel<1>, grid, block, 0, s, a);
+  else if (pass == 2) hipLaunchKernelGGL(select_hist_kernel<2>, grid, block, 0, s, a);
+  else hipLaunchKernelGGL(select_hist_kernel<3>, grid, block, 0, s, a);
+  HSR_LAUNCH_CHECK("select_hist_kernel");
+  return HSR_OK;
+}
+
+extern "C" int hsr_percentile_scan(int32_t pass, int32_t nb, double pmin, double pmax, void* work_dev,
+                                   double* lohi_dev, hsr_stream_t stream) {
+  HSR_REQUIRE(pass >= 1 && pass <= 3 && lohi_dev, HSR_ERR_INVALID, "hsr_percentile_scan: bad argument");
+  HSR_REQUIRE(pmin >= 0.0 && pmin <= 100.0 && pmax >= 0.0 && pmax <= 100.0, HSR_ERR_INVALID,
+              "hsr_percentile_scan: percentiles must be in the range [0, 100]");
+  SelArgs a;
+  int rc = select_setup(a, nullptr, 0, 0, nullptr, 0, nb, work_dev, "hsr_percentile_scan");
+  if (rc != HSR_OK) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  const double qlo = pmin / 100.0, qhi = pmax / 100.0;
+  if (pass == 1) hipLaunchKernelGGL(select_scan_kernel<1>, dim3(nb), dim3(256), 0, s, a, qlo, qhi, lohi_dev);
+  else if (pass == 2) hipLaunchKernelGGL(select_scan_kernel<2>, dim3(nb), dim3(256), 0, s, a, qlo, qhi, lohi_dev);
+  else hipLaunchKernelGGL(select_scan_kernel<3>, dim3(nb), dim3(256), 0, s, a, qlo, qhi, lohi_dev);
+  HSR_LAUNCH_CHECK("select_scan_kernel");
+  return HSR_OK;
+}
+
+extern "C" int hsr_percentile_limits(const float* x_dev, int64_t x_bs, int64_t x_ps, const uint8_t* mask_dev,
+                                     int64_t npix, int32_t nb, double pmin, double pmax, void* work_dev,
+                                     double* lohi_dev, hsr_stream_t stream) {
+  HSR_REQUIRE(x_dev && work_dev && lohi_dev, HSR_ERR_INVALID, "hsr_percentile_limits: NULL pointer");
+  HSR_REQUIRE(npix >= 1, HSR_ERR_UNSUPPORTED, "hsr_percentile_limits: npix=%lld", (long long)npix);
+  int rc = hsr_percentile_begin(work_dev, nb, stream);
+  for (int pass = 1; pass <= 3 && rc == HSR_OK; ++pass) {
+    rc = hsr_percentile_hist(pass, x_dev, x_bs, x_ps, mask_dev, npix, nb, work_dev, stream);
+    if (rc == HSR_OK) rc = hsr_percentile_scan(pass, nb, pmin, pmax, work_dev, lohi_dev, stream);
+  }
+  return rc;
 }

@@ -322,15 +322,42 @@ def poly_apply_stretch_only(x, lohi, layout: str = PLANAR, out=None, nb: Optiona
     return poly_apply(x, None, None, lohi, True, layout, out, nb)
 
 
-def percentile_limits(x, mask=None, pmin=2.0, pmax=98.0, layout: str = PLANAR, nb: Optional[int] = None):
-    """Exact np.percentile(vals[mask], [pmin, pmax]) per channel -> (nb, 2) float64 on the device."""
+def percentile_limits(x, mask=None, pmin=2.0, pmax=98.0, layout: str = PLANAR, nb: Optional[int] = None,
+                      group=None, distributed: Optional[bool] = None, _reduce=None):
+    """Exact np.percentile(vals[mask], [pmin, pmax]) per channel -> (nb, 2) float64 on the device.
+
+    With a torch.distributed group of more than one rank (or distributed=True) the limits are GLOBAL: the
+    integer histogram of each of the three radix-select passes is all-reduced (sum) between the ranks, so
+    the order statistics are exact over the union of every rank's masked samples - the stretch limits of
+    the reference pipeline (color.py:31-32) for a mosaic sharded over GPUs.  ``_reduce`` (tests) replaces
+    the all-reduce by a callable acting on the int32 histogram view."""
     torch = nat.require_gpu()
     lib = nat.load()
     xbs, xps, n, npix = _img(x, layout, nb)
     work = torch.empty(lib.hsr_percentile_work_bytes(n) // 8 + 1, dtype=torch.int64, device=x.device)
     lohi = torch.empty((n, 2), dtype=torch.float64, device=x.device)
-    nat.check(lib.hsr_percentile_limits(_ptr(x), xbs, xps, _ptr(mask), npix, n, float(pmin), float(pmax),
-                                        _ptr(work), _ptr(lohi), _stream(torch)), "hsr_percentile_limits")
+    if distributed is None:
+        import torch.distributed as dist
+        distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+    if not distributed and _reduce is None:
+        nat.check(lib.hsr_percentile_limits(_ptr(x), xbs, xps, _ptr(mask), npix, n, float(pmin), float(pmax),
+                                            _ptr(work), _ptr(lohi), _stream(torch)), "hsr_percentile_limits")
+        return lohi
+    w32 = work.view(torch.int32)
+    nat.check(lib.hsr_percentile_begin(_ptr(work), n, _stream(torch)), "hsr_percentile_begin")
+    for p in (1, 2, 3):
+        nat.check(lib.hsr_percentile_hist(p, _ptr(x), xbs, xps, _ptr(mask), npix, n, _ptr(work), _stream(torch)),
+                  "hsr_percentile_hist")
+        off, cnt = C.c_int64(0), C.c_int64(0)
+        nat.check(lib.hsr_percentile_hist_region(p, n, C.byref(off), C.byref(cnt)), "hsr_percentile_hist_region")
+        region = w32[off.value // 4: off.value // 4 + cnt.value]
+        if _reduce is not None:
+            _reduce(p, region)
+        else:
+            import torch.distributed as dist
+            dist.all_reduce(region, op=dist.ReduceOp.SUM, group=group)
+        nat.check(lib.hsr_percentile_scan(p, n, float(pmin), float(pmax), _ptr(work), _ptr(lohi), _stream(torch)),
+                  "hsr_percentile_scan")
     return lohi
 
 

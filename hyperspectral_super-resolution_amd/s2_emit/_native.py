@@ -55,6 +55,10 @@ SIGNATURES = {
     "hsr_poly_apply": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i32, _i32, _i64, _vp, _i32, _vp, _i64, _i64, _vp]),
     "hsr_percentile_work_bytes": (C.c_size_t, [_i32]),
     "hsr_percentile_limits": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i32, _f64, _f64, _vp, _vp, _vp]),
+    "hsr_percentile_begin": (C.c_int, [_vp, _i32, _vp]),
+    "hsr_percentile_hist_region": (C.c_int, [_i32, _i32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
+    "hsr_percentile_hist": (C.c_int, [_i32, _vp, _i64, _i64, _vp, _i64, _i32, _vp, _vp]),
+    "hsr_percentile_scan": (C.c_int, [_i32, _i32, _f64, _f64, _vp, _vp, _vp]),
     "hsr_valid_mask": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp]),
     "hsr_polyfeat_count": (C.c_int, [_i32, _i32]),
     "hsr_polyfeat_table": (C.c_int, [_i32, _i32, _vp]),

@@ -42,11 +42,15 @@ def robust_norm_rgb(img: np.ndarray, mask: np.ndarray, pmin: float = 2, pmax: fl
     return y
 
 
-def device_percentile_stretch(x, mask=None, pmin=2, pmax=98, layout=nat.PIXMAJOR, lohi=None, nb=None):
+def device_percentile_stretch(x, mask=None, pmin=2, pmax=98, layout=nat.PIXMAJOR, lohi=None, nb=None,
+                              group=None, distributed=None):
     """Device form: x float32 (npix, C) pixel-major or (C, npix) planar, mask uint8 (npix,).
-    Returns (stretched float32 tensor, lohi (C, 2) float64 tensor); no host synchronisation."""
+    Returns (stretched float32 tensor, lohi (C, 2) float64 tensor); no host synchronisation.
+    Inside an initialised torch.distributed job of more than one rank the limits are the exact
+    percentiles of the union of all ranks' masked samples (histogram all-reduce per select pass,
+    see _engine.percentile_limits); pass distributed=False for per-rank limits."""
     if lohi is None:
-        lohi = eng.percentile_limits(x, mask, pmin, pmax, layout, nb)
+        lohi = eng.percentile_limits(x, mask, pmin, pmax, layout, nb, group=group, distributed=distributed)
     return eng.poly_apply_stretch_only(x, lohi, layout, nb=nb), lohi
 
 

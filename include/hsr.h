@@ -152,6 +152,18 @@ int hsr_percentile_limits(const float* x_dev, int64_t x_bs, int64_t x_ps,
                           double pmin, double pmax, void* work_dev, double* lohi_dev,
                           hsr_stream_t stream);
 
+/* The same select, pass by pass (1..3), for multi-GPU global limits: every rank runs hist(pass) on its own
+ * samples, the ranks all-reduce(sum) the uint32 histogram region of that pass (hsr_percentile_hist_region gives
+ * its byte offset and length inside the workspace), then every rank runs scan(pass): the order statistics
+ * are then exact over the union of all ranks' masked samples (total count < 2^31).  begin() zeroes the
+ * workspace; after scan(3) lohi_dev holds the limits.  hsr_percentile_limits == begin + 3 x (hist, scan). */
+int hsr_percentile_begin(void* work_dev, int32_t nb, hsr_stream_t stream);
+int hsr_percentile_hist_region(int32_t pass, int32_t nb, int64_t* offset_bytes, int64_t* count_u32);
+int hsr_percentile_hist(int32_t pass, const float* x_dev, int64_t x_bs, int64_t x_ps, const uint8_t* mask_dev,
+                        int64_t npix, int32_t nb, void* work_dev, hsr_stream_t stream);
+int hsr_percentile_scan(int32_t pass, int32_t nb, double pmin, double pmax, void* work_dev, double* lohi_dev,
+                        hsr_stream_t stream);
+
 /* Validity mask of the pipeline (poly_regression.py:106,118): mask[p] = all bands of x finite
  * && x[pos_band][p] > 0 (pos_band < 0: skip) && all bands of y finite (y_dev may be NULL),
  * optionally AND-ed with mask_in_dev. */

@@ -829,3 +829,53 @@ def test_ot_color_transfer_and_ot_fit_vs_oracle(torch_gpu):
     tiny = np.zeros((H, W), bool)
     tiny[0, 0] = True
     np.testing.assert_array_equal(s2_emit.ot_match_rgb_sinkhorn_pot(src, ref, tiny), src)
+
+
+def test_global_percentiles_across_simulated_ranks(torch_gpu):
+    """Distributed order statistic: three 'ranks' (three pixel shards on one GPU) exchange only the integer
+    histogram of each radix-select pass (summed here by hand, by RCCL all-reduce in a real job) and must all
+    arrive at np.percentile of the union - exactly."""
+    torch = torch_gpu
+    from s2_emit import _engine as eng
+    rng = np.random.default_rng(99)
+    nb = 3
+    shards = [rng.standard_normal((nb, n)).astype(np.float32) * s + o for n, s, o in ((30011, 1.0, 0.0), (777, 5.0, 2.0), (12000, 0.1, -3.0))]
+    masks = [rng.random(x.shape[1]) > 0.3 for x in shards]
+    xs = [torch.from_numpy(x).cuda() for x in shards]
+    ms = [torch.from_numpy(m.view(np.uint8)).cuda() for m in masks]
+    R = len(xs)
+    # lock-step emulation: a per-pass buffer collects every rank's histogram; each rank's turn k contributes
+    # its region, and a second sweep overwrites every rank's region with the sum (what all-reduce does)
+    import threading
+    results = [None] * R
+    barrier = threading.Barrier(R)
+    shared = {}
+    lock = threading.Lock()
+
+    def worker(r):
+        torch.cuda.set_device(0)
+
+        def red(p, region):
+            torch.cuda.synchronize()
+            with lock:
+                shared.setdefault(p, torch.zeros_like(region))
+                shared[p] += region
+            barrier.wait()
+            region.copy_(shared[p])
+            torch.cuda.synchronize()
+            barrier.wait()
+        results[r] = eng.percentile_limits(xs[r], ms[r], 2, 98, _reduce=red).cpu().numpy()
+
+    ts = [threading.Thread(target=worker, args=(r,)) for r in range(R)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    allx = np.concatenate([x[:, m] for x, m in zip(shards, masks)], axis=1)
+    ref = np.array([np.percentile(allx[c], [2, 98]) for c in range(nb)])
+    for r in range(R):
+        np.testing.assert_array_equal(results[r], ref)
+    # and the single-rank pass-by-pass path equals the one-call path
+    a = eng.percentile_limits(xs[0], ms[0], 5, 95).cpu().numpy()
+    b = eng.percentile_limits(xs[0], ms[0], 5, 95, _reduce=lambda p, region: None).cpu().numpy()
+    np.testing.assert_array_equal(a, b)

@@ -54,6 +54,10 @@ def parse_args():
                     help="one-tile-deep software pipeline (exchange of tile i under K1 of tile i+1); auto = on for N > 1")
     ap.add_argument("--reserve-cus", type=int, default=4,
                     help="CUs left free of persistent K1 workgroups in pipelined mode (side-stream tail of the previous tile)")
+    ap.add_argument("--cube", default="f32", choices=["f32", "u16"],
+                    help="f32: the headline workload (float32 cube, 4 B per pixel*band).  u16: the same cube in the "
+                         "reference's on-disk tile format (uint16 x 10000, tiles_helpers/utils.py:362-374), decoded inside "
+                         "K1 - a SURVEY 8-f2 measurement, 2 B per pixel*band, not the headline")
     ap.add_argument("--event-every", type=int, default=4,
                     help="bracket the K1+K2 kernel with HIP events on every n-th timed step (each pair of event "
                          "records costs ~12 us of launch gap, so not on every step)")
@@ -114,6 +118,10 @@ def main():
     plan = SpectralFusion(prob.emit_w, prob.srf, prob.good_mask, deg=args.deg, min_valid=0.0, min_count=50,
                           clip=True, device=device, group=None, coeff_sync=args.coeff_sync if world > 1 else "local")
     real = prob.real            # (H, W, row) band-last, like the cube and the reference's (H, W, C) images
+    cube = prob.cube
+    if args.cube == "u16":      # quantise once, outside the timed region (the writer's arithmetic, on the device)
+        cube = eng.tile_encode_u16(prob.cube)
+        prob.cube = None
 
     def barrier():
         if world > 1:
@@ -127,15 +135,21 @@ def main():
 
     def run_step(k1_events=None):
         if pipelined:
-            plan.submit(prob.cube, real, k1_events=k1_events)
+            plan.submit(cube, real, k1_events=k1_events)
         else:
-            plan.step(prob.cube, real, k1_events=k1_events)
+            plan.step(cube, real, k1_events=k1_events)
 
     for _ in range(args.warmup):
         run_step()
     if pipelined:
         plan.flush()
     barrier()
+    # A generation-2 pass of Python's cycle collector takes ~40 ms with torch imported - several times the whole
+    # timed region - and stalls the launch thread (seen in rocprof traces as a 37-50 ms idle gap in front of one
+    # kernel).  As timeit does: collect now, keep the collector off while timing.
+    import gc
+    gc.collect()
+    gc.disable()
     every = max(1, args.event_every)
     ev = {i: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for i in range(0, args.steps, every)}
@@ -146,6 +160,7 @@ def main():
         plan.flush()            # the last tile's apply belongs to the timed region
     barrier()
     dt = time.perf_counter() - t0
+    gc.enable()
 
     k1_ms = sum(a.elapsed_time(b) for a, b in ev.values()) / max(1, len(ev))
     tt = torch.tensor([dt], dtype=torch.float64, device=device)
@@ -156,15 +171,15 @@ def main():
     if rank == 0:
         npb = H * W * B
         value = world * npb * args.steps / dt_max / 1e6
-        cube_bytes = npb * 4
+        cube_bytes = npb * (4 if args.cube == "f32" else 2)
         achieved = cube_bytes / (k1_ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": "srf_kernel<deg,fast> (K1+K2 fused)", "achieved": round(achieved, 1),
+        roof = {"bound": "hbm", "kernel": "srf_kernel<deg,fast> (K1+K2 fused)" if args.cube == "f32" else "srf_u16_ring_kernel<deg> (K1+K2 fused, uint16 tile decode)", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": None, "algorithmic_bytes": cube_bytes, "kernel_ms": round(k1_ms, 4),
                 "kernel_launches_timed": len(ev),
                 "step_frac_of_peak": round(cube_bytes * args.steps / dt_max / 1e9 / HBM_PEAK_GBS, 4)}
         tf = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.isfile(tf):
+        if os.path.isfile(tf) and args.cube == "f32":
             try:
                 roof["traffic"] = json.load(open(tf)).get("srf_kernel_hbm_bytes_per_launch")
             except Exception:
@@ -176,7 +191,7 @@ def main():
                 "warmup": args.warmup, "ms_per_step": round(dt_max / args.steps * 1e3, 4),
                 "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
                 "data": "synthetic",
-                "config": {"workload": f"{H}x{W}x{B} EMIT-like cube + {len(prob.names)} real-S2 planes per GPU, "
+                "config": {"workload": f"{H}x{W}x{B} EMIT-like cube{' stored as uint16 x 10000 tiles (decode fused into K1)' if args.cube == 'u16' else ''} + {len(prob.names)} real-S2 planes per GPU, "
                                        f"deg-{args.deg} per-band least squares over all valid pixels "
                                        f"(BASELINE.json configs[2]; one tile per GPU for N>1)",
                            "tiles_per_gpu": 1, "coeff_sync": args.coeff_sync if world > 1 else "none",

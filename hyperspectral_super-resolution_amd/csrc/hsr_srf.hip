@@ -57,6 +57,10 @@ struct SrfArgs {
   float min_x, min_y;
   double* partials;
   int32_t slots;
+  // uint16 tiles (srf_u16_kernel): cube points at uint16 samples, x = float(u) * scale, u == nodata -> NaN
+  int32_t u16;
+  float scale;
+  uint32_t nodata;   // > 0xffff: no nodata value
 #ifdef HSR_PHASE_STAMPS
   unsigned long long* stamps;
 #endif
@@ -92,6 +96,8 @@ static int g_tile_pixels = 64;
 // CUs left without a persistent K1 workgroup so that small kernels on another stream (slot reduction,
 // RCCL exchange, solve) can run while K1 of the next tile owns the rest of the chip.
 static int g_reserved_cus = 0;
+// uint16 tiles: 1 = double-buffered kernel where it fits (default), 0 = single-buffer kernel (A/B switch)
+static int g_u16_ring = 1;
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -400,6 +406,514 @@ __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// K1 on uint16 tiles: the training tiles on disk are uint16 reflectance x 10000 with
+// nodata 65535 (reference writer tiles_helpers/utils.py:362-374).  Same data flow as srf_kernel, but
+// the LDS-DMA moves the 2-byte samples (half the HBM bytes) and the decode x = float(u) * scale
+// happens on the way out of LDS, one separately rounded multiply per tap, so that the planes and the
+// moments are bit-identical to hsr_tile_decode_u16 followed by the float32 kernel.  A pixel holding a
+// nodata sample decodes to NaN there, and 0 * NaN poisons every band: flagged pixels are NaN in all
+// bands.  64-pixel tiles (P*B*2 = 128*B bytes: always whole 16-byte chunks), 8 waves, lane = pixel.
+template <int DEG, bool FAST, bool OUTV>
+__global__ __launch_bounds__(512, 4) void srf_u16_kernel(const SrfArgs a) {
+  constexpr int P = 64, T = 512;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  uint16_t* tile = reinterpret_cast<uint16_t*>(smem);
+  const int B = a.B;
+  uint32_t* flags = reinterpret_cast<uint32_t*>(smem + (size_t)P * B * 2);
+  const float* wl = reinterpret_cast<const float*>(flags + 64);
+  const bool wlds = a.wtaps > 0;
+  float* ostage = const_cast<float*>(wl) + a.wtaps;
+  const int ops = (int)a.out_ps;
+  int64_t prev_pix0 = 0;
+  int prev_npx = 0;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  // lane -> pixel: lanes 0..31 take the even pixels of the tile, lanes 32..63 the odd ones.  A pixel row is
+  // 2*B bytes = B/2 dwords (142.5 for B = 285), so with lane = pixel neighbouring rows alternate between two
+  // bank phases and 10 of 16 lane pairs collide; inside each half-wave the rows now start B dwords apart
+  // (odd -> conflict-free, as in the float32 kernel).
+  const int pl = 2 * (lane & 31) + (lane >> 5), grp = wave;
+  const float scale = a.scale;
+  const uint32_t nd2 = (a.nodata & 0xffffu) * 0x00010001u;
+  const bool has_nodata = a.nodata <= 0xffffu;
+
+  int bk0[kBandSlots], bkl[kBandSlots], bwo[kBandSlots], bidx[kBandSlots];
+  bool bval[kBandSlots];
+#pragma unroll
+  for (int j = 0; j < kBandSlots; ++j) {
+    const int b = a.bands.band_of[grp][j];
+    bval[j] = b >= 0;
+    bidx[j] = bval[j] ? b : 0;
+    bk0[j] = a.bands.k0[bidx[j]];
+    bkl[j] = bval[j] ? a.bands.klen[bidx[j]] : 0;
+    bwo[j] = a.bands.woff[bidx[j]];
+  }
+  if (wlds) {
+    float* wlw = const_cast<float*>(wl);
+    for (int b = 0; b < a.nb; ++b) {
+      const int kl = a.bands.klen[b];
+      for (int i = t; i < kl; i += T) wlw[a.bands.woff[b] + i] = a.wn[(size_t)b * B + a.bands.k0[b] + i];
+    }
+  }
+
+  constexpr int M = DEG > 0 ? moment_count(DEG) : 1;
+  double acc_m[kBandSlots][M];
+  if (DEG > 0) {
+#pragma unroll
+    for (int j = 0; j < kBandSlots; ++j)
+#pragma unroll
+      for (int m = 0; m < M; ++m) acc_m[j][m] = 0.0;
+  }
+  const uint16_t* cube = reinterpret_cast<const uint16_t*>(a.cube);
+
+  for (int64_t tileidx = blockIdx.x; tileidx < a.ntiles; tileidx += gridDim.x) {
+    const int64_t pix0 = tileidx * P;
+    const int64_t left = a.npix - pix0;
+    const int npx = left < P ? (int)left : P;
+    const uint16_t* src = cube + pix0 * B;
+    const bool pvalid = pl < npx;
+    const int nchunk = (npx * B + 7) >> 3;  // 16-byte chunks (8 samples) holding the tile
+
+    // targets of the fused fit: inline-asm loads right after the DMA (see srf_kernel for why)
+    float yv[kBandSlots];
+    uint32_t mraw = 1u;
+    auto load_targets = [&]() {
+      if (DEG > 0) {
+        const int64_t pc = pvalid ? pix0 + pl : a.npix - 1;
+#pragma unroll
+        for (int j = 0; j < kBandSlots; ++j) yv[j] = load_f32_async(a.real + bidx[j] * a.real_bs + pc * a.real_ps);
+        if (a.mask != nullptr) mraw = load_u8_async(a.mask + pc);
+      }
+    };
+    auto wait_targets = [&]() {
+      if (DEG > 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        static_assert(kBandSlots == 2, "pin list below");
+        asm volatile("" : "+v"(yv[0]), "+v"(yv[1]), "+v"(mraw));
+      }
+    };
+
+    if (t < P) flags[t] = 0u;
+    if (FAST && npx == P) {
+      const char* srcb = reinterpret_cast<const char*>(src);
+      for (int c0 = wave * 64; c0 < nchunk; c0 += T) {
+        const int c = c0 + lane;
+        if (c < nchunk)
+          __builtin_amdgcn_global_load_lds((gptr_t)(srcb + (size_t)c * 16), (lptr_t)(smem + (size_t)c0 * 16),
+                                           16, 0, kGldsStream);
+      }
+      load_targets();
+      if (OUTV) flush_stage<T>(ostage, a.out, prev_pix0, prev_npx, ops, t);
+      __syncthreads();
+      wait_targets();
+    } else {
+      // generic loader: any 2-byte alignment, ragged last tile; the tail of the last chunk is zeroed
+      load_targets();
+      if (OUTV) flush_stage<T>(ostage, a.out, prev_pix0, prev_npx, ops, t);
+      wait_targets();
+      const int n = npx * B;
+      for (int i = t; i < nchunk * 8; i += T) tile[i] = i < n ? ld_stream(src + i) : (uint16_t)0;
+      __syncthreads();
+    }
+    if (has_nodata) {
+      // nodata sweep: a 16-bit lane of (v ^ nodata:nodata) is zero exactly where the sample is nodata
+      const uint4* t4 = reinterpret_cast<const uint4*>(smem);
+      for (int c0 = t; c0 < nchunk; c0 += T * kScanBatch) {
+        uint4 v[kScanBatch];
+#pragma unroll
+        for (int u = 0; u < kScanBatch; ++u) {
+          const int c = c0 + u * T;
+          v[u] = t4[c < nchunk ? c : nchunk - 1];
+        }
+        uint32_t hit = 0u;
+#pragma unroll
+        for (int u = 0; u < kScanBatch; ++u) {
+          const uint32_t w[4] = {v[u].x ^ nd2, v[u].y ^ nd2, v[u].z ^ nd2, v[u].w ^ nd2};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) hit |= (w[q] - 0x00010001u) & ~w[q] & 0x80008000u;
+        }
+        if (hit) {  // rare
+#pragma unroll
+          for (int u = 0; u < kScanBatch; ++u) {
+            const int c = c0 + u * T;
+            const int e = (c < nchunk ? c : nchunk - 1) * 8;
+            const uint32_t w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              if ((w[q] & 0xffffu) == (a.nodata & 0xffffu) && e + 2 * q < npx * B) flags[(e + 2 * q) / B] = 1u;
+              if ((w[q] >> 16) == (a.nodata & 0xffffu) && e + 2 * q + 1 < npx * B) flags[(e + 2 * q + 1) / B] = 1u;
+            }
+          }
+        }
+      }
+      __syncthreads();
+    }
+
+    const bool bad = flags[pl] != 0u;
+    const uint16_t* v = tile + pl * B;
+#pragma unroll
+    for (int j = 0; j < kBandSlots; ++j) {
+      float acc = 0.0f;
+      const uint16_t* vs = v + bk0[j];
+      if (wlds) {
+        // 16 taps = 9 aligned dwords (two samples each; one extra because odd sample offsets start in the
+        // middle of a dword) realigned per lane with v_alignbyte: 9 ds_read_b32 instead of 16 ds_read_u16.
+        // The ninth dword may lie past the row (next pixel / the flag words): its upper half is never used.
+        const float4* w4 = reinterpret_cast<const float4*>(wl + bwo[j]);
+        const int e0 = pl * B + bk0[j];
+        const uint32_t sh = (uint32_t)(e0 & 1) * 2u;
+        const uint32_t* d32 = reinterpret_cast<const uint32_t*>(smem) + (e0 >> 1);
+        for (int i0 = 0; i0 < bkl[j]; i0 += kTapChunk) {
+          float4 ww[kTapChunk / 4];
+          uint32_t d[kTapChunk / 2 + 1];
+#pragma unroll
+          for (int u = 0; u < kTapChunk / 4; ++u) ww[u] = w4[(i0 >> 2) + u];
+#pragma unroll
+          for (int u = 0; u <= kTapChunk / 2; ++u) d[u] = d32[(i0 >> 1) + u];
+#pragma unroll
+          for (int u = 0; u < kTapChunk / 4; ++u) {
+            const uint32_t ea = __builtin_amdgcn_alignbyte(d[2 * u + 1], d[2 * u], sh);
+            const uint32_t eb = __builtin_amdgcn_alignbyte(d[2 * u + 2], d[2 * u + 1], sh);
+            acc = fmaf(ww[u].x, (float)(ea & 0xffffu) * scale, acc);
+            acc = fmaf(ww[u].y, (float)(ea >> 16) * scale, acc);
+            acc = fmaf(ww[u].z, (float)(eb & 0xffffu) * scale, acc);
+            acc = fmaf(ww[u].w, (float)(eb >> 16) * scale, acc);
+          }
+        }
+      } else {
+        const float* ws = a.wn + (size_t)bidx[j] * B + bk0[j];
+        for (int i = 0; i < bkl[j]; ++i) acc = fmaf(ws[i], (float)vs[i] * scale, acc);
+      }
+      if (bad) acc = __uint_as_float(0x7fc00000u);
+      if (bval[j]) {
+        if (OUTV) ostage[pl * ops + bidx[j]] = acc;
+        else if (pvalid) st_stream(a.out + bidx[j] * a.out_bs + (pix0 + pl) * a.out_ps, acc);
+        if (DEG > 0) {
+          const float y = yv[j];
+          const bool ok = pvalid && mraw != 0u && finite_f32(acc) && finite_f32(y) && acc > a.min_x && y > a.min_y;
+          if (ok) {
+            const double xd = (double)acc, yd = (double)y;
+            acc_m[j][0] += 1.0;
+            acc_m[j][2 * DEG + 1] += yd;
+            double pw = 1.0;
+#pragma unroll
+            for (int k = 1; k <= 2 * DEG; ++k) {
+              pw *= xd;
+              acc_m[j][k] += pw;
+              if (k <= DEG) acc_m[j][2 * DEG + 1 + k] += pw * yd;
+            }
+          }
+        }
+      }
+    }
+    prev_pix0 = pix0;
+    prev_npx = npx;
+    lds_barrier();
+  }
+  if (OUTV) flush_stage<T>(ostage, a.out, prev_pix0, prev_npx, ops, t);
+
+  if (DEG > 0) {
+#pragma unroll
+    for (int j = 0; j < kBandSlots; ++j) {
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        // bring the accumulator of pixel q to lane q first: the butterfly then adds in exactly the order of
+        // the float32 kernel (lane = pixel), so the partial sums are bit-identical to decode + float32 K1
+        double sv = __shfl(acc_m[j][m], (lane >> 1) + 32 * (lane & 1), 64);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) sv += __shfl_xor(sv, off, 64);
+        if (bval[j] && lane == 0) a.partials[((size_t)bidx[j] * M + m) * a.slots + blockIdx.x] = sv;
+      }
+    }
+  }
+}
+
+// LDS-DMA issued from inline asm: the compiler's waitcnt pass then does not know a DMA is pending and does
+// not force vmcnt(0) in front of every ds_read; the wait is the explicit vmcnt(0) at the top of each iteration.
+__device__ __forceinline__ void glds16_nt_asm(const void* gaddr, uint32_t lds_base) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" ::"v"(gaddr), "s"(lds_base) : "memory");
+}
+
+// Double-buffered form of srf_u16_kernel for 16-byte aligned cubes (the normal case).  A uint16 tile is
+// half the bytes of a float32 one, so with one tile per workgroup only ~73 KB per CU were in flight and the
+// kernel was latency-bound (0.169 ms).  Here every workgroup owns two tile buffers (2 x 36.5 KB, the LDS
+// footprint of the float32 kernel): the DMA of tile k+1 and its fit targets are issued right after the
+// barrier that publishes tile k and land while tile k is swept and reduced.  Two barriers per tile; the
+// closing barrier of the single-buffer kernel is not needed because nothing of tile k is overwritten before
+// the next top barrier.  Same arithmetic, same summation trees -> same bits as srf_u16_kernel.
+template <int DEG, bool OUTV>
+__global__ __launch_bounds__(512, 4) void srf_u16_ring_kernel(const SrfArgs a) {
+  constexpr int P = 64, T = 512;
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int B = a.B;
+  const int tile_bytes = P * B * 2;   // 128*B: whole 16-byte chunks
+  uint32_t* flags = reinterpret_cast<uint32_t*>(smem + 2 * (size_t)tile_bytes);   // [2][64]
+  const float* wl = reinterpret_cast<const float*>(flags + 128);
+  const bool wlds = a.wtaps > 0;
+  float* ostage = const_cast<float*>(wl) + a.wtaps;
+  const int ops = (int)a.out_ps;
+
+  const int t = threadIdx.x;
+  const int lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int pl = 2 * (lane & 31) + (lane >> 5), grp = wave;   // see srf_u16_kernel
+  const float scale = a.scale;
+  const uint32_t nd2 = (a.nodata & 0xffffu) * 0x00010001u;
+  const bool has_nodata = a.nodata <= 0xffffu;
+  const int nchunk_full = tile_bytes >> 4;
+
+  int bk0[kBandSlots], bkl[kBandSlots], bwo[kBandSlots], bidx[kBandSlots];
+  bool bval[kBandSlots];
+#pragma unroll
+  for (int j = 0; j < kBandSlots; ++j) {
+    const int b = a.bands.band_of[grp][j];
+    bval[j] = b >= 0;
+    bidx[j] = bval[j] ? b : 0;
+    bk0[j] = a.bands.k0[bidx[j]];
+    bkl[j] = bval[j] ? a.bands.klen[bidx[j]] : 0;
+    bwo[j] = a.bands.woff[bidx[j]];
+  }
+  if (wlds) {
+    float* wlw = const_cast<float*>(wl);
+    for (int b = 0; b < a.nb; ++b) {
+      const int kl = a.bands.klen[b];
+      for (int i = t; i < kl; i += T) wlw[a.bands.woff[b] + i] = a.wn[(size_t)b * B + a.bands.k0[b] + i];
+    }
+  }
+  constexpr int M = DEG > 0 ? moment_count(DEG) : 1;
+  double acc_m[kBandSlots][M];
+  if (DEG > 0) {
+#pragma unroll
+    for (int j = 0; j < kBandSlots; ++j)
+#pragma unroll
+      for (int m = 0; m < M; ++m) acc_m[j][m] = 0.0;
+  }
+  const uint16_t* cube = reinterpret_cast<const uint16_t*>(a.cube);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)(smem);
+
+  // prefetch of one tile: LDS-DMA of the samples (full tiles only; the ragged last tile is filled by hand when
+  // it is consumed) + the fit targets of this thread's pixel, all invisible to the compiler's waitcnt pass
+  float yn[kBandSlots] = {0.0f, 0.0f};
+  uint32_t mn = 1u;
+  auto prefetch = [&](int64_t tileidx, int buf) {
+    const int64_t pix0 = tileidx * P;
+    const int64_t left = a.npix - pix0;
+    if (left >= P) {
+      const char* srcb = reinterpret_cast<const char*>(cube + pix0 * B);
+      for (int c0 = wave * 64; c0 < nchunk_full; c0 += T) {
+        const int c = c0 + lane;
+        if (c < nchunk_full)
+          glds16_nt_asm(srcb + (size_t)c * 16, __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)buf * tile_bytes + (uint32_t)c0 * 16));
+      }
+    }
+    if (DEG > 0) {
+      const int64_t pc = pl < left ? pix0 + pl : a.npix - 1;
+#pragma unroll
+      for (int j = 0; j < kBandSlots; ++j) yn[j] = load_f32_async(a.real + bidx[j] * a.real_bs + pc * a.real_ps);
+      if (a.mask != nullptr) mn = load_u8_async(a.mask + pc);
+    }
+  };
+
+  int64_t tileidx = blockIdx.x;
+  if (tileidx < a.ntiles) prefetch(tileidx, 0);
+  int cur = 0;
+  int64_t prev_pix0 = 0;
+  int prev_npx = 0;
+  for (; tileidx < a.ntiles; tileidx += gridDim.x, cur ^= 1) {
+    const int64_t pix0 = tileidx * P;
+    const int64_t left = a.npix - pix0;
+    const int npx = left < P ? (int)left : P;
+    const bool pvalid = pl < npx;
+    const int nchunk = (npx * B + 7) >> 3;
+    uint16_t* tile = reinterpret_cast<uint16_t*>(smem + (size_t)cur * tile_bytes);
+    uint32_t* fl = flags + 64 * cur;
+
+    if (t < P) fl[t] = 0u;
+    // everything this wave issued one iteration ago has landed: tile k, its targets, the flush of tile k-2
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    float yv[kBandSlots];
+    uint32_t mraw;
+    static_assert(kBandSlots == 2, "pin list below");
+    asm volatile("" : "+v"(yn[0]), "+v"(yn[1]), "+v"(mn));
+    yv[0] = yn[0];
+    yv[1] = yn[1];
+    mraw = mn;
+    if (npx < P) {  // ragged last tile: plain copy, tail of the last chunk zeroed
+      const uint16_t* src = cube + pix0 * B;
+      const int n = npx * B;
+      for (int i = t; i < nchunk * 8; i += T) tile[i] = i < n ? src[i] : (uint16_t)0;
+    }
+    __syncthreads();   // tile k (every wave's share of the DMA) and the staged planes of tile k-1 are visible
+
+    const int64_t nxt = tileidx + gridDim.x;
+    if (nxt < a.ntiles) prefetch(nxt, cur ^ 1);   // buffer cur^1 was last read before the barrier above
+    if (OUTV) flush_stage<T>(ostage, a.out, prev_pix0, prev_npx, ops, t);
+
+    if (has_nodata) {
+      const uint4* t4 = reinterpret_cast<const uint4*>(tile);
+      for (int c0 = t; c0 < nchunk; c0 += T * kScanBatch) {
+        uint4 v[kScanBatch];
+#pragma unroll
+        for (int u = 0; u < kScanBatch; ++u) {
+          const int c = c0 + u * T;
+          v[u] = t4[c < nchunk ? c : nchunk - 1];
+        }
+        uint32_t hit = 0u;
+#pragma unroll
+        for (int u = 0; u < kScanBatch; ++u) {
+          const uint32_t w[4] = {v[u].x ^ nd2, v[u].y ^ nd2, v[u].z ^ nd2, v[u].w ^ nd2};
+#pragma unroll
+          for (int q = 0; q < 4; ++q) hit |= (w[q] - 0x00010001u) & ~w[q] & 0x80008000u;
+        }
+        if (hit) {  // rare
+#pragma unroll
+          for (int u = 0; u < kScanBatch; ++u) {
+            const int c = c0 + u * T;
+            const int e = (c < nchunk ? c : nchunk - 1) * 8;
+            const uint32_t w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              if ((w[q] & 0xffffu) == (a.nodata & 0xffffu) && e + 2 * q < npx * B) fl[(e + 2 * q) / B] = 1u;
+              if ((w[q] >> 16) == (a.nodata & 0xffffu) && e + 2 * q + 1 < npx * B) fl[(e + 2 * q + 1) / B] = 1u;
+            }
+          }
+        }
+      }
+    }
+    // flags of tile k complete; also orders the flush reads of the staged slab before the writes below
+    lds_barrier();
+
+    const bool bad = fl[pl] != 0u;
+#pragma unroll
+    for (int j = 0; j < kBandSlots; ++j) {
+      float acc = 0.0f;
+      if (wlds) {
+        const float4* w4 = reinterpret_cast<const float4*>(wl + bwo[j]);
+        const int e0 = pl * B + bk0[j];
+        const uint32_t sh = (uint32_t)(e0 & 1) * 2u;
+        const uint32_t* d32 = reinterpret_cast<const uint32_t*>(tile) + (e0 >> 1);
+        for (int i0 = 0; i0 < bkl[j]; i0 += kTapChunk) {
+          float4 ww[kTapChunk / 4];
+          uint32_t d[kTapChunk / 2 + 1];
+#pragma unroll
+          for (int u = 0; u < kTapChunk / 4; ++u) ww[u] = w4[(i0 >> 2) + u];
+#pragma unroll
+          for (int u = 0; u <= kTapChunk / 2; ++u) d[u] = d32[(i0 >> 1) + u];
+#pragma unroll
+          for (int u = 0; u < kTapChunk / 4; ++u) {
+            const uint32_t ea = __builtin_amdgcn_alignbyte(d[2 * u + 1], d[2 * u], sh);
+            const uint32_t eb = __builtin_amdgcn_alignbyte(d[2 * u + 2], d[2 * u + 1], sh);
+            acc = fmaf(ww[u].x, (float)(ea & 0xffffu) * scale, acc);
+            acc = fmaf(ww[u].y, (float)(ea >> 16) * scale, acc);
+            acc = fmaf(ww[u].z, (float)(eb & 0xffffu) * scale, acc);
+            acc = fmaf(ww[u].w, (float)(eb >> 16) * scale, acc);
+          }
+        }
+      } else {
+        const uint16_t* vs = tile + pl * B + bk0[j];
+        const float* ws = a.wn + (size_t)bidx[j] * B + bk0[j];
+        for (int i = 0; i < bkl[j]; ++i) acc = fmaf(ws[i], (float)vs[i] * scale, acc);
+      }
+      if (bad) acc = __uint_as_float(0x7fc00000u);
+      if (bval[j]) {
+        if (OUTV) ostage[pl * ops + bidx[j]] = acc;
+        else if (pvalid) st_stream(a.out + bidx[j] * a.out_bs + (pix0 + pl) * a.out_ps, acc);
+        if (DEG > 0) {
+          const float y = yv[j];
+          const bool ok = pvalid && mraw != 0u && finite_f32(acc) && finite_f32(y) && acc > a.min_x && y > a.min_y;
+          if (ok) {
+            const double xd = (double)acc, yd = (double)y;
+            acc_m[j][0] += 1.0;
+            acc_m[j][2 * DEG + 1] += yd;
+            double pw = 1.0;
+#pragma unroll
+            for (int k = 1; k <= 2 * DEG; ++k) {
+              pw *= xd;
+              acc_m[j][k] += pw;
+              if (k <= DEG) acc_m[j][2 * DEG + 1 + k] += pw * yd;
+            }
+          }
+        }
+      }
+    }
+    prev_pix0 = pix0;
+    prev_npx = npx;
+  }
+  if (OUTV) {
+    __syncthreads();
+    flush_stage<T>(ostage, a.out, prev_pix0, prev_npx, ops, t);
+  }
+
+  if (DEG > 0) {
+#pragma unroll
+    for (int j = 0; j < kBandSlots; ++j) {
+#pragma unroll
+      for (int m = 0; m < M; ++m) {
+        double sv = __shfl(acc_m[j][m], (lane >> 1) + 32 * (lane & 1), 64);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) sv += __shfl_xor(sv, off, 64);
+        if (bval[j] && lane == 0) a.partials[((size_t)bidx[j] * M + m) * a.slots + blockIdx.x] = sv;
+      }
+    }
+  }
+}
+
+template <int DEG, bool OUTV>
+static int launch_srf_u16_ring(const SrfArgs& a, hipStream_t stream) {
+  const size_t lds = (size_t)2 * 64 * a.B * 2 + 128 * sizeof(uint32_t) + (size_t)a.wtaps * 4 + (OUTV ? (size_t)64 * a.out_ps * 4 : 0);
+  auto kern = srf_u16_ring_kernel<DEG, OUTV>;
+  static thread_local size_t configured = 0;
+  if (lds > configured) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipGetLastError();
+    configured = lds;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.slots), dim3(512), lds, stream, a);
+  HSR_LAUNCH_CHECK("srf_u16_ring_kernel");
+  return HSR_OK;
+}
+
+template <int DEG, bool FAST, bool OUTV>
+static int launch_srf_u16(const SrfArgs& a, hipStream_t stream) {
+  const size_t lds = (size_t)64 * a.B * 2 + 64 * sizeof(uint32_t) + (size_t)a.wtaps * 4 + (OUTV ? (size_t)64 * a.out_ps * 4 : 0);
+  auto kern = srf_u16_kernel<DEG, FAST, OUTV>;
+  static thread_local size_t configured = 0;
+  if (lds > configured) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipGetLastError();
+    configured = lds;
+  }
+  hipLaunchKernelGGL(kern, dim3(a.slots), dim3(512), lds, stream, a);
+  HSR_LAUNCH_CHECK("srf_u16_kernel");
+  return HSR_OK;
+}
+
+template <int DEG>
+static int dispatch_u16_deg(const SrfArgs& a, bool fast, hipStream_t s) {
+  const bool outv = a.out_bs == 1 && (a.out_ps & 3) == 0 && a.out_ps <= HSR_MAX_BANDS && (((uintptr_t)a.out) & 15) == 0;
+  // two tile buffers must fit twice per CU next to the weights and the output slab: B <= ~300 spectral samples
+  const size_t ring_lds = (size_t)2 * 64 * a.B * 2 + 512 + (size_t)a.wtaps * 4 + (outv ? (size_t)64 * a.out_ps * 4 : 0);
+  if (fast && g_u16_ring && ring_lds <= 80 * 1024)
+    return outv ? launch_srf_u16_ring<DEG, true>(a, s) : launch_srf_u16_ring<DEG, false>(a, s);
+  if (outv) return fast ? launch_srf_u16<DEG, true, true>(a, s) : launch_srf_u16<DEG, false, true>(a, s);
+  return fast ? launch_srf_u16<DEG, true, false>(a, s) : launch_srf_u16<DEG, false, false>(a, s);
+}
+
+static int dispatch_u16(const SrfArgs& a, int deg, bool fast, hipStream_t s) {
+  switch (deg) {
+    case 0: return dispatch_u16_deg<0>(a, fast, s);
+    case 1: return dispatch_u16_deg<1>(a, fast, s);
+    case 2: return dispatch_u16_deg<2>(a, fast, s);
+    case 3: return dispatch_u16_deg<3>(a, fast, s);
+    case 4: return dispatch_u16_deg<4>(a, fast, s);
+  }
+  set_error("hsr_srf_integrate_moments_u16: deg=%d outside [1,%d]", deg, HSR_MAX_DEG);
+  return HSR_ERR_UNSUPPORTED;
+}
+
 template <int DEG, bool FAST, bool WLDS, int P, bool OUTV>
 static int launch_srf(const SrfArgs& a, hipStream_t stream) {
   const size_t lds = (size_t)P * a.ldsB * 4 + 64 * sizeof(uint32_t) + (WLDS ? (size_t)a.wtaps * 4 : 0) +
@@ -460,7 +974,8 @@ static int srf_common(SrfArgs& a, const int32_t* k0, const int32_t* klen, int32_
   HSR_REQUIRE((a.out_ps == 1 && a.out_bs >= a.npix) || (a.out_bs == 1 && a.out_ps >= a.nb), HSR_ERR_INVALID,
               "hsr_srf_integrate: output strides (%lld, %lld) are neither band-major nor pixel-major",
               (long long)a.out_bs, (long long)a.out_ps);
-  HSR_REQUIRE(((uintptr_t)a.cube & 3) == 0, HSR_ERR_INVALID, "hsr_srf_integrate: cube not 4-byte aligned");
+  HSR_REQUIRE(((uintptr_t)a.cube & (a.u16 ? 1 : 3)) == 0, HSR_ERR_INVALID, "hsr_srf_integrate: cube not %d-byte aligned",
+              a.u16 ? 2 : 4);
   for (int b = 0; b < a.nb; ++b) {
     HSR_REQUIRE(k0[b] >= 0 && klen[b] >= 0 && k0[b] + klen[b] <= a.B, HSR_ERR_INVALID,
                 "hsr_srf_integrate: support of band %d = [%d,%d) outside [0,%d)", b, k0[b], k0[b] + klen[b], a.B);
@@ -515,6 +1030,12 @@ static int srf_common(SrfArgs& a, const int32_t* k0, const int32_t* klen, int32_
     }
   }
   if (a.npix == 0) return HSR_OK;
+  if (a.u16) {  // 64-pixel tiles, two resident workgroups per CU
+    a.ntiles = (a.npix + 63) / 64;
+    const int64_t cap = (int64_t)(256 - g_reserved_cus) * 2;
+    a.slots = (int)(a.ntiles < cap ? a.ntiles : cap);
+    return dispatch_u16(a, deg, (((uintptr_t)a.cube & 15) == 0), stream);
+  }
   int P = g_tile_pixels;
   if (a.wtaps == 0) P = 64;  // the generic fallback kernel exists for 64-pixel tiles only
   a.ntiles = (a.npix + P - 1) / P;
@@ -534,6 +1055,11 @@ extern "C" int hsr_set_srf_tile(int32_t pixels) {
 }
 
 extern "C" int hsr_get_srf_tile(void) { return hsr::g_tile_pixels; }
+
+extern "C" int hsr_set_srf_u16_ring(int32_t on) {
+  hsr::g_u16_ring = on != 0;
+  return HSR_OK;
+}
 
 extern "C" int hsr_set_srf_reserved_cus(int32_t cus) {
   HSR_REQUIRE(cus >= 0 && cus <= 128, HSR_ERR_INVALID, "hsr_set_srf_reserved_cus: %d outside [0,128]", cus);
@@ -570,6 +1096,63 @@ extern "C" int hsr_srf_integrate_moments(const float* cube_dev, int64_t npix, in
   HSR_REQUIRE(npix > 0, HSR_ERR_INVALID, "hsr_srf_integrate_moments: npix must be > 0");
   hsr::SrfArgs a{};
   a.cube = cube_dev;
+  a.npix = npix;
+  a.B = B;
+  a.wn = wn_dev;
+  a.nb = nb;
+  a.out = out_dev;
+  a.out_bs = out_bs;
+  a.out_ps = out_ps;
+  a.real = real_dev;
+  a.real_bs = real_bs;
+  a.real_ps = real_ps;
+  a.mask = mask_dev;
+  a.min_x = min_x;
+  a.min_y = min_y;
+  a.partials = partials_dev;
+  int rc = hsr::srf_common(a, k0, klen, deg, (hipStream_t)stream);
+  if (rc == HSR_OK && slots_out) *slots_out = a.slots;
+  return rc;
+}
+
+extern "C" int hsr_srf_integrate_u16(const uint16_t* cube_dev, int64_t npix, int32_t B, float scale, int32_t nodata,
+                                     const float* wn_dev, const int32_t* k0, const int32_t* klen, int32_t nb,
+                                     float* out_dev, int64_t out_bs, int64_t out_ps, hsr_stream_t stream) {
+  HSR_REQUIRE(nodata <= 0xffff, HSR_ERR_INVALID, "hsr_srf_integrate_u16: nodata=%d is not a uint16 value (negative = none)", nodata);
+  hsr::SrfArgs a{};
+  a.cube = reinterpret_cast<const float*>(cube_dev);
+  a.u16 = 1;
+  a.scale = scale;
+  a.nodata = nodata < 0 ? 0x10000u : (uint32_t)nodata;
+  a.npix = npix;
+  a.B = B;
+  a.wn = wn_dev;
+  a.nb = nb;
+  a.out = out_dev;
+  a.out_bs = out_bs;
+  a.out_ps = out_ps;
+  return hsr::srf_common(a, k0, klen, 0, (hipStream_t)stream);
+}
+
+extern "C" int hsr_srf_integrate_moments_u16(const uint16_t* cube_dev, int64_t npix, int32_t B, float scale,
+                                             int32_t nodata, const float* wn_dev, const int32_t* k0,
+                                             const int32_t* klen, int32_t nb, float* out_dev, int64_t out_bs,
+                                             int64_t out_ps, const float* real_dev, int64_t real_bs, int64_t real_ps,
+                                             const uint8_t* mask_dev, float min_x, float min_y, int32_t deg,
+                                             double* partials_dev, int32_t* slots_out, hsr_stream_t stream) {
+  HSR_REQUIRE(deg >= 1 && deg <= HSR_MAX_DEG, HSR_ERR_UNSUPPORTED, "hsr_srf_integrate_moments_u16: deg=%d outside [1,%d]",
+              deg, HSR_MAX_DEG);
+  HSR_REQUIRE(real_dev && partials_dev, HSR_ERR_INVALID, "hsr_srf_integrate_moments_u16: NULL pointer");
+  HSR_REQUIRE((real_ps == 1 && real_bs >= npix) || (real_bs == 1 && real_ps >= nb), HSR_ERR_INVALID,
+              "hsr_srf_integrate_moments_u16: real strides (%lld, %lld) are neither band-major nor pixel-major",
+              (long long)real_bs, (long long)real_ps);
+  HSR_REQUIRE(npix > 0, HSR_ERR_INVALID, "hsr_srf_integrate_moments_u16: npix must be > 0");
+  HSR_REQUIRE(nodata <= 0xffff, HSR_ERR_INVALID, "hsr_srf_integrate_moments_u16: nodata=%d is not a uint16 value (negative = none)", nodata);
+  hsr::SrfArgs a{};
+  a.cube = reinterpret_cast<const float*>(cube_dev);
+  a.u16 = 1;
+  a.scale = scale;
+  a.nodata = nodata < 0 ? 0x10000u : (uint32_t)nodata;
   a.npix = npix;
   a.B = B;
   a.wn = wn_dev;

@@ -136,9 +136,46 @@ def build_srf_table(emit_w, srf_dict, good_mask=None) -> SrfTable:
 # ---------------------------------------------------------------------------------------------
 def _as_cube2d(cube):
     torch = nat.require_gpu()
-    if not (cube.is_cuda and cube.dtype == torch.float32 and cube.is_contiguous()):
-        raise ValueError("cube must be a contiguous float32 tensor on the GPU")
+    if not (cube.is_cuda and cube.dtype in (torch.float32, torch.uint16) and cube.is_contiguous()):
+        raise ValueError("cube must be a contiguous float32 (or uint16 tile) tensor on the GPU")
     return cube.reshape(-1, cube.shape[-1])
+
+
+# uint16 tiles (reference writer tiles_helpers/utils.py:309-318,362-374)
+TILE_SCALE = 10000.0         # emit_scale: reflectance -> uint16
+TILE_NODATA = 65535          # emit_nodata_u16
+
+
+def _decode_scale(scale) -> float:
+    """Decode factor as the consumers use it: float32(1/emit_scale) = the notebook's s2_scale=1e-4."""
+    return float(np.float32(1.0 / TILE_SCALE)) if scale is None else float(np.float32(scale))
+
+
+def tile_encode_u16(x, scale: float = TILE_SCALE, src_nodata=None, nodata_u16: int = TILE_NODATA):
+    """float32 GPU tensor (any shape) -> uint16 tile samples exactly as the reference's tile writer
+    quantises them (tiles_helpers/utils.py:362-374): round-half-even of the float32 product, clip to
+    [0, nodata_u16-1], non-finite / source-nodata samples -> nodata_u16."""
+    torch = nat.require_gpu()
+    lib = nat.load()
+    if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()):
+        raise ValueError("x must be a contiguous float32 tensor on the GPU")
+    out = torch.empty(x.shape, dtype=torch.uint16, device=x.device)
+    nat.check(lib.hsr_tile_encode_u16(_ptr(x), x.numel(), float(scale), int(src_nodata is not None),
+                                      float(src_nodata) if src_nodata is not None else 0.0, int(nodata_u16),
+                                      _ptr(out), _stream(torch)), "hsr_tile_encode_u16")
+    return out
+
+
+def tile_decode_u16(u, scale=None, nodata: Optional[int] = TILE_NODATA):
+    """uint16 GPU tensor -> float32: float32(u) * float32(scale) (default 1e-4), nodata -> NaN."""
+    torch = nat.require_gpu()
+    lib = nat.load()
+    if not (u.is_cuda and u.dtype == torch.uint16 and u.is_contiguous()):
+        raise ValueError("u must be a contiguous uint16 tensor on the GPU")
+    out = torch.empty(u.shape, dtype=torch.float32, device=u.device)
+    nat.check(lib.hsr_tile_decode_u16(_ptr(u), u.numel(), _decode_scale(scale), -1 if nodata is None else int(nodata),
+                                      _ptr(out), _stream(torch)), "hsr_tile_decode_u16")
+    return out
 
 
 def _i32arr(a):
@@ -146,8 +183,10 @@ def _i32arr(a):
     return a, a.ctypes.data_as(C.POINTER(C.c_int32))
 
 
-def srf_integrate(cube, table: SrfTable, out=None, layout: str = PLANAR):
-    """K1.  cube (..., B) float32 on the GPU -> pseudo-S2 image in ``layout`` (float32)."""
+def srf_integrate(cube, table: SrfTable, out=None, layout: str = PLANAR, scale=None, nodata: Optional[int] = TILE_NODATA):
+    """K1.  cube (..., B) float32 on the GPU -> pseudo-S2 image in ``layout`` (float32).
+    A uint16 cube is taken as a tile in the reference's storage format and decoded inside the kernel
+    (``scale`` default 1e-4, ``nodata`` default 65535, None = no nodata value)."""
     torch = nat.require_gpu()
     lib = nat.load()
     c2 = _as_cube2d(cube)
@@ -163,8 +202,13 @@ def srf_integrate(cube, table: SrfTable, out=None, layout: str = PLANAR):
         k0a, k0p = _i32arr(table.k0[b0:b1])              # keep the arrays alive across the call
         kla, klp = _i32arr(table.klen[b0:b1])
         dst = img[b0:b1] if layout == PLANAR else img[:, b0:]
-        nat.check(lib.hsr_srf_integrate(_ptr(c2), npix, B, _ptr(wn[b0:b1]), k0p, klp, b1 - b0,
-                                        _ptr(dst), bs, ps, _stream(torch)), "hsr_srf_integrate")
+        if c2.dtype == torch.uint16:
+            nat.check(lib.hsr_srf_integrate_u16(_ptr(c2), npix, B, _decode_scale(scale), -1 if nodata is None else int(nodata),
+                                                _ptr(wn[b0:b1]), k0p, klp, b1 - b0, _ptr(dst), bs, ps, _stream(torch)),
+                      "hsr_srf_integrate_u16")
+        else:
+            nat.check(lib.hsr_srf_integrate(_ptr(c2), npix, B, _ptr(wn[b0:b1]), k0p, klp, b1 - b0,
+                                            _ptr(dst), bs, ps, _stream(torch)), "hsr_srf_integrate")
     return img
 
 
@@ -185,8 +229,10 @@ class MomentWorkspace:
 
 def srf_integrate_moments(cube, table: SrfTable, real, deg: int, ws: MomentWorkspace, mask=None,
                           min_x=_NEG_INF, min_y=_NEG_INF, out=None, events=None, reduce=True,
-                          layout: str = PIXMAJOR, real_layout: Optional[str] = None):
+                          layout: str = PIXMAJOR, real_layout: Optional[str] = None, scale=None,
+                          nodata: Optional[int] = TILE_NODATA):
     """K1+K2 fused: pseudo-S2 image and the per-band Vandermonde moments in one cube pass.
+    A uint16 cube is decoded inside the kernel (see srf_integrate).
     ``real``: real-S2 image in ``real_layout`` (default: same as ``layout``).
     ``events``: optional (start, stop) torch.cuda.Event pair recorded on the launch stream right
     around the fused kernel (bench.py's live roofline measurement)."""
@@ -212,10 +258,17 @@ def srf_integrate_moments(cube, table: SrfTable, real, deg: int, ws: MomentWorks
     slots = C.c_int32(0)
     if events is not None:
         events[0].record()
-    nat.check(lib.hsr_srf_integrate_moments(_ptr(c2), npix, B, _ptr(wn), k0p, klp, nb, _ptr(img), bs, ps,
-                                            _ptr(real), rbs, rps, _ptr(mask), min_x, min_y, deg,
-                                            _ptr(ws.partials), C.byref(slots), _stream(torch)),
-              "hsr_srf_integrate_moments")
+    if c2.dtype == torch.uint16:
+        nat.check(lib.hsr_srf_integrate_moments_u16(_ptr(c2), npix, B, _decode_scale(scale),
+                                                    -1 if nodata is None else int(nodata), _ptr(wn), k0p, klp, nb,
+                                                    _ptr(img), bs, ps, _ptr(real), rbs, rps, _ptr(mask), min_x, min_y,
+                                                    deg, _ptr(ws.partials), C.byref(slots), _stream(torch)),
+                  "hsr_srf_integrate_moments_u16")
+    else:
+        nat.check(lib.hsr_srf_integrate_moments(_ptr(c2), npix, B, _ptr(wn), k0p, klp, nb, _ptr(img), bs, ps,
+                                                _ptr(real), rbs, rps, _ptr(mask), min_x, min_y, deg,
+                                                _ptr(ws.partials), C.byref(slots), _stream(torch)),
+                  "hsr_srf_integrate_moments")
     if events is not None:
         events[1].record()
     ws.slots = slots.value

@@ -59,6 +59,14 @@ SIGNATURES = {
     "hsr_percentile_hist_region": (C.c_int, [_i32, _i32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "hsr_percentile_hist": (C.c_int, [_i32, _vp, _i64, _i64, _vp, _i64, _i32, _vp, _vp]),
     "hsr_percentile_scan": (C.c_int, [_i32, _i32, _f64, _f64, _vp, _vp, _vp]),
+    "hsr_set_srf_u16_ring": (C.c_int, [_i32]),
+    "hsr_tile_encode_u16": (C.c_int, [_vp, _i64, _f32, _i32, _f32, _i32, _vp, _vp]),
+    "hsr_tile_decode_u16": (C.c_int, [_vp, _i64, _f32, _i32, _vp, _vp]),
+    "hsr_srf_integrate_u16": (C.c_int, [_vp, _i64, _i32, _f32, _i32, _vp, C.POINTER(_i32), C.POINTER(_i32), _i32,
+                                        _vp, _i64, _i64, _vp]),
+    "hsr_srf_integrate_moments_u16": (C.c_int, [_vp, _i64, _i32, _f32, _i32, _vp, C.POINTER(_i32), C.POINTER(_i32),
+                                                _i32, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _f32, _f32, _i32, _vp,
+                                                C.POINTER(_i32), _vp]),
     "hsr_valid_mask": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp]),
     "hsr_polyfeat_count": (C.c_int, [_i32, _i32]),
     "hsr_polyfeat_table": (C.c_int, [_i32, _i32, _vp]),

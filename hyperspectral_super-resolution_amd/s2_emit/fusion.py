@@ -80,8 +80,11 @@ class SpectralFusion:
     def __init__(self, emit_w, srf_dict, good_mask=None, deg: int = 3, min_valid: Optional[float] = 0.0,
                  min_count: int = 50, clip: bool = True, apply_mask: bool = False, device=None,
                  group=None, coeff_sync: str = "allreduce", layout: str = nat.PIXMAJOR,
-                 force_exchange: bool = False):
+                 force_exchange: bool = False, tile_scale=None, tile_nodata: Optional[int] = eng.TILE_NODATA):
         torch = nat.require_gpu()
+        # decode of uint16 cubes (the reference's tile format, tiles_helpers/utils.py:362-374): x = u * tile_scale
+        # (default float32(1e-4)), u == tile_nodata -> NaN (None: no nodata value).  Ignored for float32 cubes.
+        self.tile_scale, self.tile_nodata = tile_scale, tile_nodata
         if not 1 <= deg <= nat.HSR_MAX_DEG:
             raise ValueError(f"deg must be in [1, {nat.HSR_MAX_DEG}], got {deg}")
         if coeff_sync not in COEFF_SYNC_MODES:
@@ -153,7 +156,8 @@ class SpectralFusion:
             pseudo = matched = None
         pseudo, _ = eng.srf_integrate_moments(cube, self.table, real, self.deg, self.ws, mask,
                                               self.min_valid, self.min_valid, out=pseudo, events=k1_events,
-                                              reduce=False, layout=self.layout, real_layout=real_layout)
+                                              reduce=False, layout=self.layout, real_layout=real_layout,
+                                              scale=self.tile_scale, nodata=self.tile_nodata)
         if self._exchanges():
             moments = eng.moments_reduce(self.ws)
             moments, coeffs = exchange_moments(moments, self._solve, self.group, self.coeff_sync)
@@ -206,7 +210,7 @@ class SpectralFusion:
             main.wait_event(slot["ev_done"])        # the tail that last read this buffer set (tile i-2)
         eng.srf_integrate_moments(cube, self.table, real, self.deg, ws, mask, self.min_valid, self.min_valid,
                                   out=slot["pseudo"], events=k1_events, reduce=False, layout=self.layout,
-                                  real_layout=real_layout)
+                                  real_layout=real_layout, scale=self.tile_scale, nodata=self.tile_nodata)
         slot["ev_k1"].record(main)
         with torch.cuda.stream(st["side"]):
             st["side"].wait_event(slot["ev_k1"])

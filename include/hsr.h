@@ -164,6 +164,35 @@ int hsr_percentile_hist(int32_t pass, const float* x_dev, int64_t x_bs, int64_t 
 int hsr_percentile_scan(int32_t pass, int32_t nb, double pmin, double pmax, void* work_dev, double* lohi_dev,
                         hsr_stream_t stream);
 
+/* ---- uint16 tiles -------------------------------------------------------------------------
+ * The training tile pairs are stored as uint16 reflectance x emit_scale (10000) with 65535 as nodata
+ * (reference writer: tiles_helpers/utils.py:309-318 defaults, :362-374 arithmetic).
+ *
+ * hsr_tile_encode_u16 replaces utils.py:362-374 on n float32 samples (any layout, elementwise):
+ *   valid = isfinite(x) && !(has_src_nodata && x == src_nodata);
+ *   out   = valid ? clip(int32(rint(x * scale)), 0, nodata_u16 - 1) : nodata_u16          [bit-exact]
+ * hsr_tile_decode_u16 is the consumers' convention (Pairs_EMIT_S2_demo-2.ipynb cell 65, `out *= float(scale)`
+ * on float32): out = u == nodata ? NaN : float32(u) * scale; nodata < 0: no nodata value.
+ * hsr_srf_integrate[_moments]_u16: K1 (+K2) directly on an (npix, B) uint16 cube - the LDS-DMA moves the
+ * 2-byte samples (half the HBM bytes of the float32 cube) and the decode happens on the way out of LDS.
+ * Planes and partial moments are bit-identical to hsr_tile_decode_u16 followed by the float32 entry points;
+ * a pixel with a nodata sample is NaN in every band (0 * NaN), exactly as the two-step path.  Other
+ * arguments as hsr_srf_integrate / hsr_srf_integrate_moments. */
+int hsr_set_srf_u16_ring(int32_t on);  /* tuning switch: 1 (default) double-buffered uint16 K1, 0 single buffer */
+int hsr_tile_encode_u16(const float* x_dev, int64_t n, float scale, int32_t has_src_nodata, float src_nodata,
+                        int32_t nodata_u16, uint16_t* out_dev, hsr_stream_t stream);
+int hsr_tile_decode_u16(const uint16_t* u_dev, int64_t n, float scale, int32_t nodata, float* out_dev,
+                        hsr_stream_t stream);
+int hsr_srf_integrate_u16(const uint16_t* cube_dev, int64_t npix, int32_t B, float scale, int32_t nodata,
+                          const float* wn_dev, const int32_t* k0, const int32_t* klen, int32_t nb, float* out_dev,
+                          int64_t out_bs, int64_t out_ps, hsr_stream_t stream);
+int hsr_srf_integrate_moments_u16(const uint16_t* cube_dev, int64_t npix, int32_t B, float scale, int32_t nodata,
+                                  const float* wn_dev, const int32_t* k0, const int32_t* klen, int32_t nb,
+                                  float* out_dev, int64_t out_bs, int64_t out_ps, const float* real_dev,
+                                  int64_t real_bs, int64_t real_ps, const uint8_t* mask_dev, float min_x,
+                                  float min_y, int32_t deg, double* partials_dev, int32_t* slots_out,
+                                  hsr_stream_t stream);
+
 /* Validity mask of the pipeline (poly_regression.py:106,118): mask[p] = all bands of x finite
  * && x[pos_band][p] > 0 (pos_band < 0: skip) && all bands of y finite (y_dev may be NULL),
  * optionally AND-ed with mask_in_dev. */

@@ -452,6 +452,41 @@ def bilinear_upsample(planes, factor: int):
     return (top * (1 - tr)[None, :, None] + bot * tr[None, :, None]).astype(np.float32)
 
 
+# ---------------------------------------------------------------------------------------------
+# uint16 tile format
+# ---------------------------------------------------------------------------------------------
+def tile_encode_u16(emit_tile, src_nodata=None, emit_scale=10000.0, emit_nodata_u16=65535) -> np.ndarray:
+    """Quantisation of an EMIT tile as the reference writer does it (tiles_helpers/utils.py:362-374):
+    float32 product, round half to even, int32 cast (x86 semantics for out-of-range values), clip to
+    [0, nodata-1]; non-finite / source-nodata samples -> nodata.  Pinned by tests/golden/g10_tile_u16.npz."""
+    emit = np.asarray(emit_tile).astype(np.float32)
+    valid = np.isfinite(emit)
+    if src_nodata is not None:
+        valid &= emit != src_nodata
+    with np.errstate(invalid="ignore", over="ignore"):
+        r = np.rint(emit * np.float32(emit_scale))
+        inrange = (r >= -2147483648.0) & (r < 2147483648.0)          # NaN compares False
+        q = np.where(inrange, r, 0.0).astype(np.int64)
+    q = np.where(inrange, q, np.iinfo(np.int32).min)                 # cvttss2si "integer indefinite"
+    q = np.clip(q, 0, int(emit_nodata_u16) - 1)
+    out = np.full(emit.shape, int(emit_nodata_u16), dtype=np.uint16)
+    out[valid] = q[valid].astype(np.uint16)
+    return out
+
+
+def tile_decode_u16(u16, scale=None, nodata=65535) -> np.ndarray:
+    """uint16 tile -> float32 reflectance, the consumers' convention (Pairs_EMIT_S2_demo-2.ipynb cell 65:
+    ``out *= float(s2_scale)`` on a float32 array, s2_scale = 1e-4): float32(u) * float32(scale);
+    nodata samples become NaN (they are excluded by every validity mask downstream).  The reference has no
+    decoder of its own for the EMIT tiles: this convention is the documented one, parity unpinned."""
+    u = np.asarray(u16)
+    sc = np.float32(1e-4) if scale is None else np.float32(scale)
+    out = u.astype(np.float32) * sc
+    if nodata is not None:
+        out[u == nodata] = np.nan
+    return out
+
+
 def match_pair_reference(R, emit_w, srf_dict, good_mask, s2_rgb_hi, factor=6, deg=4, use_ot=True,
                          n_samples=5000, reg=0.05, numItermax=300, stopThr=1e-6, seed=0, src_scale=1.0 / 255.0):
     """poly_regression.py:96-172 on in-memory aligned arrays, statement by statement; the two GDAL warps

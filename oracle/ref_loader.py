@@ -15,6 +15,9 @@ How:
     top-level function definitions (lines 16-62 and 65-84) are selected from the parsed AST and
     executed with ``np`` in scope.
   * notebook helpers are executed from the cell source stored in the .ipynb JSON.
+  * ``tiles_helpers/utils.py:save_tile_pair`` does rasterio I/O around seven statements of array
+    arithmetic (lines 362-374, the uint16 quantisation of an EMIT tile); those statements are
+    selected from the function's AST by the names they assign and executed on in-memory arrays.
 """
 from __future__ import annotations
 
@@ -102,3 +105,44 @@ def load_spectral_matching_functions():
         "legacy_notebooks/Spectral_matching.ipynb",
         ["subsample_bands_evenly", "flatten_pixels", "logit", "sigmoid", "predict_cube_logit"],
     )
+
+
+def load_tile_quantiser():
+    """The uint16 tile quantisation of tiles_helpers/utils.py:362-374 as a callable
+    ``q(emit_tile, src_nodata=None, emit_scale=10000.0, emit_nodata_u16=65535) -> uint16 array``.
+    The statements run from the reference file itself (none of its text is stored here)."""
+    path = os.path.join(REFERENCE_ROOT, "tiles_helpers", "utils.py")
+    tree = ast.parse(open(path).read(), filename=path)
+    fn = next(n for n in ast.walk(tree) if isinstance(n, ast.FunctionDef) and n.name == "save_tile_pair")
+    wanted = {"emit", "valid", "scaled_i32", "emit_u16"}
+
+    def assigned(node):
+        out = set()
+        tgts = node.targets if isinstance(node, ast.Assign) else [node.target] if isinstance(node, ast.AugAssign) else []
+        for t in tgts:
+            while isinstance(t, ast.Subscript):
+                t = t.value
+            if isinstance(t, ast.Name):
+                out.add(t.id)
+        return out
+
+    stmts = []
+    for w in (n for n in ast.walk(fn) if isinstance(n, ast.With)):
+        for st in w.body:
+            if isinstance(st, (ast.Assign, ast.AugAssign)) and assigned(st) and assigned(st) <= wanted:
+                stmts.append(st)
+            elif isinstance(st, ast.If) and all(isinstance(b, ast.AugAssign) and assigned(b) <= {"valid"} for b in st.body):
+                stmts.append(st)
+        if stmts:
+            break
+    if len(stmts) < 6:
+        raise RuntimeError("save_tile_pair: quantisation statements not found (reference changed?)")
+    code = compile(ast.Module(body=stmts, type_ignores=[]), path, "exec")
+
+    def quantise(emit_tile, src_nodata=None, emit_scale=10000.0, emit_nodata_u16=65535):
+        ns = {"np": np, "emit_tile": emit_tile, "emit_ds": types.SimpleNamespace(nodata=src_nodata),
+              "emit_scale": emit_scale, "emit_nodata_u16": emit_nodata_u16}
+        exec(code, ns)
+        return ns["emit_u16"]
+
+    return quantise

@@ -232,6 +232,21 @@ def main():
          coeffs_deg4=poly["fit_ot_poly_rgb"](a, b, m9, deg=4),
          coeffs_nan_deg3=poly["fit_ot_poly_rgb"](a_nan, b, m9b, deg=3))
 
+    # ---- G10: uint16 tile quantisation (tiles_helpers/utils.py:362-374, executed from the reference file) ------
+    quant = ref_loader.load_tile_quantiser()
+    rng = np.random.default_rng(10)
+    t = np.clip(rng.normal(0.15, 0.12, (5, 12, 11)), -0.01, 0.7).astype(np.float32)
+    # exact .5 ties in float32 after the product, band-fill / nodata values, range ends, non-finite samples
+    specials = np.array([0.00005, 0.00015, 0.00025, 0.00035, 1.22075, 6.5534, 6.55345, 6.5535, 7.0, 100.0, -0.01,
+                         -0.00004, -9999.0, 3.0e5, 1.0e30, -1.0e30, 2.14748e5, 2.147484e5, np.inf, -np.inf, np.nan, 0.0],
+                        dtype=np.float32)
+    t.reshape(-1)[: specials.size] = specials
+    t[3, 5, :] = np.nan
+    t[1, 2, 3] = -9999.0
+    with np.errstate(invalid="ignore"):
+        save("g10_tile_u16", tile=t, u16_plain=quant(t), u16_srcnodata=quant(t, src_nodata=-9999.0),
+             u16_scale2000_nd4095=quant(t, src_nodata=None, emit_scale=2000.0, emit_nodata_u16=4095))
+
 
 if __name__ == "__main__":
     main()

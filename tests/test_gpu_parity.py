@@ -879,3 +879,129 @@ def test_global_percentiles_across_simulated_ranks(torch_gpu):
     a = eng.percentile_limits(xs[0], ms[0], 5, 95).cpu().numpy()
     b = eng.percentile_limits(xs[0], ms[0], 5, 95, _reduce=lambda p, region: None).cpu().numpy()
     np.testing.assert_array_equal(a, b)
+
+
+# ---------------------------------------------------------------------------------------------
+# uint16 tiles: writer quantisation bit-exact, K1 on the 2-byte cube
+# ---------------------------------------------------------------------------------------------
+def test_tile_u16_codec_bitexact(torch_gpu):
+    torch = torch_gpu
+    from s2_emit import _engine as eng
+    g = load_golden("g10_tile_u16")
+    t = torch.from_numpy(g["tile"]).cuda()
+    np.testing.assert_array_equal(eng.tile_encode_u16(t).cpu().numpy(), g["u16_plain"])
+    np.testing.assert_array_equal(eng.tile_encode_u16(t, src_nodata=-9999.0).cpu().numpy(), g["u16_srcnodata"])
+    np.testing.assert_array_equal(eng.tile_encode_u16(t, 2000.0, None, 4095).cpu().numpy(), g["u16_scale2000_nd4095"])
+    # a big random array with every float32 exponent, the specials sprinkled in, odd length and an odd offset
+    rng = np.random.default_rng(77)
+    x = (rng.standard_normal(1_000_003) * np.exp(rng.uniform(-12, 25, 1_000_003))).astype(np.float32)
+    x[::1013] = np.nan
+    x[5::4099] = -9999.0
+    x[7::5003] = np.inf
+    ties = (rng.integers(0, 70000, 50000) + 0.5) / 10000.0
+    x[100:100 + ties.size] = ties.astype(np.float32)
+    xd = torch.from_numpy(x).cuda()
+    with np.errstate(all="ignore"):
+        ref = onp.tile_encode_u16(x, src_nodata=-9999.0)
+    np.testing.assert_array_equal(eng.tile_encode_u16(xd, src_nodata=-9999.0).cpu().numpy(), ref)
+    np.testing.assert_array_equal(eng.tile_encode_u16(xd[1:].clone()[2:], src_nodata=-9999.0).cpu().numpy(), ref[3:])   # 8-byte offset: scalar path
+    np.testing.assert_array_equal(eng.tile_encode_u16(xd[1:1000].contiguous()).cpu().numpy(), onp.tile_encode_u16(x[1:1000]))
+    # decode: all 65536 codes, bit-exact against float32(u) * float32(1e-4), NaN at nodata
+    codes = np.arange(65536, dtype=np.uint16)
+    dec = eng.tile_decode_u16(torch.from_numpy(codes).cuda()).cpu().numpy()
+    np.testing.assert_array_equal(dec.view(np.uint32)[:-1], onp.tile_decode_u16(codes).view(np.uint32)[:-1])
+    assert np.isnan(dec[-1])
+    dec2 = eng.tile_decode_u16(torch.from_numpy(codes[3:60001]).cuda().clone(), scale=0.5e-3, nodata=None).cpu().numpy()
+    np.testing.assert_array_equal(dec2, onp.tile_decode_u16(codes[3:60001], 0.5e-3, None))
+    assert eng.tile_encode_u16(torch.empty(0, device="cuda")).numel() == 0
+
+
+@pytest.mark.parametrize("npix,B,offset,nodata_mode", [(64 * 40, 285, 0, "some"), (64 * 7 + 13, 285, 0, "some"),
+                                                       (1000, 285, 1, "some"), (640, 284, 0, "none"),
+                                                       (64 * 9, 285, 0, "off"), (5, 285, 0, "some"), (4096, 64, 0, "some")])
+def test_k1_on_u16_tiles_matches_decode_then_k1_bits(torch_gpu, npix, B, offset, nodata_mode):
+    """K1(+K2) on the uint16 cube == hsr_tile_decode_u16 followed by the float32 K1, bit for bit, on the
+    DMA path, the ragged last tile, a 2-byte-misaligned cube, an even band count and without nodata."""
+    torch = torch_gpu
+    from s2_emit import _engine as eng
+    srf = onp.synthetic_srf()
+    w, good = onp.synthetic_wavelengths(B) if B == 285 else (np.linspace(400, 2400, B).astype(np.float32), None)
+    table = eng.build_srf_table(w, srf, good)
+    nb = table.nb
+    rng = np.random.default_rng(npix + B)
+    u = rng.integers(0, 6000, (npix, B)).astype(np.uint16)
+    nodata = 65535
+    if nodata_mode == "some":
+        u[rng.integers(0, npix, max(1, npix // 50)), rng.integers(0, B, max(1, npix // 50))] = 65535
+        u[npix - 1, B - 1] = 65535
+        u[0, 0] = 65535
+    elif nodata_mode == "off":
+        u[3, 7] = 65535           # just a large sample when no nodata value is set
+        nodata = None
+    flat = torch.from_numpy(np.concatenate([np.zeros(offset, np.uint16), u.reshape(-1)])).cuda()
+    ud = flat[offset:].view(npix, B) if offset == 0 else torch.as_strided(flat, (npix, B), (B, 1), offset)
+    assert ud.is_contiguous() and ud.data_ptr() % 16 == (2 * offset) % 16
+    f = eng.tile_decode_u16(ud.clone(), nodata=nodata)
+    np.testing.assert_array_equal(f.cpu().numpy(), onp.tile_decode_u16(u, None, nodata))
+    for layout in ("planar", "pixmajor"):
+        a = eng.srf_integrate(ud, table, layout=layout, nodata=nodata)
+        b = eng.srf_integrate(f, table, layout=layout)
+        if layout == "pixmajor":          # rows are padded to a multiple of 4 floats; the padding is not written
+            a, b = a[:, :nb], b[:, :nb]
+        np.testing.assert_array_equal(a.cpu().numpy(), b.cpu().numpy())       # NaN == NaN here
+        fin = torch.isfinite(b)
+        assert torch.equal(a[fin].view(torch.int32), b[fin].view(torch.int32))
+    planes = eng.srf_integrate(f, table, layout="planar")
+    if nodata_mode == "some":
+        bad = (u == 65535).any(axis=1)
+        assert bool(torch.isnan(planes[:, torch.from_numpy(bad).cuda()]).all())
+        assert bool(torch.isfinite(planes[:, torch.from_numpy(~bad).cuda()]).all())
+    # fused moments: same partial sums, same coefficients
+    real = (torch.nan_to_num(planes, nan=0.1) * 1.1 + 0.01 + 0.01 * torch.randn_like(planes)).contiguous()
+    mask = torch.from_numpy((rng.random(npix) > 0.2).astype(np.uint8)).cuda()
+    for deg in (1, 3):
+        ws_a, ws_b = eng.MomentWorkspace("cuda", nb, deg), eng.MomentWorkspace("cuda", nb, deg)
+        pa, ma = eng.srf_integrate_moments(ud, table, real, deg, ws_a, mask, 0.0, 0.0, layout="pixmajor",
+                                           real_layout="planar", nodata=nodata)
+        pb, mb = eng.srf_integrate_moments(f, table, real, deg, ws_b, mask, 0.0, 0.0, layout="pixmajor", real_layout="planar")
+        np.testing.assert_array_equal(pa[:, :nb].cpu().numpy(), pb[:, :nb].cpu().numpy())
+        if (npix + 63) // 64 <= 512:          # same tile -> slot assignment in both kernels
+            assert torch.equal(ma, mb)
+        else:
+            np.testing.assert_allclose(ma.cpu().numpy(), mb.cpu().numpy(), rtol=1e-12)
+        assert ma[0, 0].item() > 0 or npix < 10
+
+
+def test_fused_step_on_u16_cube(torch_gpu):
+    """The whole hot path fed with the reference's on-disk tile format: encode (writer semantics) on the
+    device, then SpectralFusion.step on the uint16 cube == step on the decoded float32 cube."""
+    torch = torch_gpu
+    from s2_emit import SpectralFusion, _engine as eng
+    srf = onp.synthetic_srf()
+    w, good = onp.synthetic_wavelengths()
+    H, W = 96, 80
+    R = onp.synthetic_cube(H, W, seed=21)
+    R[5, 6, 100] = np.nan                       # -> nodata code -> pixel NaN in every band
+    R[9, 9, :] = -0.01                          # EMIT's masked-band fill clips to 0
+    cube_f = torch.from_numpy(R).cuda()
+    u = eng.tile_encode_u16(cube_f)
+    np.testing.assert_array_equal(u.cpu().numpy(), onp.tile_encode_u16(R))
+    dec = eng.tile_decode_u16(u)
+    ps = onp.pseudo_s2_srf_integral(onp.tile_decode_u16(onp.tile_encode_u16(R)), w, srf, good)
+    names = [k for k, v in ps.items() if v is not None]
+    pseudo_ref = np.stack([ps[k] for k in names]).astype(np.float32)
+    real = onp.synthetic_real_planes(np.nan_to_num(pseudo_ref, nan=0.1), seed=3)
+    real_d = torch.from_numpy(real).cuda()
+    plan = SpectralFusion(w, srf, good, deg=3, min_valid=0.0, min_count=50, clip=True)
+    a = plan.step(u, real_d, reuse_buffers=False)
+    b = plan.step(dec, real_d, reuse_buffers=False)
+    assert torch.equal(a.coeffs, b.coeffs) and torch.equal(a.moments, b.moments)
+    np.testing.assert_array_equal(a.matched.cpu().numpy(), b.matched.cpu().numpy())
+    got = a.planes("pseudo").cpu().numpy().reshape(pseudo_ref.shape)
+    assert np.isnan(got[:, 5, 6]).all() and np.isnan(pseudo_ref[:, 5, 6]).all()
+    assert _rel_err(got, pseudo_ref) < 2e-6
+    assert a.moments[0, 0].item() == onp.per_band_valid(pseudo_ref[0], real[0], np.ones((H, W), bool), 0.0).sum()
+    # pipelined submit/flush takes the same dtype
+    plan.submit(u, real_d)
+    c = plan.flush()
+    assert torch.equal(c.coeffs, a.coeffs)

@@ -159,3 +159,19 @@ def test_sinkhorn_invariants_parity_unpinned():
     co = onp.fit_ot_poly_rgb(np.tile(X.reshape(300, 1, 3), (1, 4, 1)), np.tile(rng.random((300, 1, 3)), (1, 4, 1)),
                              np.ones((300, 4), bool), deg=2, n_samples=400)
     assert co.shape == (3, 3) and np.isfinite(co).all()
+
+
+def test_g10_tile_u16_quantisation():
+    """uint16 tile writer (tiles_helpers/utils.py:362-374): the restatement reproduces the reference's bits,
+    including round-half-even ties, the int32 overflow wrap-to-zero and source-nodata handling."""
+    g = load_golden("g10_tile_u16")
+    t = g["tile"]
+    np.testing.assert_array_equal(onp.tile_encode_u16(t), g["u16_plain"])
+    np.testing.assert_array_equal(onp.tile_encode_u16(t, src_nodata=-9999.0), g["u16_srcnodata"])
+    np.testing.assert_array_equal(onp.tile_encode_u16(t, None, 2000.0, 4095), g["u16_scale2000_nd4095"])
+    # decode(encode(x)) is within half a quantisation step wherever x is representable
+    x = t[np.isfinite(t) & (t >= 0) & (t < 6.5)]
+    d = onp.tile_decode_u16(onp.tile_encode_u16(x))
+    assert np.max(np.abs(d - x)) <= 0.5e-4 * (1 + 1e-3)
+    assert np.isnan(onp.tile_decode_u16(np.array([65535, 0, 1234], np.uint16))[0])
+    assert onp.tile_decode_u16(np.array([1234], np.uint16))[0] == np.float32(1234) * np.float32(1e-4)

@@ -67,6 +67,8 @@ SIGNATURES = {
     "hsr_srf_integrate_moments_u16": (C.c_int, [_vp, _i64, _i32, _f32, _i32, _vp, C.POINTER(_i32), C.POINTER(_i32),
                                                 _i32, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _f32, _f32, _i32, _vp,
                                                 C.POINTER(_i32), _vp]),
+    "hsr_ot_work_bytes": (_i64, [_i64, _i64]),
+    "hsr_ot_sinkhorn_barycentric": (C.c_int, [_vp, _i64, _vp, _i64, _f64, _i32, _f64, _vp, _vp, _vp, _vp]),
     "hsr_valid_mask": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp]),
     "hsr_polyfeat_count": (C.c_int, [_i32, _i32]),
     "hsr_polyfeat_table": (C.c_int, [_i32, _i32, _vp]),

@@ -4,9 +4,10 @@ Reference: s2_emit/poly_regression.py:31-56 and s2_emit/color.py:78-104 call POT
 (``ot.dist`` + ``ot.sinkhorn``).  POT is an unpinned dependency that is absent offline, so this
 step is **parity unpinned**: it follows POT's documented ``sinkhorn_knopp`` (K = exp(-M/reg);
 v <- b/(K^T u); u <- a/(K v); error check every 10th iteration on ||v*(K^T u) - b||_2) and is
-validated by OT invariants only.  The dense 5000 x 5000 float64 kernel matrix lives in HBM and
-the mat-vecs are plain library GEMVs through torch (a "next" row, not a
-hand-written kernel yet).  Sampling stays on the host so the PCG64 stream matches the reference.
+validated against the oracle's restatement and OT invariants only.  The dense 5000 x 5000 float64 kernel
+matrix lives in HBM; the two mat-vecs per iteration, the breakdown / convergence state and the barycentric
+projection are hand-written kernels (csrc/hsr_ot.hip), enqueued in one call without host
+synchronisation.  Sampling stays on the host so the PCG64 stream matches the reference.
 """
 from __future__ import annotations
 
@@ -32,32 +33,31 @@ def sample_pairs(src_rgb, ref_rgb, mask, n_samples, seed, min_rows):
     return X, Y
 
 
-def barycentric_targets_device(Xd, Yd, reg=0.05, numItermax=300, stopThr=1e-6):
-    """Xd (ns,3), Yd (nt,3) float64 GPU tensors -> Ybar (ns,3) float64 GPU tensor."""
+def barycentric_targets_device(Xd, Yd, reg=0.05, numItermax=300, stopThr=1e-6, return_info: bool = False):
+    """Xd (ns,3), Yd (nt,3) float64 GPU tensors -> Ybar (ns,3) float64 GPU tensor.
+    One C-ABI call enqueues the kernel matrix, every Sinkhorn iteration and the barycentric projection
+    (csrc/hsr_ot.hip); nothing synchronises with the host.  ``return_info`` adds a dict with the iteration the
+    loop stopped at (reads the device state: one synchronisation)."""
     torch = nat.require_gpu()
-    ns, nt = Xd.shape[0], Yd.shape[0]
-    a = torch.full((ns,), 1.0 / ns, dtype=torch.float64, device=Xd.device)
-    b = torch.full((nt,), 1.0 / nt, dtype=torch.float64, device=Xd.device)
-    M = (Xd * Xd).sum(1)[:, None] + (Yd * Yd).sum(1)[None, :] - 2.0 * (Xd @ Yd.T)
-    M.clamp_(min=0.0)
-    K = torch.exp(M / (-reg))
-    u = torch.full((ns,), 1.0 / ns, dtype=torch.float64, device=Xd.device)
-    v = torch.full((nt,), 1.0 / nt, dtype=torch.float64, device=Xd.device)
-    for ii in range(numItermax):
-        uprev, vprev = u, v
-        KtU = K.T @ u
-        v = b / KtU
-        u = a / (K @ v)
-        if ii % 10 == 0:     # the only host synchronisations: every 10th iteration, as POT checks
-            bad = (KtU == 0).any() | ~torch.isfinite(u).all() | ~torch.isfinite(v).all()
-            if bool(bad):
-                u, v = uprev, vprev
-                break
-            err = torch.linalg.vector_norm(v * (K.T @ u) - b)
-            if float(err) < stopThr:
-                break
-    P = u[:, None] * K * v[None, :]
-    return (P @ Yd) / (P.sum(dim=1, keepdim=True) + 1e-32)
+    lib = nat.load()
+    if not (Xd.is_cuda and Yd.is_cuda and Xd.dtype == torch.float64 and Yd.dtype == torch.float64
+            and Xd.dim() == 2 and Yd.dim() == 2 and Xd.shape[1] == 3 and Yd.shape[1] == 3):
+        raise ValueError("X and Y must be (n, 3) float64 GPU tensors")
+    Xd, Yd = Xd.contiguous(), Yd.contiguous()
+    ns, nt = int(Xd.shape[0]), int(Yd.shape[0])
+    work = torch.empty(int(lib.hsr_ot_work_bytes(ns, nt)), dtype=torch.uint8, device=Xd.device)
+    ybar = torch.empty((ns, 3), dtype=torch.float64, device=Xd.device)
+    info = torch.empty(6, dtype=torch.int32, device=Xd.device)
+    nat.check(lib.hsr_ot_sinkhorn_barycentric(Xd.data_ptr(), ns, Yd.data_ptr(), nt, float(reg), int(numItermax),
+                                              float(stopThr), work.data_ptr(), ybar.data_ptr(), info.data_ptr(),
+                                              torch.cuda.current_stream().cuda_stream), "hsr_ot_sinkhorn_barycentric")
+    if not return_info:
+        return ybar
+    h = info.cpu()
+    never = 0x7FFFFFFF
+    return ybar, {"break_iter": None if int(h[0]) == never else int(h[0]),
+                  "conv_iter": None if int(h[1]) == never else int(h[1]),
+                  "checks": int(h[2]), "err": float(h[4:6].view(torch.float64)[0])}
 
 
 def barycentric_targets(X, Y, reg=0.05, numItermax=300, stopThr=1e-6) -> np.ndarray:

@@ -193,6 +193,21 @@ int hsr_srf_integrate_moments_u16(const uint16_t* cube_dev, int64_t npix, int32_
                                   float min_y, int32_t deg, double* partials_dev, int32_t* slots_out,
                                   hsr_stream_t stream);
 
+/* ---- entropic OT targets ------------------------------------------------------------------
+ * Replaces, for uniform marginals, the POT calls of s2_emit/poly_regression.py:49-56 and color.py:97-104:
+ *   M = ot.dist(X, Y, "sqeuclidean"); P = ot.sinkhorn(a, b, M, reg, numItermax=, stopThr=);
+ *   Ybar = (P @ Y) / (P.sum(axis=1, keepdims=True) + 1e-32)
+ * x_dev (n,3), y_dev (m,3), ybar_dev (n,3): float64, C order.  Follows POT's sinkhorn_knopp schedule (breakdown
+ * test every iteration -> previous (u, v); error ||v*(K^T u) - b||_2 every 10th iteration).  The whole solve is
+ * enqueued without host synchronisation; iteration state lives in the workspace and is copied to info_dev
+ * (optional, 24 bytes: int32 break_iter, conv_iter [0x7fffffff = never], checks, pad; float64 last error).
+ * PARITY UNPINNED: POT is absent offline; validated against the oracle's restatement and OT invariants.
+ * Workspace: hsr_ot_work_bytes(n, m) bytes (the n x m float64 kernel matrix dominates), 256-byte aligned. */
+int64_t hsr_ot_work_bytes(int64_t n, int64_t m);
+int hsr_ot_sinkhorn_barycentric(const double* x_dev, int64_t n, const double* y_dev, int64_t m, double reg,
+                                int32_t num_iter_max, double stop_thr, void* work_dev, double* ybar_dev,
+                                int32_t* info_dev, hsr_stream_t stream);
+
 /* Validity mask of the pipeline (poly_regression.py:106,118): mask[p] = all bands of x finite
  * && x[pos_band][p] > 0 (pos_band < 0: skip) && all bands of y finite (y_dev may be NULL),
  * optionally AND-ed with mask_in_dev. */

@@ -1005,3 +1005,57 @@ def test_fused_step_on_u16_cube(torch_gpu):
     plan.submit(u, real_d)
     c = plan.flush()
     assert torch.equal(c.coeffs, a.coeffs)
+
+
+# ---------------------------------------------------------------------------------------------
+# device Sinkhorn (parity unpinned: POT absent - oracle restatement + invariants)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("ns,nt,reg,itmax,thr", [(700, 640, 0.05, 300, 1e-6), (333, 401, 0.05, 300, 1e-6),
+                                                 (512, 512, 0.02, 35, 0.0), (257, 129, 0.5, 300, 1e-9),
+                                                 (64, 50, 0.05, 0, 1e-6)])
+def test_device_sinkhorn_vs_oracle(torch_gpu, ns, nt, reg, itmax, thr):
+    torch = torch_gpu
+    from s2_emit import _ot
+    rng = np.random.default_rng(ns + nt)
+    X = rng.random((ns, 3))
+    Y = np.clip(X[rng.integers(0, ns, nt)] ** 0.8 * 0.9 + 0.05 + 0.02 * rng.standard_normal((nt, 3)), 0, 1)
+    want = onp.ot_barycentric_targets(X, Y, reg, itmax, thr)
+    got, info = _ot.barycentric_targets_device(torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda(), reg, itmax, thr,
+                                               return_info=True)
+    got = got.cpu().numpy()
+    # same schedule as the restatement: replay it on the host to know where it stopped
+    a, b = np.full(ns, 1 / ns), np.full(nt, 1 / nt)
+    K = np.exp(onp.sqeuclidean_cost(X, Y) / -reg)
+    u, v, stop, checks = a.copy(), b.copy(), None, 0
+    for ii in range(itmax):
+        v = b / (K.T @ u)
+        u = a / (K @ v)
+        if ii % 10 == 0:
+            checks += 1
+            if np.linalg.norm(v * (K.T @ u) - b) < thr:
+                stop = ii
+                break
+    assert info["break_iter"] is None and info["conv_iter"] == stop and info["checks"] == checks
+    np.testing.assert_allclose(got, want, rtol=1e-9, atol=1e-12)
+    # invariants of the plan behind the targets: rows of P sum to a (after the u update), targets are convex
+    # combinations of Y
+    assert (got.min(0) >= Y.min(0) - 1e-12).all() and (got.max(0) <= Y.max(0) + 1e-12).all()
+    # run-to-run bitwise reproducible (fixed summation trees, no float atomics)
+    again = _ot.barycentric_targets_device(torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda(), reg, itmax, thr)
+    assert np.array_equal(again.cpu().numpy().view(np.int64), got.view(np.int64))
+
+
+def test_device_sinkhorn_breakdown_keeps_previous_iterate(torch_gpu):
+    """reg so small that K underflows to 0 for a far-away target: K^T u == 0 -> POT keeps the previous (u, v)."""
+    torch = torch_gpu
+    from s2_emit import _ot
+    rng = np.random.default_rng(5)
+    X = rng.random((200, 3)) * 0.1
+    Y = rng.random((180, 3)) * 0.1
+    Y[7] = 50.0                                   # exp(-~7500/0.01) == 0 in float64
+    with np.errstate(all="ignore"):
+        want = onp.ot_barycentric_targets(X, Y, 0.01, 50, 1e-9)
+    got, info = _ot.barycentric_targets_device(torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda(), 0.01, 50, 1e-9,
+                                               return_info=True)
+    assert info["break_iter"] == 0 and info["conv_iter"] is None and info["checks"] == 0
+    np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-9, atol=1e-12)

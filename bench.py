@@ -179,9 +179,10 @@ def main():
                 "kernel_launches_timed": len(ev),
                 "step_frac_of_peak": round(cube_bytes * args.steps / dt_max / 1e9 / HBM_PEAK_GBS, 4)}
         tf = os.path.join(ROOT, "profiles", "traffic.json")
-        if os.path.isfile(tf) and args.cube == "f32":
+        if os.path.isfile(tf):
             try:
-                roof["traffic"] = json.load(open(tf)).get("srf_kernel_hbm_bytes_per_launch")
+                roof["traffic"] = json.load(open(tf)).get("srf_kernel_hbm_bytes_per_launch" if args.cube == "f32"
+                                                          else "srf_u16_kernel_hbm_bytes_per_launch")
             except Exception:
                 pass
         if not args.no_probe:

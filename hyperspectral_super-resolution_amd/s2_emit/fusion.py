@@ -168,6 +168,94 @@ class SpectralFusion:
         return FusionOutput(self.names, pseudo, moments, coeffs, matched, self.layout)
 
 
+    # ---- host -> device tile feed -------------------------------------------------------------------
+    # once K1 runs at TB/s the host -> device feed of the 1.2 GB cube is the bottleneck of an
+    # end-to-end run over tiles that live in host memory (the reference reads them from GeoTIFF / ENVI files).
+    # stream() double-buffers the device inputs and issues the H2D copies on their own stream, so the copy of
+    # tile i+1 (PCIe) runs under K1..K3 of tile i; results come back through pinned buffers.  Pass tiles as
+    # pinned tensors (pinned_like / torch.Tensor.pin_memory) - pageable sources are first copied by the CPU
+    # (~10 GB/s, five times slower than the link).
+    @staticmethod
+    def pinned_like(array):
+        """Pinned host tensor with the shape and dtype of a NumPy array (fill it in place: .numpy())."""
+        torch = nat.require_gpu()
+        dt = {np.dtype(np.float32): torch.float32, np.dtype(np.uint16): torch.uint16, np.dtype(np.uint8): torch.uint8}[np.dtype(array.dtype)]
+        t = torch.empty(tuple(array.shape), dtype=dt, pin_memory=True)
+        t.numpy()[...] = array
+        return t
+
+    def stream(self, tiles, depth: int = 2, to_host: bool = True):
+        """Run the hot path over an iterable of host tiles ``(cube, real)`` or ``(cube, real, mask)``
+        (NumPy arrays or CPU tensors; cube float32 or uint16 (H,W,B)/(npix,B), real as in step()).
+        Yields ``(index, coeffs, matched, out)``: with ``to_host`` coeffs is a (nb, deg+1) float64 and matched a
+        float32 NumPy array in the plan's layout (pinned memory reused every ``depth`` tiles - copy what you
+        keep); otherwise the device tensors of ``out`` (valid until the next iteration)."""
+        torch = nat.require_gpu()
+        if depth < 1:
+            raise ValueError("depth must be >= 1")
+        dev = self.device
+        copy_stream = torch.cuda.Stream(device=dev)
+        main = torch.cuda.current_stream(dev)
+        slots = [dict(cube=None, real=None, mask=None, ready=torch.cuda.Event(), free=torch.cuda.Event(), used=False,
+                      coeffs_h=None, matched_h=None, done=torch.cuda.Event()) for _ in range(depth)]
+
+        def as_tensor(x):
+            t = x if isinstance(x, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(x))
+            return t if t.is_contiguous() else t.contiguous()
+
+        def upload(i, tile):
+            sl = slots[i % depth]
+            cube, real = as_tensor(tile[0]), as_tensor(tile[1])
+            mask = as_tensor(tile[2]) if len(tile) > 2 and tile[2] is not None else None
+            if mask is not None and mask.dtype == torch.bool:
+                mask = mask.view(torch.uint8)
+            with torch.cuda.stream(copy_stream):
+                if sl["used"]:
+                    copy_stream.wait_event(sl["free"])       # the step that last read this buffer set
+                for key, src in (("cube", cube), ("real", real), ("mask", mask)):
+                    if src is None:
+                        sl[key] = None
+                        continue
+                    if sl[key] is None or sl[key].shape != src.shape or sl[key].dtype != src.dtype:
+                        sl[key] = torch.empty(src.shape, dtype=src.dtype, device=dev)
+                    sl[key].copy_(src, non_blocking=True)
+                sl["ready"].record(copy_stream)
+            sl["used"] = True
+
+        it = iter(tiles)
+        pending = []
+        idx = 0
+        for _ in range(depth):                       # prime: the first copies start before any compute
+            tile = next(it, None)
+            if tile is None:
+                break
+            upload(idx, tile)
+            pending.append(idx)
+            idx += 1
+        while pending:
+            i = pending.pop(0)
+            sl = slots[i % depth]
+            main.wait_event(sl["ready"])
+            out = self.step(sl["cube"], sl["real"], None if sl["mask"] is None else sl["mask"].reshape(-1))
+            if to_host:
+                if sl["matched_h"] is None or sl["matched_h"].shape != out.matched.shape:
+                    sl["matched_h"] = torch.empty(out.matched.shape, dtype=torch.float32, pin_memory=True)
+                    sl["coeffs_h"] = torch.empty(out.coeffs.shape, dtype=torch.float64, pin_memory=True)
+                sl["matched_h"].copy_(out.matched, non_blocking=True)
+                sl["coeffs_h"].copy_(out.coeffs, non_blocking=True)
+            sl["free"].record(main)                  # inputs of this slot may be overwritten from here on
+            sl["done"].record(main)
+            tile = next(it, None)                    # refill the slot just consumed: its copy overlaps the next step
+            if tile is not None:
+                upload(idx, tile)
+                pending.append(idx)
+                idx += 1
+            if to_host:
+                sl["done"].synchronize()
+                yield i, sl["coeffs_h"].numpy(), sl["matched_h"].numpy(), out
+            else:
+                yield i, out.coeffs, out.matched, out
+
     # ---- one-tile-deep software pipeline -----------------------------------------------------------
     # submit(i) enqueues K1+K2 of tile i on the caller's stream and the whole tail of tile i (slot
     # reduction -> RCCL exchange -> solve -> K3) on a side stream, so the tail of tile i runs underneath K1

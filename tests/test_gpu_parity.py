@@ -1059,3 +1059,41 @@ def test_device_sinkhorn_breakdown_keeps_previous_iterate(torch_gpu):
                                                return_info=True)
     assert info["break_iter"] == 0 and info["conv_iter"] is None and info["checks"] == 0
     np.testing.assert_allclose(got.cpu().numpy(), want, rtol=1e-9, atol=1e-12)
+
+
+# ---------------------------------------------------------------------------------------------
+# host -> device tile feed: double-buffered H2D under compute == tile-by-tile step()
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("depth,kind", [(2, "f32"), (1, "f32"), (3, "u16")])
+def test_stream_host_tiles_matches_step(torch_gpu, depth, kind):
+    torch = torch_gpu
+    from s2_emit import SpectralFusion
+    srf = onp.synthetic_srf()
+    w, good = onp.synthetic_wavelengths()
+    H, W = 48, 40
+    plan = SpectralFusion(w, srf, good, deg=2, min_valid=0.0, min_count=50, clip=True)
+    tiles, expect = [], []
+    for i in range(5):
+        R = onp.synthetic_cube(H, W, seed=100 + i)
+        if kind == "u16":
+            R = onp.tile_encode_u16(R)
+        ps = onp.pseudo_s2_srf_integral(onp.tile_decode_u16(R) if kind == "u16" else R, w, srf, good)
+        real = onp.synthetic_real_planes(np.stack([ps[k] for k in plan.names]).astype(np.float32), seed=i)
+        mask = (np.random.default_rng(i).random((H, W)) > 0.1) if i % 2 else None
+        # pinned tensors and plain NumPy arrays are both accepted
+        cube_in = SpectralFusion.pinned_like(R) if i % 2 == 0 else R
+        tiles.append((cube_in, real, mask))
+        o = plan.step(torch.from_numpy(R).cuda(), torch.from_numpy(real).cuda(),
+                      None if mask is None else torch.from_numpy(mask.view(np.uint8).reshape(-1)).cuda(), reuse_buffers=False)
+        expect.append((o.coeffs.cpu().numpy(), o.matched.cpu().numpy()))
+    seen = []
+    for i, coeffs, matched, out in plan.stream(iter(tiles), depth=depth):
+        seen.append(i)
+        np.testing.assert_array_equal(coeffs, expect[i][0])
+        np.testing.assert_array_equal(matched[:, :len(plan.names)], expect[i][1][:, :len(plan.names)])
+        assert out.layout == "pixmajor"
+    assert seen == [0, 1, 2, 3, 4]
+    dev = [(i, c.clone(), m.clone()) for i, c, m, _ in plan.stream(tiles[:2], depth=depth, to_host=False)]
+    assert [d[0] for d in dev] == [0, 1] and dev[1][1].is_cuda
+    np.testing.assert_array_equal(dev[1][1].cpu().numpy(), expect[1][0])
+    assert list(plan.stream([], depth=depth)) == []

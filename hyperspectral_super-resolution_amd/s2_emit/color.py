@@ -26,20 +26,13 @@ def robust_norm(x: np.ndarray, pmin: float = 2, pmax: float = 98) -> np.ndarray:
 
 
 def robust_norm_rgb(img: np.ndarray, mask: np.ndarray, pmin: float = 2, pmax: float = 98) -> np.ndarray:
-    """
-    Per-channel percentile stretch within mask; pixels outside the mask become NaN (color.py:10-23).
-    img: (H,W,3)
-    mask: (H,W) bool
-    Host NumPy (API surface).
-    """
-    y = np.zeros_like(img, dtype=float)
-    for c in range(3):
-        chan = img[..., c]
-        lo, hi = np.percentile(chan[mask], [pmin, pmax])
-        cc = (chan - lo) / (hi - lo + 1e-12)
-        cc[~mask] = np.nan
-        y[..., c] = np.clip(cc, 0, 1)
-    return y
+    """Per-channel percentile stretch with limits from the masked pixels; float64 output with NaN outside the
+    mask (color.py:10-23).  img (H,W,3), mask (H,W) bool.  Host NumPy (API surface)."""
+    inside = np.asarray(mask, dtype=bool)
+    limits = np.percentile(img[inside][:, :3], [pmin, pmax], axis=0)          # (2, 3): lo row, hi row
+    scaled = (np.asarray(img[..., :3], dtype=float) - limits[0]) / (limits[1] - limits[0] + 1e-12)
+    scaled[~inside] = np.nan
+    return np.clip(scaled, 0, 1)
 
 
 def device_percentile_stretch(x, mask=None, pmin=2, pmax=98, layout=nat.PIXMAJOR, lohi=None, nb=None,
@@ -88,19 +81,22 @@ def apply_shared_percentile_stretch(img, mask, pmin: float = 2, pmax: float = 98
     return out if as_torch else out.cpu().numpy()
 
 
+def _value_cdf(values: np.ndarray):
+    """Distinct sorted values of a 1-D sample and their empirical CDF n(<= v) / (n + 1e-32)."""
+    order = np.sort(values, kind="stable")
+    last = np.flatnonzero(np.append(order[1:] != order[:-1], True))           # last index of every run
+    return order[last], (last + 1).astype(np.float64) / (order.size + 1e-32)
+
+
 def _hist_match_channel(src: np.ndarray, ref: np.ndarray, mask: np.ndarray) -> np.ndarray:
-    """CDF matching of the masked values of one channel (color.py:36-53)."""
-    sv = src[mask].ravel()
-    rv = ref[mask].ravel()
-    s_values, s_idx, s_counts = np.unique(sv, return_inverse=True, return_counts=True)
-    r_values, r_counts = np.unique(rv, return_counts=True)
-    s_cdf = np.cumsum(s_counts).astype(np.float64)
-    s_cdf /= (s_cdf[-1] + 1e-32)
-    r_cdf = np.cumsum(r_counts).astype(np.float64)
-    r_cdf /= (r_cdf[-1] + 1e-32)
-    mapped = np.interp(s_cdf, r_cdf, r_values)
+    """CDF matching of one channel inside the mask (color.py:36-53): every masked source value goes to the
+    reference value at the same cumulative frequency (np.interp between the reference's distinct values)."""
+    picked = src[mask].ravel()
+    s_vals, s_cdf = _value_cdf(picked)
+    r_vals, r_cdf = _value_cdf(ref[mask].ravel())
+    lut = np.interp(s_cdf, r_cdf, r_vals)
     out = src.copy()
-    out[mask] = mapped[s_idx].reshape(sv.shape)
+    out[mask] = lut[np.searchsorted(s_vals, picked)]
     return out
 
 

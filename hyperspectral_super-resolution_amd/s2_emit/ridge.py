@@ -72,41 +72,88 @@ class PolyRidge:
         self._dev = {}
 
     # ---- fit --------------------------------------------------------------------------------------
-    def fit(self, X, Y):
-        """X (N, n_in), Y (N, T) - NumPy or GPU tensors; rows must be finite (see flatten_pixels)."""
+    # The fit is a sum over pixels twice over (scaler statistics, then the Gram matrix), so it shards by
+    # pixels exactly like the per-band fit (variant a9): ranks exchange (count, mean, M2) of
+    # their inputs - combined in rank order with the pairwise update of Chan et al., identically on every
+    # rank - and then all-reduce the [1|Phi]^T [1|Phi|Y] Gram (<= 288 x 608 float64 = 1.4 MB); every rank
+    # solves the same system and holds a bit-identical model.  The stages are separate methods so that the
+    # exchange can also be driven by hand (tests emulate ranks with shards on one GPU).
+    @staticmethod
+    def _to_dev(X, Y):
         torch = nat.require_gpu()
-        lib = nat.load()
         Xd = (X if _is_torch(X) else torch.from_numpy(np.ascontiguousarray(X, dtype=np.float32))).to("cuda", torch.float32).contiguous()
         Yd = (Y if _is_torch(Y) else torch.from_numpy(np.ascontiguousarray(Y))).to("cuda", torch.float64).contiguous()
         if Yd.dim() == 1:
             Yd = Yd[:, None]
+        return Xd, Yd
+
+    @staticmethod
+    def local_stats(Xd):
+        """(1 + 2 n_in,) float64 device tensor [n, mean..., M2...] of this shard's inputs."""
+        torch = nat.require_gpu()
+        X64 = Xd.double()
+        n = X64.shape[0]
+        mean = X64.mean(dim=0) if n else torch.zeros(X64.shape[1], dtype=torch.float64, device=Xd.device)
+        m2 = ((X64 - mean) ** 2).sum(dim=0)
+        return torch.cat([torch.tensor([float(n)], dtype=torch.float64, device=Xd.device), mean, m2])
+
+    @staticmethod
+    def combine_stats(stats):
+        """(world, 1 + 2 n_in) stacked local_stats -> (mean, scale) of the union; fixed rank order."""
+        torch = nat.require_gpu()
+        n_in = (stats.shape[1] - 1) // 2
+        n = stats[0, 0].clone()
+        mean = stats[0, 1:1 + n_in].clone()
+        m2 = stats[0, 1 + n_in:].clone()
+        for r in range(1, stats.shape[0]):
+            nb_, mb, m2b = stats[r, 0], stats[r, 1:1 + n_in], stats[r, 1 + n_in:]
+            tot = n + nb_
+            delta = mb - mean
+            safe = torch.where(tot > 0, tot, torch.ones_like(tot))
+            mean = mean + delta * (nb_ / safe)
+            m2 = m2 + m2b + delta * delta * (n * nb_ / safe)
+            n = tot
+        scale = (m2 / n).sqrt()
+        scale = torch.where(scale == 0, torch.ones_like(scale), scale)          # StandardScaler: zero variance -> 1
+        return mean, scale
+
+    def local_gram(self, Xd, Yd, mean, scale):
+        """[1 | Phi(z)]^T [1 | Phi(z) | Y] of this shard on the float64 matrix cores -> (na, na + tp) device tensor."""
+        torch = nat.require_gpu()
+        lib = nat.load()
         n, n_in = Xd.shape
         T = Yd.shape[1]
         nf = lib.hsr_polyfeat_count(n_in, self.degree)
         if nf <= 0:
             raise ValueError(f"unsupported polynomial features: n_in={n_in}, degree={self.degree}")
         nat.check(lib.hsr_polyfeat_prepare(n_in, self.degree), "hsr_polyfeat_prepare")
-        X64 = Xd.double()
-        mean = X64.mean(dim=0)
-        scale = X64.var(dim=0, unbiased=False).sqrt()
-        scale = torch.where(scale == 0, torch.ones_like(scale), scale)          # StandardScaler: zero variance -> 1
         na = (nf + 1 + 15) // 16 * 16                                          # [1 | features] padded
         tp = (T + 15) // 16 * 16
+        G = torch.zeros((na, na + tp), dtype=torch.float64, device=Xd.device)
+        if n == 0:
+            return G
         Q = torch.zeros((n, na + tp), dtype=torch.float64, device=Xd.device)    # [P | Y | 0]
         Q[:, na:na + T] = Yd
         nat.check(lib.hsr_polyfeat_expand_f64(_ptr(Xd), Xd.stride(0), Xd.stride(1) if n_in > 1 else 1, _ptr(mean),
                                               _ptr(scale), n, n_in, self.degree, _ptr(Q), Q.stride(0), na,
                                               _stream(torch)), "hsr_polyfeat_expand_f64")
         work = torch.empty(max(1, lib.hsr_gram_work_bytes(na, na + tp, n) // 8), dtype=torch.float64, device=Xd.device)
-        G = torch.empty((na, na + tp), dtype=torch.float64, device=Xd.device)
         nat.check(lib.hsr_gram_f64(_ptr(Q), Q.stride(0), na, _ptr(Q), Q.stride(0), na + tp, n, _ptr(work), _ptr(G),
                                    G.stride(0), _stream(torch)), "hsr_gram_f64")
+        return G
+
+    def solve_gram(self, G, mean, scale, n_in: int, T: int):
+        """Centre, add alpha I, Cholesky-solve; stores the model (host float64 copies + device float32 operands)."""
+        torch = nat.require_gpu()
+        lib = nat.load()
+        nf = lib.hsr_polyfeat_count(n_in, self.degree)
+        na = (nf + 1 + 15) // 16 * 16
         cnt = G[0, 0]
         s = G[0, 1:nf + 1]                               # column sums of the features
         ybar = G[0, na:na + T] / cnt
         Gc = G[1:nf + 1, 1:nf + 1] - torch.outer(s, s) / cnt
         rhs = G[1:nf + 1, na:na + T] - torch.outer(s, ybar)
-        Gc = Gc + self.alpha * torch.eye(nf, dtype=torch.float64, device=Xd.device)
+        Gc = Gc + self.alpha * torch.eye(nf, dtype=torch.float64, device=G.device)
         L = torch.linalg.cholesky(Gc)
         Wm = torch.cholesky_solve(rhs, L)               # (nf, T)
         b = ybar - (s / cnt) @ Wm
@@ -114,11 +161,34 @@ class PolyRidge:
         self.mean_, self.scale_ = mean.cpu().numpy(), scale.cpu().numpy()
         self.coef_, self.intercept_ = Wm.t().contiguous().cpu().numpy(), b.cpu().numpy()
         kpad = (nf + 1) // 2 * 2
-        Wf = torch.zeros((kpad, T), dtype=torch.float32, device=Xd.device)
+        Wf = torch.zeros((kpad, T), dtype=torch.float32, device=G.device)
         Wf[:nf] = Wm.float()
         self._dev = dict(W=Wf, b=b.float().contiguous(), mean=mean.float().contiguous(),
                          inv=(1.0 / scale).float().contiguous())
         return self
+
+    def fit(self, X, Y, group=None, distributed: Optional[bool] = None):
+        """X (N, n_in), Y (N, T) - NumPy or GPU tensors; rows must be finite (see flatten_pixels).
+        Inside an initialised torch.distributed job of more than one rank (or distributed=True) X, Y are this
+        rank's pixels and the fit is over the union of all ranks' pixels (two small collectives, see above)."""
+        torch = nat.require_gpu()
+        Xd, Yd = self._to_dev(X, Y)
+        if distributed is None:
+            import torch.distributed as dist
+            distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
+        stats = self.local_stats(Xd)
+        if distributed:
+            import torch.distributed as dist
+            world = dist.get_world_size(group)
+            gathered = [torch.empty_like(stats) for _ in range(world)]
+            dist.all_gather(gathered, stats, group=group)
+            mean, scale = self.combine_stats(torch.stack(gathered))
+        else:
+            mean, scale = self.combine_stats(stats[None])
+        G = self.local_gram(Xd, Yd, mean, scale)
+        if distributed:
+            dist.all_reduce(G, op=dist.ReduceOp.SUM, group=group)
+        return self.solve_gram(G, mean, scale, Xd.shape[1], Yd.shape[1])
 
     # ---- predict ------------------------------------------------------------------------------------
     def _predict_dev(self, x, x_ps: int, x_cs: int, npix: int, activation: int):

@@ -486,6 +486,17 @@ def test_rccl_exchange_path_single_rank(torch_gpu):
             torch.cuda.synchronize()
             for o in (o1, o2):
                 assert torch.equal(o.coeffs, base.coeffs) and torch.equal(o.matched.view(torch.int32), base.matched.view(torch.int32)), mode
+        # the other collectives of the path over RCCL: global percentile limits (integer histograms) and the
+        # distributed polynomial-ridge fit (all-gather of scaler statistics, all-reduce of the Gram)
+        from s2_emit import PolyRidge, _engine as eng
+        x3 = torch.rand(3, 5000, device="cuda")
+        assert torch.equal(eng.percentile_limits(x3, None, 2, 98, distributed=True), eng.percentile_limits(x3, None, 2, 98))
+        g = load_golden("g7_ridge")
+        Xr, Yr = g["X"].astype(np.float32), g["Ylogit"]
+        m0 = PolyRidge(3, 1.0).fit(Xr, Yr)
+        m1 = PolyRidge(3, 1.0).fit(Xr, Yr, distributed=True)
+        np.testing.assert_array_equal(m0.coef_, m1.coef_)
+        np.testing.assert_array_equal(m0.intercept_, m1.intercept_)
     finally:
         if created:
             dist.destroy_process_group()
@@ -1097,3 +1108,33 @@ def test_stream_host_tiles_matches_step(torch_gpu, depth, kind):
     assert [d[0] for d in dev] == [0, 1] and dev[1][1].is_cuda
     np.testing.assert_array_equal(dev[1][1].cpu().numpy(), expect[1][0])
     assert list(plan.stream([], depth=depth)) == []
+
+
+def test_poly_ridge_fit_over_pixel_shards(torch_gpu):
+    """Distributed a9 fit emulated on one GPU: three 'ranks' hold disjoint pixel shards; exchanging only the
+    scaler statistics (all-gather) and the Gram matrices (all-reduce = sum) reproduces the fit on the union."""
+    torch = torch_gpu
+    from s2_emit import PolyRidge
+    g = load_golden("g7_ridge")
+    X, Y = g["X"].astype(np.float32), g["Ylogit"]
+    n = X.shape[0]
+    cuts = [0, n // 5, n // 5 + 1, n]               # very unequal shards, one of a single pixel
+    ref = PolyRidge(3, 1.0).fit(X, Y)
+    shards = [PolyRidge._to_dev(X[a:b], Y[a:b]) for a, b in zip(cuts[:-1], cuts[1:])]
+    stats = torch.stack([PolyRidge.local_stats(xd) for xd, _ in shards])
+    mean, scale = PolyRidge.combine_stats(stats)
+    np.testing.assert_allclose(mean.cpu().numpy(), g["mean"], rtol=1e-12)
+    np.testing.assert_allclose(scale.cpu().numpy(), g["scale"], rtol=1e-12)
+    model = PolyRidge(3, 1.0)
+    G = sum(model.local_gram(xd, yd, mean, scale) for xd, yd in shards)
+    model.solve_gram(G, mean, scale, X.shape[1], Y.shape[1])
+    np.testing.assert_allclose(model.intercept_, g["intercept"], rtol=1e-6, atol=1e-7)
+    Xte = g["Xtest"].reshape(-1, 10).astype(np.float32)
+    np.testing.assert_allclose(model.predict(Xte), ref.predict(Xte), rtol=0, atol=2e-5)
+    np.testing.assert_allclose(model.predict(Xte), g["pred_logit"], rtol=0, atol=2e-4)
+    # an empty shard contributes nothing
+    e = PolyRidge._to_dev(X[:0], Y[:0])
+    st2 = torch.stack([stats[0], PolyRidge.local_stats(e[0]), stats[1], stats[2]])
+    m2, s2 = PolyRidge.combine_stats(st2)
+    assert torch.equal(m2, mean) and torch.equal(s2, scale)
+    assert float(model.local_gram(e[0], e[1], mean, scale).abs().max()) == 0.0

@@ -29,6 +29,10 @@ for p in (ROOT, os.path.join(ROOT, "hyperspectral_super-resolution_amd")):
     if p not in sys.path:
         sys.path.insert(0, p)
 
+# dmabuf IPC only on this pool (RCCL / cross-process sharing fail with the legacy mode); must be in the
+# environment before the HSA runtime initialises, i.e. before the first torch.cuda call
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E vendor peak (MI355X_MICROARCH.md)
 
 
@@ -107,7 +111,6 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
             dist.init_process_group("nccl", device_id=device)     # "nccl" is RCCL on ROCm
         else:

@@ -84,72 +84,235 @@ __global__ __launch_bounds__(256) void expand_f64_kernel(const float* __restrict
 // A (n, lda), B (n, ldb) row-major float64 with na, nb multiples of 16 inside lda/ldb.  Grid:
 // (tiles_i * tiles_j, chunks).  v_mfma_f64_16x16x4_f64: lane l supplies A[i = l&15][k = l>>4] and
 // B[k = l>>4][j = l&15]; D[row = (l>>4) + 4*reg][col = l&15] (the f64 map, NOT the f32 one).
-__global__ __launch_bounds__(64) void gram_f64_kernel(const double* __restrict__ A, int64_t lda, int tiles_i,
-                                                      const double* __restrict__ B, int64_t ldb, int tiles_j,
-                                                      int64_t n, int64_t rows_per_chunk,
-                                                      double* __restrict__ partials) {
-  // One wave = a 32 x 32 output block (2 x 2 MFMA tiles): two A and two B operands per k-step feed four
-  // MFMAs, half the operand loads per MFMA of the one-tile-per-wave version.
-  const int bj = (tiles_j + 1) / 2;
-  const int blk = blockIdx.x;
-  const int ti0 = (blk / bj) * 2, tj0 = (blk % bj) * 2;
-  const bool i1 = ti0 + 1 < tiles_i, j1 = tj0 + 1 < tiles_j;
-  const int lane = threadIdx.x;
+// One wave = a 48 x 48 output block (R x R = 3 x 3 MFMA tiles): three A and three B operands per k-step feed
+// nine MFMAs.  The kernel is bound by operand traffic from L2, not by the matrix pipe (the 2 x 2 version:
+// one operand load per MFMA, 50 % MFMA busy), so the lever is operands per MFMA: 0.67 here.  With `sym`
+// (B's first tiles_i tile columns are A itself, the Gram of the fit) blocks strictly below the diagonal
+// are skipped and mirrored by the reduction: 15 of the 36 symmetric blocks at 288 features.
+constexpr int kGramR = 3;
+
+__device__ __forceinline__ bool gram_block_skipped(int bi, int bj, int sym) { return sym && bj < bi; }
+
+__global__ __launch_bounds__(256) void gram_f64_kernel(const double* __restrict__ A, int64_t lda, int tiles_i,
+                                                       const double* __restrict__ B, int64_t ldb, int tiles_j,
+                                                       int64_t n, int64_t rows_per_chunk, int sym,
+                                                       double* __restrict__ partials) {
+  constexpr int R = kGramR;
+  __shared__ double red[R * R][256];   // cross-wave reduction of the block's output tiles (18 KB)
+  const int nbj = (tiles_j + R - 1) / R;
+  const int bi = blockIdx.x / nbj, bj = blockIdx.x % nbj;
+  if (gram_block_skipped(bi, bj, sym)) return;
+  const int ti0 = bi * R, tj0 = bj * R;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int col = lane & 15, kk = lane >> 4;
-  const int64_t r0 = (int64_t)blockIdx.y * rows_per_chunk;
-  int64_t r1 = r0 + rows_per_chunk;
-  if (r1 > n) r1 = n;
-  f64x4 acc[2][2];
+  // the chunk's rows are dealt to the 4 waves in quarters (whole k-steps); their sums are combined in wave
+  // order below, so the result does not depend on timing
+  const int64_t c0 = (int64_t)blockIdx.y * rows_per_chunk;
+  const int64_t quarter = ((rows_per_chunk / 4) + 3) / 4 * 4;
+  const int64_t r0 = c0 + wave * quarter;
+  int64_t cend = c0 + rows_per_chunk;
+  if (cend > n) cend = n;
+  int64_t r1 = wave == 3 ? cend : r0 + quarter;
+  if (r1 > cend) r1 = cend;
+  f64x4 acc[R][R];
 #pragma unroll
-  for (int x = 0; x < 2; ++x)
+  for (int x = 0; x < R; ++x)
 #pragma unroll
-    for (int y = 0; y < 2; ++y) acc[x][y] = f64x4{0.0, 0.0, 0.0, 0.0};
+    for (int y = 0; y < R; ++y) acc[x][y] = f64x4{0.0, 0.0, 0.0, 0.0};
   const double* ap = A + ti0 * 16 + col;
   const double* bp = B + tj0 * 16 + col;
-  const int ao = i1 ? 16 : 0, bo = j1 ? 16 : 0;   // second tile aliases the first when it does not exist
-  constexpr int KU = 8;   // k-steps whose operand loads are in flight together (32 independent loads)
-  for (int64_t r = r0; r < r1; r += 4 * KU) {
-    double a0[KU], a1[KU], b0[KU], b1[KU];
+  int ao[R], bo[R];   // tiles past the edge alias the first one (loaded, multiplied, never stored)
+#pragma unroll
+  for (int x = 0; x < R; ++x) {
+    ao[x] = ti0 + x < tiles_i ? 16 * x : 0;
+    bo[x] = tj0 + x < tiles_j ? 16 * x : 0;
+  }
+  constexpr int KU = 4;   // k-steps per operand batch (24 loads); two batches alternate: one in flight, one in the MFMAs
+  auto load = [&](double (&av)[KU][R], double (&bv)[KU][R], int64_t r) {
 #pragma unroll
     for (int u = 0; u < KU; ++u) {
       const int64_t rr = r + 4 * u + kk;
-      const bool ok = rr < r1;                    // ragged tail: rows beyond r1 contribute zeros
-      const int64_t rc = ok ? rr : r0;            // clamped address, value masked below
-      const double va0 = ap[rc * lda], va1 = ap[rc * lda + ao], vb0 = bp[rc * ldb], vb1 = bp[rc * ldb + bo];
-      a0[u] = ok ? va0 : 0.0;
-      a1[u] = ok ? va1 : 0.0;
-      b0[u] = ok ? vb0 : 0.0;
-      b1[u] = ok ? vb1 : 0.0;
-    }
+      const bool ok = rr < r1;                    // ragged tail / past the end: zeros
+      const int64_t rc = ok ? rr : c0;            // clamped address, value masked below
 #pragma unroll
-    for (int u = 0; u < KU; ++u) {
-      acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b0[u], acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0[u], b1[u], acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b0[u], acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1[u], b1[u], acc[1][1], 0, 0, 0);
+      for (int x = 0; x < R; ++x) {
+        const double va = ap[rc * lda + ao[x]], vb = bp[rc * ldb + bo[x]];
+        av[u][x] = ok ? va : 0.0;
+        bv[u][x] = ok ? vb : 0.0;
+      }
+    }
+  };
+  auto mma = [&](const double (&av)[KU][R], const double (&bv)[KU][R]) {
+#pragma unroll
+    for (int u = 0; u < KU; ++u)
+#pragma unroll
+      for (int x = 0; x < R; ++x)
+#pragma unroll
+        for (int y = 0; y < R; ++y)
+          acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][x], bv[u][y], acc[x][y], 0, 0, 0);
+  };
+  if (r0 < r1) {
+    double a0[KU][R], b0[KU][R], a1[KU][R], b1[KU][R];
+    load(a0, b0, r0);
+    for (int64_t r = r0; r < r1; r += 8 * KU) {
+      load(a1, b1, r + 4 * KU);
+      mma(a0, b0);
+      load(a0, b0, r + 8 * KU);
+      if (r + 4 * KU < r1) mma(a1, b1);
     }
   }
+  // ordered cross-wave sum: wave 0 stores, waves 1..3 add in turn
+#pragma unroll 1
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int x = 0; x < R; ++x)
+#pragma unroll
+        for (int y = 0; y < R; ++y)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            double* p = &red[x * R + y][(kk + 4 * g) * 16 + col];
+            *p = w == 0 ? acc[x][y][g] : *p + acc[x][y][g];
+          }
+    }
+    __syncthreads();
+  }
   const int ntiles = tiles_i * tiles_j;
+  for (int q = 0; q < R * R; ++q) {
+    const int x = q / R, y = q % R;
+    if (ti0 + x >= tiles_i || tj0 + y >= tiles_j) continue;
+    const int tile = (ti0 + x) * tiles_j + (tj0 + y);
+    partials[((size_t)blockIdx.y * ntiles + tile) * 256 + threadIdx.x] = red[q][threadIdx.x];
+  }
+}
+
+// LDS-panel form of the Gram kernel (the fast path).  Measured on the way here: f64 MFMA does not overlap with
+// the wave's own VALU work (a variant that built the feature panels on chip, 2 v_mul_f64 per operand, ran the
+// MFMAs at exactly MFMA time + VALU time), and the register-operand kernel above stalls on its 24 global loads
+// per batch.  So the operands take the one route that costs no VALU and no VGPRs: global_load_lds_dwordx4
+// straight into two 16-row x 96-column panels (A and B) per batch, double-buffered, and conflict-free
+// ds_read_b64 from there.  A workgroup (4 waves = 2 x 2 blocks of 3 x 3 MFMA tiles) owns a 96 x 96 output block
+// over a chunk of rows; blocks below the diagonal of the symmetric part are not launched.
+constexpr int kGpCols = 96;          // panel width = 6 MFMA tiles
+constexpr int kGpRows = 8;           // rows per batch = 2 k-steps
+constexpr int kGpBufs = 4;           // panel ring: batch b lives in slot b % 4, the DMA runs 3 batches ahead
+constexpr int kGpAhead = kGpBufs - 1;
+constexpr int kGpStride = 112;       // doubles per LDS panel row: 896 B = 128 B mod 256 B -> kk rows 0/1 and 2/3 on disjoint banks
+constexpr int kGpDmaPerWave = 2 * kGpRows / 4;   // panel rows (A and B) each wave moves per batch
+
+struct GramLdsArgs {
+  const double* A;
+  const double* B;
+  int64_t lda, ldb, n, rows_per_chunk;
+  int32_t na, nb, tiles_i, tiles_j;
+  double* partials;
+  uint8_t blocks[64][2];             // (bi, bj) of the launched output blocks
+};
+
+__device__ __forceinline__ void glds16_asm(const void* gaddr, uint32_t lds_base) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gaddr), "s"(lds_base) : "memory");
+}
+
+__global__ __launch_bounds__(256, 2) void gram_f64_lds_kernel(const GramLdsArgs a) {
+  __shared__ __attribute__((aligned(16))) double pan[kGpBufs][2][kGpRows][kGpStride];   // [slot][A|B][row][col]
+  const int bi = a.blocks[blockIdx.x][0], bj = a.blocks[blockIdx.x][1];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane & 15, kk = lane >> 4;
+  const int wx = wave >> 1, wy = wave & 1;
+  const int64_t c0 = (int64_t)blockIdx.y * a.rows_per_chunk;
+  int64_t cend = c0 + a.rows_per_chunk;
+  if (cend > a.n) cend = a.n;
+  const int nbatch = (int)((cend - c0 + kGpRows - 1) / kGpRows);
+  const int nfull = (int)((cend - c0) / kGpRows);   // batches whose rows all exist (every wave issues all its DMAs)
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(&pan[0][0][0][0]);
+
+  // 16 panel rows per batch (8 of A, 8 of B), 4 per wave; a row is 96 doubles = 48 lanes x 16 bytes.  Lanes whose
+  // columns lie past the matrix (last block of a ragged width) stay off: their LDS words only feed tiles that are
+  // never stored.  Rows past the chunk are zero-filled by hand (only in the last batch of the last chunk).
+  const int acol = bi * kGpCols + 2 * lane, bcol = bj * kGpCols + 2 * lane;
+  const bool a_on = lane < 48 && acol < a.na, b_on = lane < 48 && bcol < a.nb;
+  auto issue = [&](int b) {
+    const int slot = b % kGpBufs;
 #pragma unroll
-  for (int x = 0; x < 2; ++x) {
+    for (int i = 0; i < kGpDmaPerWave; ++i) {
+      const int pr = wave * kGpDmaPerWave + i;     // panel row: A rows, then B rows
+      const int p = pr / kGpRows, r = pr % kGpRows;
+      const int64_t row = c0 + (int64_t)b * kGpRows + r;
+      const uint32_t dst = lds0 + (uint32_t)(((slot * 2 + p) * kGpRows + r) * kGpStride * 8);
+      const bool on = p ? b_on : a_on;
+      if (row < cend) {
+        const double* src = p ? a.B + row * a.ldb + bcol : a.A + row * a.lda + acol;
+        if (on) glds16_asm(src, dst);
+      } else if (lane < 48) {
+        pan[slot][p][r][2 * lane] = 0.0;
+        pan[slot][p][r][2 * lane + 1] = 0.0;
+      }
+    }
+  };
+
+  constexpr int R = 3;
+  f64x4 acc[R][R];
 #pragma unroll
-    for (int y = 0; y < 2; ++y) {
-      if ((x == 1 && !i1) || (y == 1 && !j1)) continue;
-      const int tile = (ti0 + x) * tiles_j + (tj0 + y);
-      double* out = partials + ((size_t)blockIdx.y * ntiles + tile) * 256;
+  for (int x = 0; x < R; ++x)
+#pragma unroll
+    for (int y = 0; y < R; ++y) acc[x][y] = f64x4{0.0, 0.0, 0.0, 0.0};
+
+  for (int b = 0; b < kGpAhead && b < nbatch; ++b) issue(b);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int b = 0; b < nbatch; ++b) {
+    // slot (b+3) % 4 held batch b-1: every wave finished reading it before the barrier that ended iteration b-1
+    if (b + kGpAhead < nbatch) issue(b + kGpAhead);
+    const double (*pa)[kGpStride] = pan[b % kGpBufs][0];
+    const double (*pb)[kGpStride] = pan[b % kGpBufs][1];
+#pragma unroll
+    for (int u = 0; u < kGpRows / 4; ++u) {
+      double av[R], bv[R];
+#pragma unroll
+      for (int x = 0; x < R; ++x) {
+        av[x] = pa[4 * u + kk][wx * 48 + 16 * x + col];
+        bv[x] = pb[4 * u + kk][wy * 48 + 16 * x + col];
+      }
+#pragma unroll
+      for (int x = 0; x < R; ++x)
+#pragma unroll
+        for (int y = 0; y < R; ++y)
+          acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[x], bv[y], acc[x][y], 0, 0, 0);
+    }
+    // panel(b+1) must have landed; the DMAs of batches b+2 and b+3 (a full complement each, when both are whole
+    // batches) may stay in flight.  Near the end of the chunk the counts are no longer fixed: wait for everything.
+    if (b + kGpAhead < nfull) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kGpAhead - 1) * kGpDmaPerWave) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  const int ntiles = a.tiles_i * a.tiles_j;
+#pragma unroll
+  for (int x = 0; x < R; ++x) {
+#pragma unroll
+    for (int y = 0; y < R; ++y) {
+      const int ti = bi * 6 + wx * 3 + x, tj = bj * 6 + wy * 3 + y;
+      if (ti >= a.tiles_i || tj >= a.tiles_j) continue;
+      double* out = a.partials + ((size_t)blockIdx.y * ntiles + (size_t)ti * a.tiles_j + tj) * 256;
 #pragma unroll
       for (int g = 0; g < 4; ++g) out[(kk + 4 * g) * 16 + col] = acc[x][y][g];
     }
   }
 }
 
-// chunks summed in index order -> C[(ti*16 + r) * ldc + tj*16 + c]
+// chunks summed in index order -> C[(ti*16 + r) * ldc + tj*16 + c]; tiles of skipped blocks are the
+// transposes of their mirror tiles
 __global__ __launch_bounds__(256) void gram_reduce_kernel(const double* __restrict__ partials, int ntiles, int chunks,
-                                                          int tiles_j, double* __restrict__ C, int64_t ldc) {
+                                                          int tiles_j, int sym, int blk, double* __restrict__ C,
+                                                          int64_t ldc) {
   const int tile = blockIdx.x, e = threadIdx.x;
-  double s = 0.0;
-  for (int c = 0; c < chunks; ++c) s += partials[((size_t)c * ntiles + tile) * 256 + e];
   const int ti = tile / tiles_j, tj = tile % tiles_j;
+  const bool mirror = gram_block_skipped(ti / blk, tj / blk, sym);   // blk = tiles per skipped block edge
+  const int src_tile = mirror ? tj * tiles_j + ti : tile;
+  const int src_e = mirror ? (e & 15) * 16 + (e >> 4) : e;
+  double s = 0.0;
+  for (int c = 0; c < chunks; ++c) s += partials[((size_t)c * ntiles + src_tile) * 256 + src_e];
   C[(size_t)(ti * 16 + (e >> 4)) * ldc + tj * 16 + (e & 15)] = s;
 }
 
@@ -484,10 +647,45 @@ extern "C" int hsr_polyfeat_expand_f64(const float* x_dev, int64_t x_rs, int64_t
   return HSR_OK;
 }
 
-extern "C" size_t hsr_gram_work_bytes(int32_t na, int32_t nb, int64_t n) {
-  if (na < 16 || nb < 16 || n < 1) return 0;
+// Row chunking of the LDS-panel kernel: launched blocks x chunks should fill the 512 resident workgroup slots
+// (256 CUs x 2) in whole rounds - 513 workgroups take as long as 1024.  One round when that leaves >= 256 rows
+// per chunk, else as many chunks as fit.
+static int gram_lds_blocks(int na, int nb, int sym) {
+  const int nbi = (na + kGpCols - 1) / kGpCols, nbj = (nb + kGpCols - 1) / kGpCols;
+  int k = 0;
+  for (int bi = 0; bi < nbi; ++bi)
+    for (int bj = 0; bj < nbj; ++bj)
+      if (!(sym && bj < bi)) ++k;
+  return k;
+}
+
+static int64_t gram_lds_chunks(int64_t n, int nblocks, int64_t* rows_out) {
+  int64_t chunks = 512 / nblocks;
+  if (chunks * 256 > n) chunks = n / 256;
+  if (chunks > 256) chunks = 256;
+  if (chunks < 1) chunks = 1;
+  int64_t rows = (n + chunks - 1) / chunks;
+  rows = (rows + 15) / 16 * 16;                    // whole batches
+  chunks = (n + rows - 1) / rows;
+  if (rows_out) *rows_out = rows;
+  return chunks;
+}
+
+static int64_t gram_reg_chunks(int64_t n, int64_t* rows_out) {
   int64_t chunks = (n + 1023) / 1024;
   if (chunks > 256) chunks = 256;
+  int64_t rows = (n + chunks - 1) / chunks;
+  rows = (rows + 15) / 16 * 16;                    // whole k-steps inside every wave's quarter of a chunk
+  chunks = (n + rows - 1) / rows;
+  if (rows_out) *rows_out = rows;
+  return chunks;
+}
+
+extern "C" size_t hsr_gram_work_bytes(int32_t na, int32_t nb, int64_t n) {
+  if (na < 16 || nb < 16 || n < 1) return 0;
+  // both kernels use at most 256 chunks; size for the larger count so that either path can run
+  int64_t c1 = gram_reg_chunks(n, nullptr), c2 = gram_lds_chunks(n, gram_lds_blocks(na, nb, nb >= na), nullptr);
+  const int64_t chunks = c1 > c2 ? c1 : c2;
   return (size_t)chunks * (na / 16) * (nb / 16) * 256 * sizeof(double);
 }
 
@@ -497,16 +695,47 @@ extern "C" int hsr_gram_f64(const double* a_dev, int64_t lda, int32_t na, const 
   HSR_REQUIRE(a_dev && b_dev && work_dev && c_dev && n > 0, HSR_ERR_INVALID, "hsr_gram_f64: bad argument");
   HSR_REQUIRE(na >= 16 && nb >= 16 && na % 16 == 0 && nb % 16 == 0 && lda >= na && ldb >= nb && ldc >= nb,
               HSR_ERR_INVALID, "hsr_gram_f64: na=%d nb=%d must be multiples of 16 inside the leading dimensions", na, nb);
-  int64_t chunks = (n + 1023) / 1024;
-  if (chunks > 256) chunks = 256;
-  int64_t rows = (n + chunks - 1) / chunks;
-  rows = (rows + 3) / 4 * 4;                       // whole k-steps inside a chunk
-  chunks = (n + rows - 1) / rows;
   const int ti = na / 16, tj = nb / 16;
+  // Gram of one matrix with itself (the fit: A == B, same leading dimension): the first na columns of the
+  // result are symmetric, compute the upper block triangle only
+  const int sym = (a_dev == b_dev && lda == ldb && nb >= na) ? 1 : 0;
   hipStream_t s = (hipStream_t)stream;
-  hipLaunchKernelGGL(gram_f64_kernel, dim3(((ti + 1) / 2) * ((tj + 1) / 2), (unsigned)chunks), dim3(64), 0, s, a_dev, lda,
-                     ti, b_dev, ldb, tj, n, rows, work_dev);
-  hipLaunchKernelGGL(gram_reduce_kernel, dim3(ti * tj), dim3(256), 0, s, work_dev, ti * tj, (int)chunks, tj, c_dev, ldc);
+  const bool dma_ok = (lda % 2 == 0) && (ldb % 2 == 0) && (((uintptr_t)a_dev | (uintptr_t)b_dev) & 15) == 0;
+  const int nblocks = gram_lds_blocks(na, nb, sym);
+  if (dma_ok && nblocks <= 64) {
+    GramLdsArgs g{};
+    g.A = a_dev;
+    g.B = b_dev;
+    g.lda = lda;
+    g.ldb = ldb;
+    g.n = n;
+    g.na = na;
+    g.nb = nb;
+    g.tiles_i = ti;
+    g.tiles_j = tj;
+    g.partials = work_dev;
+    const int nbi = (na + kGpCols - 1) / kGpCols, nbj = (nb + kGpCols - 1) / kGpCols;
+    int k = 0;
+    for (int bi = 0; bi < nbi; ++bi)
+      for (int bj = 0; bj < nbj; ++bj)
+        if (!(sym && bj < bi)) {
+          g.blocks[k][0] = (uint8_t)bi;
+          g.blocks[k][1] = (uint8_t)bj;
+          ++k;
+        }
+    const int64_t chunks = gram_lds_chunks(n, nblocks, &g.rows_per_chunk);
+    hipLaunchKernelGGL(gram_f64_lds_kernel, dim3(nblocks, (unsigned)chunks), dim3(256), 0, s, g);
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3(ti * tj), dim3(256), 0, s, work_dev, ti * tj, (int)chunks, tj, sym,
+                       kGpCols / 16, c_dev, ldc);
+    HSR_LAUNCH_CHECK("gram_f64_lds_kernel");
+    return HSR_OK;
+  }
+  int64_t rows = 0;
+  const int64_t chunks = gram_reg_chunks(n, &rows);
+  constexpr int R = hsr::kGramR;
+  hipLaunchKernelGGL(gram_f64_kernel, dim3(((ti + R - 1) / R) * ((tj + R - 1) / R), (unsigned)chunks), dim3(256), 0, s,
+                     a_dev, lda, ti, b_dev, ldb, tj, n, rows, sym, work_dev);
+  hipLaunchKernelGGL(gram_reduce_kernel, dim3(ti * tj), dim3(256), 0, s, work_dev, ti * tj, (int)chunks, tj, sym, R, c_dev, ldc);
   HSR_LAUNCH_CHECK("gram_f64_kernel");
   return HSR_OK;
 }

@@ -522,6 +522,15 @@ def test_gram_f64_mfma_layout_exact(torch_gpu):
         Cd = torch.full((32, 48), -1.0, dtype=torch.float64, device="cuda")
         nat.check(lib.hsr_gram_f64(_ptr(Ad), 32, 32, _ptr(Bd), 48, 48, n, _ptr(work), _ptr(Cd), 48, _stream(torch)))
         np.testing.assert_array_equal(Cd.cpu().numpy(), A.T @ B)
+    # the Gram of one matrix with itself takes the symmetric path (blocks below the diagonal mirrored):
+    # [first na columns]^T [all columns], shapes that leave ragged 3 x 3 tile blocks on both axes
+    for n, na, nb_ in ((501, 112, 160), (64, 16, 16), (2000, 288, 320), (333, 64, 64)):
+        Q = rng.integers(-3, 4, (n, nb_)).astype(np.float64)
+        Qd = torch.from_numpy(Q).cuda()
+        work = torch.empty(max(1, lib.hsr_gram_work_bytes(na, nb_, n) // 8), dtype=torch.float64, device="cuda")
+        Cd = torch.full((na, nb_), -1.0, dtype=torch.float64, device="cuda")
+        nat.check(lib.hsr_gram_f64(_ptr(Qd), nb_, na, _ptr(Qd), nb_, nb_, n, _ptr(work), _ptr(Cd), nb_, _stream(torch)))
+        np.testing.assert_array_equal(Cd.cpu().numpy(), Q[:, :na].T @ Q)
 
 
 def test_poly_ridge_golden_g7(torch_gpu):
@@ -1138,3 +1147,4 @@ def test_poly_ridge_fit_over_pixel_shards(torch_gpu):
     m2, s2 = PolyRidge.combine_stats(st2)
     assert torch.equal(m2, mean) and torch.equal(s2, scale)
     assert float(model.local_gram(e[0], e[1], mean, scale).abs().max()) == 0.0
+

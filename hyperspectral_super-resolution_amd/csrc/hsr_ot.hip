@@ -283,24 +283,45 @@ extern "C" int64_t hsr_ot_work_bytes(int64_t n, int64_t m) {
   return (int64_t)hsr::ot_layout(n, m, nullptr, nullptr);
 }
 
-extern "C" int hsr_ot_sinkhorn_barycentric(const double* x_dev, int64_t n, const double* y_dev, int64_t m, double reg,
-                                           int32_t num_iter_max, double stop_thr, void* work_dev, double* ybar_dev,
-                                           int32_t* info_dev, hsr_stream_t stream) {
+// The solve in three stages, for callers that want to look at the state between blocks of iterations (one host
+// synchronisation per look) instead of enqueueing all numItermax iterations: after convergence the remaining
+// launches return at once, but ~800 empty launches still cost ~2 ms.
+static int ot_prepare(hsr::OtWork& w, int64_t n, int64_t m, void* work_dev, const char* who) {
   using namespace hsr;
-  HSR_REQUIRE(x_dev && y_dev && work_dev && ybar_dev, HSR_ERR_INVALID, "hsr_ot_sinkhorn_barycentric: NULL pointer");
-  HSR_REQUIRE(n >= 1 && m >= 1 && n <= (1 << 20) && m <= (1 << 20), HSR_ERR_UNSUPPORTED,
-              "hsr_ot_sinkhorn_barycentric: n=%lld m=%lld outside [1, 2^20]", (long long)n, (long long)m);
-  HSR_REQUIRE(reg > 0.0 && num_iter_max >= 0, HSR_ERR_INVALID, "hsr_ot_sinkhorn_barycentric: reg must be > 0, numItermax >= 0");
-  HSR_REQUIRE(((uintptr_t)work_dev & 255) == 0, HSR_ERR_INVALID, "hsr_ot_sinkhorn_barycentric: workspace not 256-byte aligned");
-  OtWork w{};
+  HSR_REQUIRE(work_dev, HSR_ERR_INVALID, "%s: NULL workspace", who);
+  HSR_REQUIRE(n >= 1 && m >= 1 && n <= (1 << 20) && m <= (1 << 20), HSR_ERR_UNSUPPORTED, "%s: n=%lld m=%lld outside [1, 2^20]",
+              who, (long long)n, (long long)m);
+  HSR_REQUIRE(((uintptr_t)work_dev & 255) == 0, HSR_ERR_INVALID, "%s: workspace not 256-byte aligned", who);
   ot_layout(n, m, &w, (unsigned char*)work_dev);
+  return HSR_OK;
+}
+
+extern "C" int hsr_ot_begin(const double* x_dev, int64_t n, const double* y_dev, int64_t m, double reg, void* work_dev,
+                            hsr_stream_t stream) {
+  using namespace hsr;
+  HSR_REQUIRE(x_dev && y_dev, HSR_ERR_INVALID, "hsr_ot_begin: NULL pointer");
+  HSR_REQUIRE(reg > 0.0, HSR_ERR_INVALID, "hsr_ot_begin: reg must be > 0");
+  OtWork w{};
+  int rc = ot_prepare(w, n, m, work_dev, "hsr_ot_begin");
+  if (rc != HSR_OK) return rc;
+  hipLaunchKernelGGL(ot_init_kernel, dim3((unsigned)((m + 255) / 256), (unsigned)w.nchunks), dim3(256), 0, (hipStream_t)stream,
+                     w, x_dev, y_dev, reg);
+  HSR_LAUNCH_CHECK("ot_init_kernel");
+  return HSR_OK;
+}
+
+extern "C" int hsr_ot_iterate(int64_t n, int64_t m, int32_t first_iter, int32_t count, double stop_thr, void* work_dev,
+                              int32_t* info_dev, hsr_stream_t stream) {
+  using namespace hsr;
+  HSR_REQUIRE(first_iter >= 0 && count >= 0, HSR_ERR_INVALID, "hsr_ot_iterate: bad iteration range");
+  OtWork w{};
+  int rc = ot_prepare(w, n, m, work_dev, "hsr_ot_iterate");
+  if (rc != HSR_OK) return rc;
   hipStream_t s = (hipStream_t)stream;
   const double aval = 1.0 / (double)n, bval = 1.0 / (double)m;   // uniform marginals, as the reference builds them
   const dim3 gcol((unsigned)((m + kOtColsPerBlock - 1) / kOtColsPerBlock), (unsigned)w.nchunks);
   const unsigned gfin = (unsigned)((m + 63) / 64), grow = (unsigned)((n + 3) / 4);
-  hipLaunchKernelGGL(ot_init_kernel, dim3((unsigned)((m + 255) / 256), (unsigned)w.nchunks), dim3(256), 0, s, w, x_dev, y_dev, reg);
-  HSR_LAUNCH_CHECK("ot_init_kernel");
-  for (int32_t ii = 0; ii < num_iter_max; ++ii) {
+  for (int32_t ii = first_iter; ii < first_iter + count; ++ii) {
     const int cur = ii & 1, nxt = cur ^ 1;
     hipLaunchKernelGGL(ot_col_partial_kernel, gcol, dim3(256), 0, s, w, ii, cur);
     hipLaunchKernelGGL(ot_col_finish_kernel, dim3(gfin), dim3(256), 0, s, w, ii, nxt, bval);
@@ -312,11 +333,36 @@ extern "C" int hsr_ot_sinkhorn_barycentric(const double* x_dev, int64_t n, const
     }
   }
   HSR_LAUNCH_CHECK("ot sinkhorn iterations");
-  hipLaunchKernelGGL(ot_barycentric_kernel, dim3(grow), dim3(256), 0, s, w, y_dev, num_iter_max, ybar_dev);
-  HSR_LAUNCH_CHECK("ot_barycentric_kernel");
   if (info_dev) {   // {break_iter, conv_iter, checks, pad, err(double)} = 24 bytes
-    int rc = check_hip(hipMemcpyAsync(info_dev, w.state, sizeof(OtState), hipMemcpyDeviceToDevice, s), "hipMemcpyAsync");
+    rc = check_hip(hipMemcpyAsync(info_dev, w.state, sizeof(OtState), hipMemcpyDeviceToDevice, s), "hipMemcpyAsync");
     if (rc != HSR_OK) return rc;
   }
   return HSR_OK;
+}
+
+extern "C" int hsr_ot_finish(const double* y_dev, int64_t n, int64_t m, int32_t iterations_done, void* work_dev,
+                             double* ybar_dev, int32_t* info_dev, hsr_stream_t stream) {
+  using namespace hsr;
+  HSR_REQUIRE(y_dev && ybar_dev && iterations_done >= 0, HSR_ERR_INVALID, "hsr_ot_finish: bad argument");
+  OtWork w{};
+  int rc = ot_prepare(w, n, m, work_dev, "hsr_ot_finish");
+  if (rc != HSR_OK) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  hipLaunchKernelGGL(ot_barycentric_kernel, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, s, w, y_dev, iterations_done, ybar_dev);
+  HSR_LAUNCH_CHECK("ot_barycentric_kernel");
+  if (info_dev) {
+    rc = check_hip(hipMemcpyAsync(info_dev, w.state, sizeof(OtState), hipMemcpyDeviceToDevice, s), "hipMemcpyAsync");
+    if (rc != HSR_OK) return rc;
+  }
+  return HSR_OK;
+}
+
+extern "C" int hsr_ot_sinkhorn_barycentric(const double* x_dev, int64_t n, const double* y_dev, int64_t m, double reg,
+                                           int32_t num_iter_max, double stop_thr, void* work_dev, double* ybar_dev,
+                                           int32_t* info_dev, hsr_stream_t stream) {
+  HSR_REQUIRE(num_iter_max >= 0, HSR_ERR_INVALID, "hsr_ot_sinkhorn_barycentric: numItermax must be >= 0");
+  int rc = hsr_ot_begin(x_dev, n, y_dev, m, reg, work_dev, stream);
+  if (rc == HSR_OK) rc = hsr_ot_iterate(n, m, 0, num_iter_max, stop_thr, work_dev, nullptr, stream);
+  if (rc == HSR_OK) rc = hsr_ot_finish(y_dev, n, m, num_iter_max, work_dev, ybar_dev, info_dev, stream);
+  return rc;
 }

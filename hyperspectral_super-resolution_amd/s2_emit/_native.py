@@ -68,6 +68,9 @@ SIGNATURES = {
                                                 _i32, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _f32, _f32, _i32, _vp,
                                                 C.POINTER(_i32), _vp]),
     "hsr_ot_work_bytes": (_i64, [_i64, _i64]),
+    "hsr_ot_begin": (C.c_int, [_vp, _i64, _vp, _i64, _f64, _vp, _vp]),
+    "hsr_ot_iterate": (C.c_int, [_i64, _i64, _i32, _i32, _f64, _vp, _vp, _vp]),
+    "hsr_ot_finish": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp]),
     "hsr_ot_sinkhorn_barycentric": (C.c_int, [_vp, _i64, _vp, _i64, _f64, _i32, _f64, _vp, _vp, _vp, _vp]),
     "hsr_valid_mask": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp]),
     "hsr_polyfeat_count": (C.c_int, [_i32, _i32]),

@@ -11,6 +11,8 @@ synchronisation.  Sampling stays on the host so the PCG64 stream matches the ref
 """
 from __future__ import annotations
 
+from typing import Optional
+
 import numpy as np
 
 from . import _native as nat
@@ -33,11 +35,14 @@ def sample_pairs(src_rgb, ref_rgb, mask, n_samples, seed, min_rows):
     return X, Y
 
 
-def barycentric_targets_device(Xd, Yd, reg=0.05, numItermax=300, stopThr=1e-6, return_info: bool = False):
+def barycentric_targets_device(Xd, Yd, reg=0.05, numItermax=300, stopThr=1e-6, return_info: bool = False,
+                               poll_every: Optional[int] = None):
     """Xd (ns,3), Yd (nt,3) float64 GPU tensors -> Ybar (ns,3) float64 GPU tensor.
-    One C-ABI call enqueues the kernel matrix, every Sinkhorn iteration and the barycentric projection
-    (csrc/hsr_ot.hip); nothing synchronises with the host.  ``return_info`` adds a dict with the iteration the
-    loop stopped at (reads the device state: one synchronisation)."""
+    By default one C-ABI call enqueues the kernel matrix, every Sinkhorn iteration and the barycentric projection
+    (csrc/hsr_ot.hip); nothing synchronises with the host.  With ``poll_every=k`` the iterations are enqueued in
+    blocks of k and the device state is read after each block (one synchronisation per block), so that nothing is
+    enqueued after convergence - same result, ~2 ms less when the solve converges early.  ``return_info`` adds a
+    dict with the iteration the loop stopped at (reads the device state: one synchronisation)."""
     torch = nat.require_gpu()
     lib = nat.load()
     if not (Xd.is_cuda and Yd.is_cuda and Xd.dtype == torch.float64 and Yd.dtype == torch.float64
@@ -48,13 +53,28 @@ def barycentric_targets_device(Xd, Yd, reg=0.05, numItermax=300, stopThr=1e-6, r
     work = torch.empty(int(lib.hsr_ot_work_bytes(ns, nt)), dtype=torch.uint8, device=Xd.device)
     ybar = torch.empty((ns, 3), dtype=torch.float64, device=Xd.device)
     info = torch.empty(6, dtype=torch.int32, device=Xd.device)
-    nat.check(lib.hsr_ot_sinkhorn_barycentric(Xd.data_ptr(), ns, Yd.data_ptr(), nt, float(reg), int(numItermax),
-                                              float(stopThr), work.data_ptr(), ybar.data_ptr(), info.data_ptr(),
-                                              torch.cuda.current_stream().cuda_stream), "hsr_ot_sinkhorn_barycentric")
+    stream = torch.cuda.current_stream().cuda_stream
+    never = 0x7FFFFFFF
+    if poll_every is None or poll_every <= 0:
+        nat.check(lib.hsr_ot_sinkhorn_barycentric(Xd.data_ptr(), ns, Yd.data_ptr(), nt, float(reg), int(numItermax),
+                                                  float(stopThr), work.data_ptr(), ybar.data_ptr(), info.data_ptr(),
+                                                  stream), "hsr_ot_sinkhorn_barycentric")
+    else:
+        nat.check(lib.hsr_ot_begin(Xd.data_ptr(), ns, Yd.data_ptr(), nt, float(reg), work.data_ptr(), stream), "hsr_ot_begin")
+        done = 0
+        while done < int(numItermax):
+            cnt = min(int(poll_every), int(numItermax) - done)
+            nat.check(lib.hsr_ot_iterate(ns, nt, done, cnt, float(stopThr), work.data_ptr(), info.data_ptr(), stream),
+                      "hsr_ot_iterate")
+            done += cnt
+            h = info[:2].cpu()
+            if int(h[0]) != never or int(h[1]) != never:
+                break
+        nat.check(lib.hsr_ot_finish(Yd.data_ptr(), ns, nt, done, work.data_ptr(), ybar.data_ptr(), info.data_ptr(), stream),
+                  "hsr_ot_finish")
     if not return_info:
         return ybar
     h = info.cpu()
-    never = 0x7FFFFFFF
     return ybar, {"break_iter": None if int(h[0]) == never else int(h[0]),
                   "conv_iter": None if int(h[1]) == never else int(h[1]),
                   "checks": int(h[2]), "err": float(h[4:6].view(torch.float64)[0])}
@@ -64,4 +84,4 @@ def barycentric_targets(X, Y, reg=0.05, numItermax=300, stopThr=1e-6) -> np.ndar
     torch = nat.require_gpu()
     Xd = torch.from_numpy(np.ascontiguousarray(X)).cuda()
     Yd = torch.from_numpy(np.ascontiguousarray(Y)).cuda()
-    return barycentric_targets_device(Xd, Yd, reg, numItermax, stopThr).cpu().numpy()
+    return barycentric_targets_device(Xd, Yd, reg, numItermax, stopThr, poll_every=50).cpu().numpy()

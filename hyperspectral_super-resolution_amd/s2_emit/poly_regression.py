@@ -64,7 +64,7 @@ def fit_ot_poly_rgb(
     torch = nat.require_gpu()
     Xd = torch.from_numpy(np.ascontiguousarray(X)).cuda()
     Yd = torch.from_numpy(np.ascontiguousarray(Y)).cuda()
-    Ybar = _ot.barycentric_targets_device(Xd, Yd, reg, numItermax, stopThr)
+    Ybar = _ot.barycentric_targets_device(Xd, Yd, reg, numItermax, stopThr, poll_every=50)   # the result is read on the host next
     return polyfit_columns(Xd, Ybar, deg)
 
 

@@ -204,6 +204,17 @@ int hsr_srf_integrate_moments_u16(const uint16_t* cube_dev, int64_t npix, int32_
  * PARITY UNPINNED: POT is absent offline; validated against the oracle's restatement and OT invariants.
  * Workspace: hsr_ot_work_bytes(n, m) bytes (the n x m float64 kernel matrix dominates), 256-byte aligned. */
 int64_t hsr_ot_work_bytes(int64_t n, int64_t m);
+/* The same solve in stages: begin (kernel matrix, u = 1/n, v = 1/m, state reset), iterate [first_iter, first_iter +
+ * count) - may be called repeatedly, copying the 24-byte state to info_dev so that a caller can stop enqueueing
+ * once break_iter / conv_iter is set (one host synchronisation per look) - and finish (barycentric projection with
+ * the (u, v) the loop ended on; iterations_done = total iterations enqueued).
+ * hsr_ot_sinkhorn_barycentric == begin + iterate(0, numItermax) + finish, without any synchronisation. */
+int hsr_ot_begin(const double* x_dev, int64_t n, const double* y_dev, int64_t m, double reg, void* work_dev,
+                 hsr_stream_t stream);
+int hsr_ot_iterate(int64_t n, int64_t m, int32_t first_iter, int32_t count, double stop_thr, void* work_dev,
+                   int32_t* info_dev, hsr_stream_t stream);
+int hsr_ot_finish(const double* y_dev, int64_t n, int64_t m, int32_t iterations_done, void* work_dev, double* ybar_dev,
+                  int32_t* info_dev, hsr_stream_t stream);
 int hsr_ot_sinkhorn_barycentric(const double* x_dev, int64_t n, const double* y_dev, int64_t m, double reg,
                                 int32_t num_iter_max, double stop_thr, void* work_dev, double* ybar_dev,
                                 int32_t* info_dev, hsr_stream_t stream);

@@ -1063,6 +1063,12 @@ def test_device_sinkhorn_vs_oracle(torch_gpu, ns, nt, reg, itmax, thr):
     # run-to-run bitwise reproducible (fixed summation trees, no float atomics)
     again = _ot.barycentric_targets_device(torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda(), reg, itmax, thr)
     assert np.array_equal(again.cpu().numpy().view(np.int64), got.view(np.int64))
+    # enqueueing in blocks with a look at the device state in between stops early and changes nothing
+    for k in (7, 50):
+        polled, pinfo = _ot.barycentric_targets_device(torch.from_numpy(X).cuda(), torch.from_numpy(Y).cuda(), reg, itmax, thr,
+                                                       return_info=True, poll_every=k)
+        assert np.array_equal(polled.cpu().numpy().view(np.int64), got.view(np.int64))
+        assert pinfo["conv_iter"] == info["conv_iter"] and pinfo["checks"] == info["checks"]
 
 
 def test_device_sinkhorn_breakdown_keeps_previous_iterate(torch_gpu):

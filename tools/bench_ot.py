@@ -14,6 +14,11 @@ for thr in (1e-6, 0.0):
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
         it = (info["conv_iter"] + 1) if info["conv_iter"] is not None else 300
         print(f"stopThr={thr:g}: {dt*1e3:.2f} ms wall, stopped after {it} iterations, {info}", flush=True)
+        if thr != 0.0:
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            _ot.barycentric_targets_device(Xd, Yd, 0.05, 300, thr, poll_every=50)
+            torch.cuda.synchronize()
+            print(f"   with poll_every=50: {(time.perf_counter()-t0)*1e3:.2f} ms wall", flush=True)
         if thr == 0.0:
             passes = 2 * 300 + 30
             print(f"   {passes} passes over the 200 MB kernel matrix -> {passes*200e6/dt/1e12:.2f} TB/s effective", flush=True)

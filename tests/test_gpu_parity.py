@@ -601,6 +601,22 @@ def test_resamplers_vs_oracle(torch_gpu):
     refu = onp.bilinear_upsample(coarse, 6)
     assert np.array_equal(np.isnan(up), np.isnan(refu))
     np.testing.assert_allclose(up[~np.isnan(refu)], refu[~np.isnan(refu)], rtol=2e-7, atol=1e-7)
+    # same float64 expressions in the same order, no contraction: the bits agree too; all output layouts and the
+    # 16-byte store path for band-last rows of 4, on a grid that is not a multiple of the 256 x 8 workgroup block
+    big = rng.random((3, 37, 50)).astype(np.float32)
+    refb = onp.bilinear_upsample(big, 6)
+    bd = torch.from_numpy(big).cuda().reshape(3, -1)
+    up_pl = eng.bilinear_upsample(bd, 37, 50, 6).cpu().numpy().reshape(3, 222, 300)
+    np.testing.assert_array_equal(up_pl, refb)
+    up_pm = eng.bilinear_upsample(bd, 37, 50, 6, "planar", "pixmajor")            # (npix, 4): vector store path
+    assert up_pm.shape == (222 * 300, 4)
+    np.testing.assert_array_equal(up_pm[:, :3].t().cpu().numpy().reshape(3, 222, 300), refb)
+    pm_in = torch.from_numpy(np.ascontiguousarray(np.moveaxis(big, 0, -1))).cuda().reshape(-1, 3)
+    up_pp = eng.bilinear_upsample(pm_in, 37, 50, 6, "pixmajor", "planar", nb=3)
+    np.testing.assert_array_equal(up_pp.cpu().numpy().reshape(3, 222, 300), refb)
+    five = rng.random((5, 8, 9)).astype(np.float32)
+    up5 = eng.bilinear_upsample(torch.from_numpy(five).cuda().reshape(5, -1), 8, 9, 3, "planar", "pixmajor")   # rows of 8: scalar stores
+    np.testing.assert_array_equal(up5[:, :5].t().cpu().numpy().reshape(5, 24, 27), onp.bilinear_upsample(five, 3))
 
 
 @pytest.mark.parametrize("use_ot", [False, True])

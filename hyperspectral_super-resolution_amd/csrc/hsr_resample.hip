@@ -27,6 +27,70 @@ __global__ __launch_bounds__(256) void block_mean_kernel(const T* __restrict__ i
   }
 }
 
+// Staged form for the two layouts the pipeline uses - band-major planes (in_ps == 1) and tightly packed band-last
+// rows (in_bs == 1, in_ps == nb, e.g. the uint8 RGB of the S2 visual product): a workgroup copies the f fine rows
+// under 64 coarse pixels into LDS with 16-byte loads (rows and segments start 16-byte aligned, checked on the host)
+// and every thread then adds its f x f window from there in the same (dy, dx) order as block_mean_kernel - same
+// bits.  The direct kernel fetched every sample with its own 1- or 4-byte global load (1.5 / 3.4 TB/s).
+constexpr int kBmCols = 64;   // coarse pixels per workgroup
+
+template <typename T>
+__global__ __launch_bounds__(256) void block_mean_tile_kernel(const T* __restrict__ in, int64_t plane_stride,
+                                                              int interleave, int Hc, int Wc, int f, float scale,
+                                                              float* __restrict__ out, int64_t out_bs, int64_t out_ps) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char bm_smem[];
+  T* tile = reinterpret_cast<T*>(bm_smem);
+  const int cx0 = blockIdx.x * kBmCols, y = blockIdx.y, plane = blockIdx.z;
+  const int ncx = Wc - cx0 < kBmCols ? Wc - cx0 : kBmCols;
+  const int64_t row_elems = (int64_t)Wc * f * interleave;          // elements per fine row
+  const int seg_full = kBmCols * f * interleave;                   // LDS row pitch (elements)
+  const int seg = ncx * f * interleave;                            // elements of this segment
+  const T* src = in + (size_t)plane * plane_stride + (int64_t)y * f * row_elems + (int64_t)cx0 * f * interleave;
+  const int chunks = (int)(((size_t)seg * sizeof(T) + 15) / 16);   // the segment ends on a 16-byte boundary of the row
+  for (int i = threadIdx.x; i < chunks * f; i += 256) {
+    const int dy = i / chunks, c = i - dy * chunks;
+    const uint4 v = *reinterpret_cast<const uint4*>(reinterpret_cast<const unsigned char*>(src + (int64_t)dy * row_elems) + (size_t)c * 16);
+    *reinterpret_cast<uint4*>(bm_smem + ((size_t)dy * seg_full * sizeof(T) + (size_t)c * 16)) = v;
+  }
+  __syncthreads();
+  for (int o = threadIdx.x; o < ncx * interleave; o += 256) {
+    const int cx = o / interleave, b = o - cx * interleave;
+    double s = 0.0;
+    for (int dy = 0; dy < f; ++dy)
+      for (int dx = 0; dx < f; ++dx) s += (double)tile[(size_t)dy * seg_full + (cx * f + dx) * interleave + b];
+    const float m = (float)(s / (double)(f * f));
+    const int band = interleave > 1 ? b : plane;
+    out[(size_t)band * out_bs + ((int64_t)y * Wc + cx0 + cx) * out_ps] = m * scale;
+  }
+}
+
+template <typename T>
+static bool launch_block_mean_tile(const T* in, int64_t in_bs, int64_t in_ps, int nb, int Hc, int Wc, int f, float scale,
+                                   float* out, int64_t out_bs, int64_t out_ps, hipStream_t s) {
+  int interleave, planes;
+  int64_t plane_stride;
+  if (in_ps == 1) {                       // band-major planes
+    interleave = 1;
+    planes = nb;
+    plane_stride = in_bs;
+  } else if (in_bs == 1 && in_ps == nb) { // tightly packed band-last rows
+    interleave = nb;
+    planes = 1;
+    plane_stride = 0;
+  } else {
+    return false;
+  }
+  const size_t row_bytes = (size_t)Wc * f * interleave * sizeof(T);
+  const size_t lds = (size_t)f * kBmCols * f * interleave * sizeof(T);
+  if ((((uintptr_t)in) & 15) || (row_bytes & 15) || ((plane_stride * sizeof(T)) & 15) || lds > 48 * 1024 ||
+      ((size_t)kBmCols * f * interleave * sizeof(T) & 15) || Hc > 65535 || planes > 65535)
+    return false;
+  const dim3 grid((unsigned)((Wc + kBmCols - 1) / kBmCols), (unsigned)Hc, (unsigned)planes);
+  hipLaunchKernelGGL(block_mean_tile_kernel<T>, grid, dim3(256), lds, s, in, plane_stride, interleave, Hc, Wc, f, scale, out,
+                     out_bs, out_ps);
+  return true;
+}
+
 // Separable taps of the pixel-centre aligned upsampling: pos = (i + 0.5) / f - 0.5, i0 = floor(pos), t = pos - i0,
 // both neighbours clamped to the image (in this order: i1 = i0 + 1 is formed before i0 is clamped).
 __device__ __forceinline__ void up_tap(int i, int f, int n, int* i0, int* i1, double* t) {
@@ -106,6 +170,17 @@ extern "C" int hsr_block_mean(const void* in_dev, int32_t in_dtype, int64_t in_b
               "hsr_block_mean: bad shape");
   const dim3 grid(grid_for((int64_t)Hc * Wc), nb), block(256);
   hipStream_t s = (hipStream_t)stream;
+  bool staged = false;
+  switch (in_dtype) {
+    case 0: staged = launch_block_mean_tile((const float*)in_dev, in_bs, in_ps, nb, Hc, Wc, factor, scale, out_dev, out_bs, out_ps, s); break;
+    case 1: staged = launch_block_mean_tile((const uint8_t*)in_dev, in_bs, in_ps, nb, Hc, Wc, factor, scale, out_dev, out_bs, out_ps, s); break;
+    case 2: staged = launch_block_mean_tile((const uint16_t*)in_dev, in_bs, in_ps, nb, Hc, Wc, factor, scale, out_dev, out_bs, out_ps, s); break;
+    default: break;
+  }
+  if (staged) {
+    HSR_LAUNCH_CHECK("block_mean_tile_kernel");
+    return HSR_OK;
+  }
   switch (in_dtype) {
     case 0: hipLaunchKernelGGL(block_mean_kernel<float>, grid, block, 0, s, (const float*)in_dev, in_bs, in_ps, Hc, Wc, factor, scale, nb, out_dev, out_bs, out_ps); break;
     case 1: hipLaunchKernelGGL(block_mean_kernel<uint8_t>, grid, block, 0, s, (const uint8_t*)in_dev, in_bs, in_ps, Hc, Wc, factor, scale, nb, out_dev, out_bs, out_ps); break;

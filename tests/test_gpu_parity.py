@@ -595,6 +595,25 @@ def test_resamplers_vs_oracle(torch_gpu):
     pm = torch.from_numpy(np.ascontiguousarray(np.moveaxis(fine8, 0, -1))).cuda().reshape(-1, 3)   # (npix, 3) uint8
     got_pm = eng.block_mean(pm, 5, 7, 6, 1.0 / 255.0, layout=nat.PIXMAJOR, nb=3)
     np.testing.assert_array_equal(got_pm[:, :3].t().cpu().numpy().reshape(3, 5, 7), ref)
+    # shapes whose fine rows are 16-byte multiples take the LDS-staged kernel (one full 64-pixel segment + a
+    # ragged one): same (dy, dx) summation order -> same bits as the restatement, all dtypes and both layouts
+    for f_, Wc_ in ((6, 80), (4, 72), (2, 200)):
+        Hc_ = 5
+        a8 = rng.integers(0, 256, (3, Hc_ * f_, Wc_ * f_), dtype=np.uint8)
+        want8 = onp.block_mean(a8, f_) * np.float32(1.0 / 255.0)
+        got = eng.block_mean(torch.from_numpy(a8).cuda().reshape(3, -1), Hc_, Wc_, f_, 1.0 / 255.0)
+        np.testing.assert_array_equal(got.cpu().numpy().reshape(3, Hc_, Wc_), want8)
+        pm8 = torch.from_numpy(np.ascontiguousarray(np.moveaxis(a8, 0, -1))).cuda().reshape(-1, 3)
+        got = eng.block_mean(pm8, Hc_, Wc_, f_, 1.0 / 255.0, layout=nat.PIXMAJOR, nb=3)
+        np.testing.assert_array_equal(got[:, :3].t().cpu().numpy().reshape(3, Hc_, Wc_), want8)
+        got = eng.block_mean(pm8, Hc_, Wc_, f_, 1.0 / 255.0, layout=nat.PIXMAJOR, out_layout=nat.PLANAR, nb=3)
+        np.testing.assert_array_equal(got.cpu().numpy().reshape(3, Hc_, Wc_), want8)
+        a32 = rng.random((2, Hc_ * f_, Wc_ * f_)).astype(np.float32)
+        got = eng.block_mean(torch.from_numpy(a32).cuda().reshape(2, -1), Hc_, Wc_, f_)
+        np.testing.assert_array_equal(got.cpu().numpy().reshape(2, Hc_, Wc_), onp.block_mean(a32, f_))
+        a16 = rng.integers(0, 65536, (2, Hc_ * f_, Wc_ * f_), dtype=np.uint16)
+        got = eng.block_mean(torch.from_numpy(a16).cuda().reshape(2, -1), Hc_, Wc_, f_, 1e-4)
+        np.testing.assert_array_equal(got.cpu().numpy().reshape(2, Hc_, Wc_), onp.block_mean(a16, f_) * np.float32(1e-4))
     coarse = rng.random((3, 9, 11)).astype(np.float32)
     coarse[1, 4, 4] = np.nan
     up = eng.bilinear_upsample(torch.from_numpy(coarse).cuda().reshape(3, -1), 9, 11, 6).cpu().numpy().reshape(3, 54, 66)

@@ -35,6 +35,30 @@ def sample_pairs(src_rgb, ref_rgb, mask, n_samples, seed, min_rows):
     return X, Y
 
 
+def sample_pairs_device(src, ref, mask, n_samples, seed, min_rows):
+    """Device form of sample_pairs: src, ref (H,W,3) GPU tensors, mask (H,W) bool / uint8 GPU tensor.
+    The row selection happens on the GPU (row-major order of the True mask positions, non-finite rows dropped
+    for X and Y independently - exactly what ``src_rgb[mask]`` + the isfinite filter produce on the host); only
+    the two row counts come back, so that ``default_rng(seed).choice`` draws the reference's indices, which are
+    then gathered on the device.  Returns (X, Y) float64 GPU tensors or None (fewer than ``min_rows`` rows).
+    On a 1024 x 1024 image the host version spends ~60 ms in boolean indexing; this one well under 1 ms."""
+    torch = nat.require_gpu()
+    s3 = src.reshape(-1, src.shape[-1])[:, :3]
+    r3 = ref.reshape(-1, ref.shape[-1])[:, :3]
+    m = mask.reshape(-1).to(torch.bool)
+    idx_x = torch.nonzero(m & torch.isfinite(s3).all(dim=1)).squeeze(1)
+    idx_y = torch.nonzero(m & torch.isfinite(r3).all(dim=1)).squeeze(1)
+    nx, ny = int(idx_x.numel()), int(idx_y.numel())          # the synchronisation of this step
+    if nx < min_rows or ny < min_rows:
+        return None
+    rng = np.random.default_rng(seed)
+    sel_x = rng.choice(nx, size=min(n_samples, nx), replace=False)
+    sel_y = rng.choice(ny, size=min(n_samples, ny), replace=False)
+    gx = idx_x[torch.from_numpy(sel_x).to(idx_x.device)]
+    gy = idx_y[torch.from_numpy(sel_y).to(idx_y.device)]
+    return s3[gx].to(torch.float64).contiguous(), r3[gy].to(torch.float64).contiguous()
+
+
 def barycentric_targets_device(Xd, Yd, reg=0.05, numItermax=300, stopThr=1e-6, return_info: bool = False,
                                poll_every: Optional[int] = None):
     """Xd (ns,3), Yd (nt,3) float64 GPU tensors -> Ybar (ns,3) float64 GPU tensor.

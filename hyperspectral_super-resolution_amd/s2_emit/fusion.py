@@ -414,9 +414,8 @@ def match_pair(R, emit_w, srf_dict, good_mask, s2_rgb_hi, factor: int = 6, deg: 
     s2_n = eng.poly_apply_stretch_only(s2_60, lohi_s, PM, nb=3)
     if use_ot:
         emit_n = eng.poly_apply_stretch_only(emit_rgb, lohi_e, PM, nb=3)
-        co = fit_ot_poly_rgb(emit_n[:, :3].reshape(H, W, 3).cpu().numpy(), s2_n[:, :3].reshape(H, W, 3).cpu().numpy(),
-                             valid60.reshape(H, W).cpu().numpy().astype(bool), deg=deg, n_samples=n_samples, reg=reg,
-                             numItermax=numItermax, stopThr=stopThr, seed=seed)
+        co = fit_ot_poly_rgb(emit_n[:, :3].reshape(H, W, 3), s2_n[:, :3].reshape(H, W, 3), valid60.reshape(H, W),
+                             deg=deg, n_samples=n_samples, reg=reg, numItermax=numItermax, stopThr=stopThr, seed=seed)
         coeffs = torch.from_numpy(np.ascontiguousarray(co)).to(dev)
     else:
         ws = eng.MomentWorkspace(dev, 3, deg)

@@ -49,21 +49,33 @@ def fit_ot_poly_rgb(
     mask: (H,W) boolean
     Returns coeffs: (3, deg+1) poly coefficients (highest power first) for R,G,B.
     """
-    if _is_torch(src_rgb):
-        src_rgb = src_rgb.detach().cpu().numpy()
-    if _is_torch(ref_rgb):
-        ref_rgb = ref_rgb.detach().cpu().numpy()
-    if _is_torch(mask):
-        mask = mask.detach().cpu().numpy().astype(bool)
-    s = _ot.sample_pairs(src_rgb, ref_rgb, mask, n_samples, seed, min_rows=200)
-    if s is None:                                   # identity fallback (poly_regression.py:38-41)
+    def identity():                                 # soft fallback of poly_regression.py:38-41
         coeffs = np.zeros((3, deg + 1), dtype=np.float64)
         coeffs[:, -2] = 1.0
         return coeffs
-    X, Y = s
+
+    if not (_is_torch(src_rgb) or _is_torch(ref_rgb) or _is_torch(mask)):
+        # small masks are settled on the host (no device needed for the fallback; a few thousand rows cost nothing)
+        m = np.asarray(mask, dtype=bool)
+        cnt = int(m.sum())
+        if cnt < 200:
+            return identity()
+        if cnt <= 65536:
+            nx = int(np.isfinite(np.asarray(src_rgb)[m].reshape(-1, 3)).all(axis=1).sum())
+            ny = int(np.isfinite(np.asarray(ref_rgb)[m].reshape(-1, 3)).all(axis=1).sum())
+            if nx < 200 or ny < 200:
+                return identity()
     torch = nat.require_gpu()
-    Xd = torch.from_numpy(np.ascontiguousarray(X)).cuda()
-    Yd = torch.from_numpy(np.ascontiguousarray(Y)).cuda()
+
+    def dev(a, dtype=None):
+        t = a.detach() if _is_torch(a) else torch.from_numpy(np.ascontiguousarray(a))
+        return t.to("cuda") if dtype is None else t.to("cuda", dtype)
+
+    # sampling on the device: only the two row counts and the drawn indices cross PCIe (see _ot.sample_pairs_device)
+    s = _ot.sample_pairs_device(dev(src_rgb), dev(ref_rgb), dev(mask, torch.bool), n_samples, seed, min_rows=200)
+    if s is None:
+        return identity()
+    Xd, Yd = s
     Ybar = _ot.barycentric_targets_device(Xd, Yd, reg, numItermax, stopThr, poll_every=50)   # the result is read on the host next
     return polyfit_columns(Xd, Ybar, deg)
 

@@ -1189,3 +1189,26 @@ def test_poly_ridge_fit_over_pixel_shards(torch_gpu):
     assert torch.equal(m2, mean) and torch.equal(s2, scale)
     assert float(model.local_gram(e[0], e[1], mean, scale).abs().max()) == 0.0
 
+
+
+def test_ot_sampling_on_device_matches_host_rows(torch_gpu):
+    """The row selection of fit_ot_poly_rgb done on the GPU (nonzero of mask & finite rows, the reference's PCG64
+    draw on the two counts, gather) returns exactly the rows the host code of poly_regression.py:31-47 picks."""
+    torch = torch_gpu
+    from s2_emit import _ot
+    rng = np.random.default_rng(17)
+    src = rng.random((61, 47, 3)).astype(np.float32)
+    ref = rng.random((61, 47, 3))
+    src[5, 5, 1] = np.nan
+    src[40, 2, 0] = np.inf
+    ref[7, 7, 2] = np.nan
+    mask = rng.random((61, 47)) > 0.3
+    for ns in (500, 100000):
+        X, Y = _ot.sample_pairs(src, ref, mask, ns, 4, 200)
+        Xd, Yd = _ot.sample_pairs_device(torch.from_numpy(src).cuda(), torch.from_numpy(ref).cuda(),
+                                         torch.from_numpy(mask).cuda(), ns, 4, 200)
+        np.testing.assert_array_equal(Xd.cpu().numpy(), X)
+        np.testing.assert_array_equal(Yd.cpu().numpy(), Y)
+    few = np.zeros((61, 47), bool)
+    few[0, :50] = True
+    assert _ot.sample_pairs_device(torch.from_numpy(src).cuda(), torch.from_numpy(ref).cuda(), torch.from_numpy(few).cuda(), 500, 0, 200) is None

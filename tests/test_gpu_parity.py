@@ -378,6 +378,32 @@ def test_fused_pipeline_vs_oracle(torch_gpu, H, W, deg):
     assert out.moments.cpu().numpy()[0, 0] == ok0.sum() == H * W - 1
 
 
+def test_config_c2_512_tile_vs_oracle(torch_gpu):
+    """BASELINE.json configs[1]: a single 512 x 512 x 285 tile, SRF synthesis + deg-3 fit + apply on one GPU,
+    against the reference-ordered float64 oracle on the same inputs; the north-star tolerance (1e-4 relative)
+    is asserted on the matched planes, the pseudo planes are held to 2e-6."""
+    torch = torch_gpu
+    from s2_emit import SpectralFusion
+    srf = onp.synthetic_srf()
+    w, good = onp.synthetic_wavelengths()
+    H = W = 512
+    R = onp.synthetic_cube(H, W, seed=2)
+    ps_ref = onp.pseudo_s2_srf_integral(R[:8], w, srf, good)
+    names = [k for k, v in ps_ref.items() if v is not None]
+    rng = np.random.default_rng(2)
+    real = np.clip(rng.random((len(names), H, W)) * 0.5 + 0.01, 0.01, 1).astype(np.float32)
+    pseudo_o, coeffs_o, matched_o, names_o = onp.fuse_lsq_reference(R, w, srf, good, real, 3, 0.0, 50, True)
+    plan = SpectralFusion(w, srf, good, deg=3, min_valid=0.0, min_count=50, clip=True)
+    assert plan.names == names_o
+    out = plan.step(torch.from_numpy(R).cuda(), torch.from_numpy(real).cuda())
+    assert _rel_err(out.planes("pseudo").cpu().numpy().reshape(pseudo_o.shape), pseudo_o) < 2e-6
+    assert _rel_err(out.planes("matched").cpu().numpy().reshape(matched_o.shape), matched_o) < 1e-4
+    co = out.coeffs.cpu().numpy()
+    xs = np.linspace(float(pseudo_o.min()), float(pseudo_o.max()), 64)
+    for b in range(len(names)):
+        np.testing.assert_allclose(np.polyval(co[b], xs), np.polyval(coeffs_o[b], xs), rtol=1e-4, atol=1e-6)
+
+
 def test_fuse_pair_numpy_wrapper(torch_gpu):
     import s2_emit
     srf = onp.synthetic_srf()

@@ -257,15 +257,20 @@ class SpectralFusion:
                 yield i, out.coeffs, out.matched, out
 
     # ---- one-tile-deep software pipeline -----------------------------------------------------------
-    # submit(i) enqueues K1+K2 of tile i on the caller's stream and the whole tail of tile i (slot
-    # reduction -> RCCL exchange -> solve -> K3) on a side stream, so the tail of tile i runs underneath K1
-    # of tile i+1 ("overlap the collective of tile i with K1 of tile i+1").  K1's persistent
-    # workgroups own every CU they run on, so a few CUs are left free for the side stream
-    # (hsr_set_srf_reserved_cus; 4 is enough for the fit kernels and RCCL).  Measured on one GPU: K3 does NOT
-    # ride along for free - overlapped, K1 slows by more than K3 costs alone (0.265 ms/tile with 4-12 reserved
-    # CUs, 0.29 with 16-32, 0.256 sequential) - so the pipeline pays only where an exchange latency is to be
-    # hidden (N > 1).  Two alternating buffer sets: the FusionOutput returned
-    # for tile i is valid until the second submit() after it; the caller's stream is made to wait for it.
+    # The fit of tile i (slot reduction -> RCCL exchange -> solve: a few small kernels and a latency-bound
+    # collective) runs on a side stream underneath K1 of tile i+1 ("overlap the collective of tile
+    # i with K1 of tile i+1"); K3 of tile i stays on the caller's stream, enqueued right behind K1 of tile i+1:
+    #
+    #     caller's stream :  K1(0)  K1(1)  K3(0)  K1(2)  K3(1)  K1(3)  K3(2) ...
+    #     side stream     :         fit(0)        fit(1)        fit(2)       ...
+    #
+    # so every bandwidth-bound kernel has the whole chip to itself and the exchange latency (and, on one GPU, the
+    # reduce+solve launch) disappears from the critical path.  K1's persistent workgroups own every CU they run on,
+    # so a few CUs are left free for the side stream (hsr_set_srf_reserved_cus; 4 are enough for the fit kernels
+    # and RCCL).  The first version also sent K3 to the side stream: K1 and K3 then fought for HBM and a tile took
+    # 0.265 ms against 0.256 ms sequential.  Two alternating buffer sets; ordering between tiles i and i+2 needs no
+    # extra events: K3(i) waits for fit(i) and precedes K1(i+2) on the caller's stream.  The FusionOutput returned
+    # for tile i is valid until the second submit() after it.
     def _pipe_state(self, npix: int):
         torch = nat.require_gpu()
         if self._pipe is None or self._pipe["npix"] != npix:
@@ -274,19 +279,23 @@ class SpectralFusion:
             for _ in range(2):
                 slots.append(dict(pseudo=eng.alloc_image(torch, nb, npix, self.layout, self.device),
                                   matched=eng.alloc_image(torch, nb, npix, self.layout, self.device),
-                                  ws=eng.MomentWorkspace(self.device, nb, self.deg),
-                                  ev_k1=torch.cuda.Event(), ev_done=torch.cuda.Event(), used=False))
+                                  ws=eng.MomentWorkspace(self.device, nb, self.deg), mask=None,
+                                  ev_k1=torch.cuda.Event(), ev_fit=torch.cuda.Event()))
             self._pipe = dict(npix=npix, slots=slots, n=0, pending=None, side=torch.cuda.Stream(device=self.device))
         return self._pipe
 
-    def _pipe_output(self, slot) -> FusionOutput:
+    def _pipe_finish(self, slot) -> FusionOutput:
+        """K3 of a submitted tile on the caller's stream, behind its fit."""
         torch = nat.require_gpu()
-        torch.cuda.current_stream().wait_event(slot["ev_done"])     # consumers on the caller's stream are ordered
+        torch.cuda.current_stream().wait_event(slot["ev_fit"])
         ws = slot["ws"]
+        eng.poly_apply(slot["pseudo"], ws.coeffs, slot["mask"] if self.apply_mask else None, None, self.clip,
+                       self.layout, out=slot["matched"], nb=self.table.nb)
+        slot["mask"] = None
         return FusionOutput(self.names, slot["pseudo"], ws.moments, ws.coeffs, slot["matched"], self.layout)
 
     def submit(self, cube, real, mask=None, k1_events=None) -> Optional[FusionOutput]:
-        """Pipelined step: start tile i, return tile i-1 (None on the first call)."""
+        """Pipelined step: start tile i, finish and return tile i-1 (None on the first call)."""
         torch = nat.require_gpu()
         npix = cube.numel() // cube.shape[-1]
         real, real_layout = self._real_image(real, npix)
@@ -294,12 +303,11 @@ class SpectralFusion:
         slot = st["slots"][st["n"] % 2]
         ws = slot["ws"]
         main = torch.cuda.current_stream()
-        if slot["used"]:
-            main.wait_event(slot["ev_done"])        # the tail that last read this buffer set (tile i-2)
         eng.srf_integrate_moments(cube, self.table, real, self.deg, ws, mask, self.min_valid, self.min_valid,
                                   out=slot["pseudo"], events=k1_events, reduce=False, layout=self.layout,
                                   real_layout=real_layout, scale=self.tile_scale, nodata=self.tile_nodata)
         slot["ev_k1"].record(main)
+        slot["mask"] = mask
         with torch.cuda.stream(st["side"]):
             st["side"].wait_event(slot["ev_k1"])
             if self._exchanges():
@@ -308,22 +316,19 @@ class SpectralFusion:
                                  self.group, self.coeff_sync)
             else:
                 eng.moments_reduce_solve(ws, self.min_count)
-            eng.poly_apply(slot["pseudo"], ws.coeffs, mask if self.apply_mask else None, None, self.clip,
-                           self.layout, out=slot["matched"], nb=self.table.nb)
-            slot["ev_done"].record(st["side"])
-        slot["used"] = True
+            slot["ev_fit"].record(st["side"])
         prev = st["pending"]
-        out = self._pipe_output(prev) if prev is not None else None
+        out = self._pipe_finish(prev) if prev is not None else None     # K3(i-1), behind K1(i) on this stream
         st["pending"] = slot
         st["n"] += 1
         return out
 
     def flush(self) -> Optional[FusionOutput]:
-        """Wait (on the caller's stream) for the tile left in the pipeline by the last submit() and return it."""
+        """Finish (K3, on the caller's stream) the tile left in the pipeline by the last submit() and return it."""
         st = self._pipe
         if st is None or st["pending"] is None:
             return None
-        out = self._pipe_output(st["pending"])
+        out = self._pipe_finish(st["pending"])
         st["pending"] = None
         return out
 

@@ -54,6 +54,22 @@ def test_sizing_helpers_and_error_strings():
     # strides must describe band-major planes or pixel-major rows
     rc = lib.hsr_srf_integrate(ctypes.c_void_p(16), 10, 285, ctypes.c_void_p(16), k, k, 1, ctypes.c_void_p(16), 3, 7, None)
     assert rc == 1 and b"neither band-major nor pixel-major" in lib.hsr_last_error()
+    # the rows added later in the round validate the same way
+    P = ctypes.c_void_p(256)
+    assert lib.hsr_tile_decode_u16(P, 10, 1e-4, 70000, P, None) == 1 and b"not a uint16 value" in lib.hsr_last_error()
+    assert lib.hsr_tile_decode_u16(None, 0, 1e-4, 65535, None, None) == 0            # empty input: nothing to do
+    assert lib.hsr_tile_encode_u16(P, 10, 1e4, 0, 0.0, 0, P, None) == 1 and b"nodata_u16" in lib.hsr_last_error()
+    assert lib.hsr_srf_integrate_u16(P, 10, 285, 1e-4, 1 << 20, P, k, k, 1, P, 10, 1, None) == 1
+    assert lib.hsr_percentile_hist(4, P, 10, 1, None, 10, 1, P, None) == 1
+    off, cnt = ctypes.c_int64(0), ctypes.c_int64(0)
+    assert lib.hsr_percentile_hist_region(1, 3, ctypes.byref(off), ctypes.byref(cnt)) == 0 and cnt.value == 3 * (2048 + 4)
+    assert lib.hsr_percentile_hist_region(3, 3, ctypes.byref(off), ctypes.byref(cnt)) == 0 and cnt.value == 3 * 4 * 1024
+    assert off.value + cnt.value * 4 <= lib.hsr_percentile_work_bytes(3)
+    assert lib.hsr_ot_work_bytes(5000, 5000) > 5000 * 5000 * 8 and lib.hsr_ot_work_bytes(0, 5) == 0
+    assert lib.hsr_ot_sinkhorn_barycentric(P, 10, P, 10, -1.0, 5, 1e-6, P, P, None, None) == 1 and b"reg must be > 0" in lib.hsr_last_error()
+    assert lib.hsr_ot_iterate(10, 10, 0, 5, 1e-6, ctypes.c_void_p(8), None, None) == 1 and b"256-byte aligned" in lib.hsr_last_error()
+    assert lib.hsr_gram_f64(P, 30, 32, P, 48, 48, 10, P, P, 48, None) == 1
+    assert lib.hsr_gram_work_bytes(288, 576, 29127) >= 34 * 18 * 36 * 256 * 8
     assert lib.hsr_set_srf_tile(48) == 1 and lib.hsr_get_srf_tile() == 64
     assert lib.hsr_set_srf_tile(32) == 0 and lib.hsr_get_srf_tile() == 32 and lib.hsr_set_srf_tile(64) == 0
 

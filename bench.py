@@ -58,6 +58,9 @@ def parse_args():
                     help="one-tile-deep software pipeline (exchange of tile i under K1 of tile i+1); auto = on for N > 1")
     ap.add_argument("--reserve-cus", type=int, default=4,
                     help="CUs left free of persistent K1 workgroups in pipelined mode (side-stream tail of the previous tile)")
+    ap.add_argument("--force-exchange", action="store_true",
+                    help="rehearsal only (N = 1): create a one-rank RCCL group and run the multi-GPU code path - "
+                         "pipelined submit() with the collective on the side stream - to measure its launch cost on one GPU")
     ap.add_argument("--cube", default="f32", choices=["f32", "u16"],
                     help="f32: the headline workload (float32 cube, 4 B per pixel*band).  u16: the same cube in the "
                          "reference's on-disk tile format (uint16 x 10000, tiles_helpers/utils.py:362-374), decoded inside "
@@ -66,6 +69,16 @@ def parse_args():
                     help="bracket the K1+K2 kernel with HIP events on every n-th timed step (each pair of event "
                          "records costs ~12 us of launch gap, so not on every step)")
     return ap.parse_args()
+
+
+def _claim_stdout() -> int:
+    """The contract is ONE JSON line on stdout.  RCCL prints a version banner on stdout (through C stdio, at a moment
+    of its own choosing - communicator creation is lazy), torch may warn, libraries may chat: so file descriptor 1
+    is pointed at stderr for the whole run and the JSON line is written to the saved descriptor at the end."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    return saved
 
 
 def cpu_baseline(args):
@@ -91,6 +104,7 @@ def cpu_baseline(args):
 
 def main():
     args = parse_args()
+    real_stdout = _claim_stdout()
     import torch
     import torch.distributed as dist
     from s2_emit import SpectralFusion
@@ -116,10 +130,17 @@ def main():
         else:
             dist.init_process_group("gloo")
 
+    if args.force_exchange:
+        if world != 1:
+            raise SystemExit("--force-exchange is a one-process rehearsal")
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29531", rank=0, world_size=1, device_id=device)
+
     H, W, B = args.height, args.width, args.bands
     prob = device_problem(H, W, B, deg=args.deg, seed=rank, device=device)
     plan = SpectralFusion(prob.emit_w, prob.srf, prob.good_mask, deg=args.deg, min_valid=0.0, min_count=50,
-                          clip=True, device=device, group=None, coeff_sync=args.coeff_sync if world > 1 else "local")
+                          clip=True, device=device, group=None,
+                          coeff_sync=args.coeff_sync if (world > 1 or args.force_exchange) else "local",
+                          force_exchange=args.force_exchange)
     real = prob.real            # (H, W, row) band-last, like the cube and the reference's (H, W, C) images
     cube = prob.cube
     if args.cube == "u16":      # quantise once, outside the timed region (the writer's arithmetic, on the device)
@@ -131,7 +152,7 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    pipelined = args.pipeline == "on" or (args.pipeline == "auto" and world > 1)
+    pipelined = args.pipeline == "on" or (args.pipeline == "auto" and (world > 1 or args.force_exchange))
     if pipelined:      # keep a few CUs free of persistent K1 workgroups for the side stream (fit kernels, RCCL, K3)
         from s2_emit import _native as nat
         nat.check(nat.load().hsr_set_srf_reserved_cus(args.reserve_cus))
@@ -198,14 +219,15 @@ def main():
                 "config": {"workload": f"{H}x{W}x{B} EMIT-like cube{' stored as uint16 x 10000 tiles (decode fused into K1)' if args.cube == 'u16' else ''} + {len(prob.names)} real-S2 planes per GPU, "
                                        f"deg-{args.deg} per-band least squares over all valid pixels "
                                        f"(BASELINE.json configs[2]; one tile per GPU for N>1)",
-                           "tiles_per_gpu": 1, "coeff_sync": args.coeff_sync if world > 1 else "none",
+                           "tiles_per_gpu": 1, "coeff_sync": (args.coeff_sync if world > 1 else "none") +
+                           (f" (rehearsal: one-rank RCCL {args.coeff_sync} forced)" if args.force_exchange else ""),
                            "pipeline": f"one tile deep, {args.reserve_cus} CUs reserved" if pipelined else "off",
                            "backend": (args.backend if world > 1 else "none") + (" (rehearsal: all ranks on cuda:0)" if args.same_device else "")},
                 "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args)
-        print(json.dumps(line), flush=True)
-    if world > 1:
+        os.write(real_stdout, (json.dumps(line) + "\n").encode())
+    if world > 1 or args.force_exchange:
         dist.barrier()
         dist.destroy_process_group()
 

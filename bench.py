@@ -56,7 +56,7 @@ def parse_args():
                     help="rehearsal only: every rank uses cuda:0 (needs --backend gloo)")
     ap.add_argument("--pipeline", default="auto", choices=["auto", "on", "off"],
                     help="one-tile-deep software pipeline (exchange of tile i under K1 of tile i+1); auto = on for N > 1")
-    ap.add_argument("--reserve-cus", type=int, default=4,
+    ap.add_argument("--reserve-cus", type=int, default=8,
                     help="CUs left free of persistent K1 workgroups in pipelined mode (side-stream tail of the previous tile)")
     ap.add_argument("--force-exchange", action="store_true",
                     help="rehearsal only (N = 1): create a one-rank RCCL group and run the multi-GPU code path - "

@@ -139,10 +139,17 @@ __device__ __forceinline__ double row_sum(const double* __restrict__ row, int sl
   return wave_sum(s);
 }
 
-__global__ __launch_bounds__(64) void reduce_kernel(const double* __restrict__ partials, int slots,
-                                                    double* __restrict__ moments) {
-  const double s = row_sum(partials + (size_t)blockIdx.x * slots, slots, threadIdx.x);
-  if (threadIdx.x == 0) moments[blockIdx.x] = s;
+// At most 16 workgroups of 4 waves: in the pipelined multi-GPU step this kernel runs on a side stream while the
+// persistent K1 of the next tile owns the chip, and only workgroups that fit the few CUs K1 leaves free get
+// dispatched before K1 ends (measured: 132 one-wave workgroups starved for the whole 0.22 ms with 4 free CUs,
+// 16 workgroups run in 8 us).
+__global__ __launch_bounds__(256) void reduce_kernel(const double* __restrict__ partials, int slots, int nrows,
+                                                     double* __restrict__ moments) {
+  const int lane = threadIdx.x & 63;
+  for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < nrows; row += gridDim.x * 4) {
+    const double s = row_sum(partials + (size_t)row * slots, slots, lane);
+    if (lane == 0) moments[row] = s;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -576,8 +583,9 @@ extern "C" int hsr_moments_reduce(const double* partials_dev, int32_t slots, int
   HSR_REQUIRE(slots >= 1 && slots <= HSR_MAX_PARTIALS, HSR_ERR_INVALID, "hsr_moments_reduce: slots=%d", slots);
   HSR_REQUIRE(nb >= 1 && nb <= HSR_MAX_BANDS && deg >= 1 && deg <= HSR_MAX_DEG, HSR_ERR_UNSUPPORTED,
               "hsr_moments_reduce: nb=%d deg=%d", nb, deg);
-  hipLaunchKernelGGL(reduce_kernel, dim3(nb * moment_count(deg)), dim3(64), 0, (hipStream_t)stream, partials_dev,
-                     slots, moments_dev);
+  const int nrows = nb * moment_count(deg);
+  hipLaunchKernelGGL(reduce_kernel, dim3((nrows + 3) / 4 < 16 ? (nrows + 3) / 4 : 16), dim3(256), 0, (hipStream_t)stream, partials_dev,
+                     slots, nrows, moments_dev);
   HSR_LAUNCH_CHECK("reduce_kernel");
   return HSR_OK;
 }

@@ -262,12 +262,15 @@ class SpectralFusion:
     # i with K1 of tile i+1"); K3 of tile i stays on the caller's stream, enqueued right behind K1 of tile i+1:
     #
     #     caller's stream :  K1(0)  K1(1)  K3(0)  K1(2)  K3(1)  K1(3)  K3(2) ...
-    #     side stream     :         fit(0)        fit(1)        fit(2)       ...
+    #     side stream     :  fit(0)        fit(1)        fit(2)        fit(3) ...      (fit(i) under K1(i+1))
     #
     # so every bandwidth-bound kernel has the whole chip to itself and the exchange latency (and, on one GPU, the
     # reduce+solve launch) disappears from the critical path.  K1's persistent workgroups own every CU they run on,
-    # so a few CUs are left free for the side stream (hsr_set_srf_reserved_cus; 4 are enough for the fit kernels
-    # and RCCL).  The first version also sent K3 to the side stream: K1 and K3 then fought for HBM and a tile took
+    # so CUs are left free for the side stream (hsr_set_srf_reserved_cus).  Measured (tools/corun_probe.py): a kernel
+    # from another queue is only dispatched next to the persistent K1 if every XCD has a completely free CU - with 8
+    # free CUs (496 workgroups) the reduce + solve pair runs in 25 us under K1, with 6 or fewer it waits for K1 to end.  The side stream is created with high priority: streams of the default priority were mapped to the
+    # SAME hardware queue as the caller's stream on this stack (rocprofv3 Queue_Id), which serialised everything.
+    # The first version also sent K3 to the side stream: K1 and K3 then fought for HBM and a tile took
     # 0.265 ms against 0.256 ms sequential.  Two alternating buffer sets; ordering between tiles i and i+2 needs no
     # extra events: K3(i) waits for fit(i) and precedes K1(i+2) on the caller's stream.  The FusionOutput returned
     # for tile i is valid until the second submit() after it.
@@ -281,7 +284,7 @@ class SpectralFusion:
                                   matched=eng.alloc_image(torch, nb, npix, self.layout, self.device),
                                   ws=eng.MomentWorkspace(self.device, nb, self.deg), mask=None,
                                   ev_k1=torch.cuda.Event(), ev_fit=torch.cuda.Event()))
-            self._pipe = dict(npix=npix, slots=slots, n=0, pending=None, side=torch.cuda.Stream(device=self.device))
+            self._pipe = dict(npix=npix, slots=slots, n=0, pending=None, side=torch.cuda.Stream(device=self.device, priority=-1))
         return self._pipe
 
     def _pipe_finish(self, slot) -> FusionOutput:
@@ -306,8 +309,12 @@ class SpectralFusion:
         eng.srf_integrate_moments(cube, self.table, real, self.deg, ws, mask, self.min_valid, self.min_valid,
                                   out=slot["pseudo"], events=k1_events, reduce=False, layout=self.layout,
                                   real_layout=real_layout, scale=self.tile_scale, nodata=self.tile_nodata)
-        slot["ev_k1"].record(main)
         slot["mask"] = mask
+        prev = st["pending"]
+        out = self._pipe_finish(prev) if prev is not None else None     # K3(i-1), directly behind K1(i) on this stream
+        # the event that releases fit(i) is recorded behind K3(i-1), not between K1(i) and K3(i-1): an event record
+        # in between cost a ~13 us bubble on the caller's stream; fit(i) still has all of K1(i+1) to hide under
+        slot["ev_k1"].record(main)
         with torch.cuda.stream(st["side"]):
             st["side"].wait_event(slot["ev_k1"])
             if self._exchanges():
@@ -317,8 +324,6 @@ class SpectralFusion:
             else:
                 eng.moments_reduce_solve(ws, self.min_count)
             slot["ev_fit"].record(st["side"])
-        prev = st["pending"]
-        out = self._pipe_finish(prev) if prev is not None else None     # K3(i-1), behind K1(i) on this stream
         st["pending"] = slot
         st["n"] += 1
         return out

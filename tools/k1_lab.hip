@@ -1,5 +1,7 @@
 // K1 lab: A/B of kernel structures for the SRF band integration in ONE process (interleaved rounds,
-// hipEvent timing).  Not part of the library; build: hipcc --offload-arch=gfx950 -O3 tools/k1_lab.hip -o tools/k1_lab
+// hipEvent timing).  Not part of the library; build (after `make -C hyperspectral_super-resolution_amd/csrc`):
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/k1_lab.hip -Lhyperspectral_super-resolution_amd/lib -lhsr_mi355x \
+//         -Wl,-rpath,'$ORIGIN/../hyperspectral_super-resolution_amd/lib' -o tools/k1_lab
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>

@@ -72,6 +72,8 @@ SIGNATURES = {
     "hsr_ot_iterate": (C.c_int, [_i64, _i64, _i32, _i32, _f64, _vp, _vp, _vp]),
     "hsr_ot_finish": (C.c_int, [_vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp]),
     "hsr_ot_sinkhorn_barycentric": (C.c_int, [_vp, _i64, _vp, _i64, _f64, _i32, _f64, _vp, _vp, _vp, _vp]),
+    "hsr_chol_work_bytes": (C.c_size_t, [_i32]),
+    "hsr_chol_solve_f64": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _vp, _vp, _vp]),
     "hsr_valid_mask": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _vp, _i64, _i64, _i32, _vp, _i64, _vp, _vp]),
     "hsr_polyfeat_count": (C.c_int, [_i32, _i32]),
     "hsr_polyfeat_table": (C.c_int, [_i32, _i32, _vp]),

@@ -68,8 +68,24 @@ class PolyRidge:
     def __init__(self, degree: int = 3, alpha: float = 1.0):
         self.degree, self.alpha = int(degree), float(alpha)
         self.n_in = self.n_feat = self.n_targets = 0
-        self.mean_ = self.scale_ = self.coef_ = self.intercept_ = None     # float64 host copies (sklearn names)
         self._dev = {}
+        self._fit64 = None     # float64 device tensors of the last fit: (mean, scale, W (nf, T), intercept)
+        self._host = None      # their host copies, made on first access of mean_ / scale_ / coef_ / intercept_
+
+    # scikit-learn's attribute names, float64 NumPy arrays.  They are copied from the device on first use, so that
+    # fit() itself never synchronises with the host (it is ~0.4 ms of enqueued GPU work).
+    def _host_copy(self):
+        if self._fit64 is None:
+            return (None, None, None, None)
+        if self._host is None:
+            mean, scale, Wm, b = self._fit64
+            self._host = (mean.cpu().numpy(), scale.cpu().numpy(), Wm.t().contiguous().cpu().numpy(), b.cpu().numpy())
+        return self._host
+
+    mean_ = property(lambda self: self._host_copy()[0])
+    scale_ = property(lambda self: self._host_copy()[1])
+    coef_ = property(lambda self: self._host_copy()[2])
+    intercept_ = property(lambda self: self._host_copy()[3])
 
     # ---- fit --------------------------------------------------------------------------------------
     # The fit is a sum over pixels twice over (scaler statistics, then the Gram matrix), so it shards by
@@ -132,8 +148,10 @@ class PolyRidge:
         G = torch.zeros((na, na + tp), dtype=torch.float64, device=Xd.device)
         if n == 0:
             return G
-        Q = torch.zeros((n, na + tp), dtype=torch.float64, device=Xd.device)    # [P | Y | 0]
+        Q = torch.empty((n, na + tp), dtype=torch.float64, device=Xd.device)    # [P | Y | 0]; expand fills [0, na)
         Q[:, na:na + T] = Yd
+        if tp > T:
+            Q[:, na + T:].zero_()
         nat.check(lib.hsr_polyfeat_expand_f64(_ptr(Xd), Xd.stride(0), Xd.stride(1) if n_in > 1 else 1, _ptr(mean),
                                               _ptr(scale), n, n_in, self.degree, _ptr(Q), Q.stride(0), na,
                                               _stream(torch)), "hsr_polyfeat_expand_f64")
@@ -153,13 +171,22 @@ class PolyRidge:
         ybar = G[0, na:na + T] / cnt
         Gc = G[1:nf + 1, 1:nf + 1] - torch.outer(s, s) / cnt
         rhs = G[1:nf + 1, na:na + T] - torch.outer(s, ybar)
-        Gc = Gc + self.alpha * torch.eye(nf, dtype=torch.float64, device=G.device)
-        L = torch.linalg.cholesky(Gc)
-        Wm = torch.cholesky_solve(rhs, L)               # (nf, T)
+        # (Gc + alpha I) W = rhs by the library's Cholesky (csrc/hsr_chol.hip); padded to a multiple of 32 with an
+        # identity block and zero right-hand-side rows, which leaves the solution untouched
+        npad = (nf + 31) // 32 * 32
+        Gp = torch.eye(npad, dtype=torch.float64, device=G.device)
+        Gp[:nf, :nf] = Gc
+        Gp[:nf, :nf].diagonal().add_(self.alpha)
+        Bp = torch.zeros((npad, T), dtype=torch.float64, device=G.device)
+        Bp[:nf] = rhs
+        self._chol_info = torch.zeros(1, dtype=torch.int32, device=G.device)   # 0, or the first non-positive pivot
+        cwork = torch.empty(lib.hsr_chol_work_bytes(npad) // 8, dtype=torch.float64, device=G.device)
+        nat.check(lib.hsr_chol_solve_f64(_ptr(Gp), Gp.stride(0), npad, _ptr(Bp), Bp.stride(0), T, _ptr(cwork),
+                                         _ptr(self._chol_info), _stream(torch)), "hsr_chol_solve_f64")
+        Wm = Bp[:nf]                                     # (nf, T)
         b = ybar - (s / cnt) @ Wm
         self.n_in, self.n_feat, self.n_targets = n_in, nf, T
-        self.mean_, self.scale_ = mean.cpu().numpy(), scale.cpu().numpy()
-        self.coef_, self.intercept_ = Wm.t().contiguous().cpu().numpy(), b.cpu().numpy()
+        self._fit64, self._host = (mean, scale, Wm, b), None
         kpad = (nf + 1) // 2 * 2
         Wf = torch.zeros((kpad, T), dtype=torch.float32, device=G.device)
         Wf[:nf] = Wm.float()

@@ -246,6 +246,16 @@ int hsr_polyfeat_expand_f64(const float* x_dev, int64_t x_rs, int64_t x_cs, cons
 size_t hsr_gram_work_bytes(int32_t na, int32_t nb, int64_t n);
 int hsr_gram_f64(const double* a_dev, int64_t lda, int32_t na, const double* b_dev, int64_t ldb, int32_t nb,
                  int64_t n, double* work_dev, double* c_dev, int64_t ldc, hsr_stream_t stream);
+/* Cholesky solve of the ridge system (Phi_c^T Phi_c + alpha I) W = Phi_c^T Y_c of the fit
+ * (legacy_notebooks/Spectral_matching.ipynb raw lines 475-490: Ridge(alpha=1), solver 'cholesky' semantics):
+ * a_dev (n, lda) float64 symmetric positive definite - its lower triangle is overwritten by the factor L -,
+ * b_dev (n, ldb) holds nrhs right-hand sides in its columns and is overwritten by the solution.  n must be a
+ * multiple of 32 in [32, 512]: pad with an identity block and zero right-hand-side rows.  *info_dev = 0, or the
+ * 1-based index of the first non-positive pivot (LAPACK potrf convention); asynchronous like everything else. */
+size_t hsr_chol_work_bytes(int32_t n);   /* workspace: the inverses of the 32 x 32 diagonal blocks of L */
+int hsr_chol_solve_f64(double* a_dev, int64_t lda, int32_t n, double* b_dev, int64_t ldb, int32_t nrhs,
+                       double* work_dev, int32_t* info_dev, hsr_stream_t stream);
+
 /* out[t * out_stride + p] = act(sum_f W[f][t] * phi_f((x_p - mean) * inv_scale) + bias[t]) with the features
  * expanded on chip (v_mfma_f32_32x32x2_f32); W (count rounded up to even rows, ldw) float32 with zero rows past
  * count; activation 1 = sigmoid(clip(z, -50, 50)) (notebook raw lines 178-181), 0 = identity. */

@@ -1238,3 +1238,48 @@ def test_ot_sampling_on_device_matches_host_rows(torch_gpu):
     few = np.zeros((61, 47), bool)
     few[0, :50] = True
     assert _ot.sample_pairs_device(torch.from_numpy(src).cuda(), torch.from_numpy(ref).cuda(), torch.from_numpy(few).cuda(), 500, 0, 200) is None
+
+
+def test_chol_solve_vs_numpy(torch_gpu):
+    """hsr_chol_solve_f64 (single-workgroup blocked Cholesky + per-column substitution) against numpy.linalg.solve
+    on random SPD systems of the supported sizes, and LAPACK's info convention on an indefinite matrix."""
+    torch = torch_gpu
+    from s2_emit import _native as nat
+    from s2_emit._engine import _ptr, _stream
+    lib = nat.load()
+    rng = np.random.default_rng(23)
+    for n, T in ((32, 1), (96, 5), (288, 32), (288, 285), (512, 7), (64, 4)):
+        M = rng.standard_normal((n, n + 40))
+        A = M @ M.T / n + 0.5 * np.eye(n)
+        Bm = rng.standard_normal((n, T))
+        Ad, Bd = torch.from_numpy(A.copy()).cuda(), torch.from_numpy(Bm.copy()).cuda()
+        info = torch.full((1,), -5, dtype=torch.int32, device="cuda")
+        cw = torch.empty(lib.hsr_chol_work_bytes(n) // 8, dtype=torch.float64, device="cuda")
+        nat.check(lib.hsr_chol_solve_f64(_ptr(Ad), n, n, _ptr(Bd), T, T, _ptr(cw), _ptr(info), _stream(torch)))
+        assert int(info.item()) == 0
+        X = np.linalg.solve(A, Bm)
+        np.testing.assert_allclose(Bd.cpu().numpy(), X, rtol=1e-9, atol=1e-11)
+        Lg = np.tril(Ad.cpu().numpy())
+        np.testing.assert_allclose(Lg, np.linalg.cholesky(A), rtol=1e-10, atol=1e-12)
+    # leading dimensions larger than the matrix / the right-hand sides
+    n, T = 64, 3
+    M = rng.standard_normal((n, 2 * n))
+    A = M @ M.T / n + np.eye(n)
+    Bm = rng.standard_normal((n, T))
+    Abig = torch.zeros((n, n + 7), dtype=torch.float64, device="cuda")
+    Abig[:, :n] = torch.from_numpy(A).cuda()
+    Bbig = torch.zeros((n, T + 2), dtype=torch.float64, device="cuda")
+    Bbig[:, :T] = torch.from_numpy(Bm).cuda()
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    cw = torch.empty(lib.hsr_chol_work_bytes(512) // 8, dtype=torch.float64, device="cuda")
+    nat.check(lib.hsr_chol_solve_f64(_ptr(Abig), n + 7, n, _ptr(Bbig), T + 2, T, _ptr(cw), _ptr(info), _stream(torch)))
+    np.testing.assert_allclose(Bbig[:, :T].cpu().numpy(), np.linalg.solve(A, Bm), rtol=1e-9, atol=1e-11)
+    assert float(Bbig[:, T:].abs().max()) == 0.0
+    # not positive definite: first bad pivot reported (1-based), nothing raised on the device
+    Ai = np.eye(64)
+    Ai[40, 40] = -1.0
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    Aid, Bid = torch.from_numpy(Ai).cuda(), torch.zeros((64, 1), dtype=torch.float64, device="cuda")   # keep them alive
+    nat.check(lib.hsr_chol_solve_f64(_ptr(Aid), 64, 64, _ptr(Bid), 1, 1, _ptr(cw), _ptr(info), _stream(torch)))
+    assert int(info.item()) == 41
+    assert lib.hsr_chol_solve_f64(_ptr(Abig), n + 7, 40, _ptr(Bbig), T + 2, T, _ptr(cw), _ptr(info), _stream(torch)) == 2   # n % 32 != 0

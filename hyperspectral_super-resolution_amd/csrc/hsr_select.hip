@@ -87,8 +87,10 @@ __device__ __forceinline__ void hist_sample(uint32_t* h, uint32_t* nanc, const u
 // VEC: band-major planes whose rows start 16-byte aligned (and a 4-byte aligned mask): 4 samples + 4 mask bytes
 // per load, two loads in flight per thread.  The first version walked the plane sample by sample behind a
 // dependent mask-byte load and ran at 1.4 TB/s.
-template <int PASS, bool VEC>
+// MODE 0: any strides, one sample per load.  MODE 1: VEC above.  (Band-last rows of 4 floats: select_hist_rows4_kernel.)
+template <int PASS, int MODE>
 __global__ __launch_bounds__(256) void select_hist_kernel(const SelArgs a) {
+  constexpr bool VEC = MODE == 1;
   constexpr int NB = PASS == 1 ? kBins1 : (PASS == 2 ? kBins2 * kQ : kBins3 * kQ);
   __shared__ uint32_t h[NB];
   __shared__ uint32_t nanc;
@@ -152,6 +154,76 @@ __global__ __launch_bounds__(256) void select_hist_kernel(const SelArgs a) {
   for (int i = threadIdx.x; i < NB; i += 256)
     if (h[i]) atomicAdd(&g[i], h[i]);
   if (PASS == 1 && threadIdx.x == 0 && nanc) atomicAdd(&a.hist1[(size_t)c * kHist1 + kBins1], nanc);
+}
+
+// Band-last rows of exactly 4 floats (the RGB + pad images of the driver): ONE pass over the image per radix pass
+// for all channels - a 16-byte load per pixel, the histograms of all nb <= 4 channels side by side in LDS (24 / 96 /
+// 48 KB for three channels).  Walking the image once per channel, sample by sample (MODE 0), ran at ~1.1 TB/s on the
+// 6144 x 6144 x 4 image and was half of match_pair's time; loading whole rows once per channel was worse still
+// (the channel passes do not share L2 lines in time: 3x the traffic).
+template <int PASS>
+__global__ __launch_bounds__(512) void select_hist_rows4_kernel(const SelArgs a) {
+  constexpr int NB = PASS == 1 ? kBins1 : (PASS == 2 ? kBins2 * kQ : kBins3 * kQ);
+  extern __shared__ uint32_t hall[];          // [nb][NB]
+  __shared__ uint32_t nanc[4];
+  __shared__ uint32_t pre_s[4][kQ];
+  const int nb = a.nb;
+  for (int i = threadIdx.x; i < nb * NB; i += 512) hall[i] = 0u;
+  if (threadIdx.x < 4) nanc[threadIdx.x] = 0u;
+  if (PASS > 1 && threadIdx.x < nb * kQ) pre_s[threadIdx.x / kQ][threadIdx.x % kQ] = a.state[threadIdx.x / kQ].prefix[threadIdx.x % kQ];
+  __syncthreads();
+  uint32_t pre[4][kQ];
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int q = 0; q < kQ; ++q) pre[c][q] = (PASS > 1 && c < nb) ? pre_s[c][q] : 0u;
+  const float4* rows = reinterpret_cast<const float4*>(a.x);
+  constexpr int U = 4;
+  const int64_t stride = (int64_t)gridDim.x * 512;
+  const int64_t first = (int64_t)blockIdx.x * 512 + (threadIdx.x & ~63);
+  for (int64_t base = first; base < a.npix; base += U * stride) {   // wave-uniform trip count (ballots inside)
+    float4 v[U];
+    bool on[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const int64_t p = base + u * stride + (threadIdx.x & 63);
+      on[u] = p < a.npix;
+      const int64_t pc = on[u] ? p : 0;
+      v[u] = ld_stream(rows + pc);
+      if (a.mask) on[u] = on[u] && a.mask[pc] != 0;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+      for (int c = 0; c < 4; ++c)
+        if (c < nb) hist_sample<PASS>(hall + c * NB, &nanc[c], pre[c], e[c], on[u]);   // c < nb is block-uniform
+    }
+  }
+  __syncthreads();
+  for (int c = 0; c < nb; ++c) {
+    uint32_t* g = PASS == 1 ? a.hist1 + (size_t)c * kHist1
+                            : (PASS == 2 ? a.hist2 + (size_t)c * kQ * kBins2 : a.hist3 + (size_t)c * kQ * kBins3);
+    for (int i = threadIdx.x; i < NB; i += 512)
+      if (hall[c * NB + i]) atomicAdd(&g[i], hall[c * NB + i]);
+    if (PASS == 1 && threadIdx.x == 0 && nanc[c]) atomicAdd(&a.hist1[(size_t)c * kHist1 + kBins1], nanc[c]);
+  }
+}
+
+template <int PASS>
+static void launch_rows4(const SelArgs& a, hipStream_t s) {
+  constexpr int NB = PASS == 1 ? kBins1 : (PASS == 2 ? kBins2 * kQ : kBins3 * kQ);
+  const size_t lds = (size_t)a.nb * NB * sizeof(uint32_t);
+  static thread_local size_t configured = 0;
+  if (lds > configured) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(select_hist_rows4_kernel<PASS>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              (int)lds);
+    (void)hipGetLastError();
+    configured = lds;
+  }
+  int64_t gx = (a.npix + 512 * 4 - 1) / (512 * 4);
+  if (gx > 1024) gx = 1024;
+  hipLaunchKernelGGL(select_hist_rows4_kernel<PASS>, dim3((unsigned)gx), dim3(512), lds, s, a);
 }
 
 // Locate, for one histogram of `nbins` (multiple of 256) bins, the bin holding 0-based rank r:
@@ -344,14 +416,19 @@ extern "C" int hsr_percentile_hist(int32_t pass, const float* x_dev, int64_t x_b
   const dim3 grid = select_grid(npix, nb), block(256);
   // band-major planes with 16-byte aligned rows (and a 4-byte aligned mask) take the 4-samples-per-load path
   const bool vec = x_ps == 1 && (x_bs & 3) == 0 && (((uintptr_t)x_dev) & 15) == 0 && (((uintptr_t)mask_dev) & 3) == 0;
+  const bool rows4 = x_bs == 1 && x_ps == 4 && nb <= 4 && (((uintptr_t)x_dev) & 15) == 0;
   if (vec) {
-    if (pass == 1) hipLaunchKernelGGL((select_hist_kernel<1, true>), grid, block, 0, s, a);
-    else if (pass == 2) hipLaunchKernelGGL((select_hist_kernel<2, true>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((select_hist_kernel<3, true>), grid, block, 0, s, a);
+    if (pass == 1) hipLaunchKernelGGL((select_hist_kernel<1, 1>), grid, block, 0, s, a);
+    else if (pass == 2) hipLaunchKernelGGL((select_hist_kernel<2, 1>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((select_hist_kernel<3, 1>), grid, block, 0, s, a);
+  } else if (rows4) {
+    if (pass == 1) launch_rows4<1>(a, s);
+    else if (pass == 2) launch_rows4<2>(a, s);
+    else launch_rows4<3>(a, s);
   } else {
-    if (pass == 1) hipLaunchKernelGGL((select_hist_kernel<1, false>), grid, block, 0, s, a);
-    else if (pass == 2) hipLaunchKernelGGL((select_hist_kernel<2, false>), grid, block, 0, s, a);
-    else hipLaunchKernelGGL((select_hist_kernel<3, false>), grid, block, 0, s, a);
+    if (pass == 1) hipLaunchKernelGGL((select_hist_kernel<1, 0>), grid, block, 0, s, a);
+    else if (pass == 2) hipLaunchKernelGGL((select_hist_kernel<2, 0>), grid, block, 0, s, a);
+    else hipLaunchKernelGGL((select_hist_kernel<3, 0>), grid, block, 0, s, a);
   }
   HSR_LAUNCH_CHECK("select_hist_kernel");
   return HSR_OK;

@@ -51,6 +51,11 @@ for name, n in (("1024^2", Hc * Wc), ("6144^2", Hf * Wf)):
     lohi = eng.percentile_limits(x, m, 2, 98)
     ms = timed(lambda: eng.poly_apply_stretch_only(x, lohi))
     row(f"stretch (K3 without polynomial) 3 planes {name}", ms, 2 * 3 * n * 4)
+for name, n in (("1024^2", Hc * Wc), ("6144^2", Hf * Wf)):
+    xr = torch.rand((n, 4), device=dev)
+    m = (torch.rand(n, device=dev) > 0.1).to(torch.uint8)
+    ms = timed(lambda: eng.percentile_limits(xr, m, 2, 98, "pixmajor", nb=3))
+    row(f"percentile_limits band-last rows of 4 (3 channels) {name}", ms, 3 * n * 17, "3 passes x (16 B row + 1 B mask)")
 x12 = torch.rand((Hc * Wc, 12), device=dev)
 y3 = torch.rand((Hc * Wc, 3), device=dev)
 ms = timed(lambda: eng.valid_mask(x12, 0, y3, None, "pixmajor"))

@@ -124,16 +124,35 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
-        if args.backend == "nccl":
-            dist.init_process_group("nccl", device_id=device)     # "nccl" is RCCL on ROCm
+    if args.force_exchange and world != 1:
+        raise SystemExit("--force-exchange is a one-process rehearsal")
+    backend_note = ""
+    if world > 1 or args.force_exchange:
+        def rccl_options():
+            # RCCL's internal stream must not share a hardware queue with the stream K1 runs on (streams of the default
+            # priority did, on this stack): ask for the high-priority stream
+            opts = dist.ProcessGroupNCCL.Options()
+            opts.is_high_priority_stream = True
+            return opts
+        if args.force_exchange:
+            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29531", rank=0, world_size=1, device_id=device,
+                                    pg_options=rccl_options())
+        elif args.backend == "nccl":
+            try:
+                dist.init_process_group("nccl", device_id=device, pg_options=rccl_options())     # "nccl" is RCCL on ROCm
+                probe = torch.ones(1, device=device)
+                dist.all_reduce(probe)                                 # the communicator really works, on every rank
+                torch.cuda.synchronize()
+                if int(probe.item()) != world:
+                    raise RuntimeError(f"all-reduce of ones gave {probe.item()} on {world} ranks")
+            except Exception as exc:       # keep the scaling run alive: gloo moves the 1 KB of moments through the host
+                sys.stderr.write(f"[bench] RCCL unusable ({exc!r}); falling back to gloo for the exchange\n")
+                if dist.is_initialized():
+                    dist.destroy_process_group()
+                dist.init_process_group("gloo")
+                backend_note = f" (fallback to gloo after RCCL error: {type(exc).__name__})"
         else:
             dist.init_process_group("gloo")
-
-    if args.force_exchange:
-        if world != 1:
-            raise SystemExit("--force-exchange is a one-process rehearsal")
-        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29531", rank=0, world_size=1, device_id=device)
 
     H, W, B = args.height, args.width, args.bands
     prob = device_problem(H, W, B, deg=args.deg, seed=rank, device=device)
@@ -222,7 +241,8 @@ def main():
                            "tiles_per_gpu": 1, "coeff_sync": (args.coeff_sync if world > 1 else "none") +
                            (f" (rehearsal: one-rank RCCL {args.coeff_sync} forced)" if args.force_exchange else ""),
                            "pipeline": f"one tile deep, {args.reserve_cus} CUs reserved" if pipelined else "off",
-                           "backend": (args.backend if world > 1 else "none") + (" (rehearsal: all ranks on cuda:0)" if args.same_device else "")},
+                           "backend": (args.backend if world > 1 else "none") + backend_note +
+                           (" (rehearsal: all ranks on cuda:0)" if args.same_device else "")},
                 "roofline": roof}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args)

@@ -58,6 +58,8 @@ def parse_args():
                     help="one-tile-deep software pipeline (exchange of tile i under K1 of tile i+1); auto = on for N > 1")
     ap.add_argument("--reserve-cus", type=int, default=8,
                     help="CUs left free of persistent K1 workgroups in pipelined mode (side-stream tail of the previous tile)")
+    ap.add_argument("--simulate-rccl-failure", action="store_true",
+                    help="rehearsal only: raise inside the RCCL set-up to exercise the gloo fallback")
     ap.add_argument("--force-exchange", action="store_true",
                     help="rehearsal only (N = 1): create a one-rank RCCL group and run the multi-GPU code path - "
                          "pipelined submit() with the collective on the side stream - to measure its launch cost on one GPU")
@@ -119,7 +121,7 @@ def main():
     if args.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if args.same_device:
-        if args.backend != "gloo":
+        if args.backend != "gloo" and not args.simulate_rccl_failure:
             raise SystemExit("--same-device is a rehearsal mode and needs --backend gloo (RCCL wants one GPU per rank)")
         local_rank = 0
     torch.cuda.set_device(local_rank)
@@ -139,6 +141,8 @@ def main():
                                     pg_options=rccl_options())
         elif args.backend == "nccl":
             try:
+                if args.simulate_rccl_failure:
+                    raise RuntimeError("simulated")
                 dist.init_process_group("nccl", device_id=device, pg_options=rccl_options())     # "nccl" is RCCL on ROCm
                 probe = torch.ones(1, device=device)
                 dist.all_reduce(probe)                                 # the communicator really works, on every rank

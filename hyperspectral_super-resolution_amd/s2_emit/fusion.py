@@ -168,6 +168,42 @@ class SpectralFusion:
         return FusionOutput(self.names, pseudo, moments, coeffs, matched, self.layout)
 
 
+    # ---- one fit over several tiles on one GPU --------------------------------------------------------
+    def fuse_mosaic(self, tiles, masks=None):
+        """Global fit over a mosaic held by ONE GPU (BASELINE configs[4] on a single device, and the single-process
+        twin of the multi-GPU step): K1+K2 per tile, the per-tile moments added in tile order, one solve (plus the
+        exchange when a process group is active, so that ranks holding several tiles each still fit one polynomial),
+        K3 per tile.  ``tiles``: sequence of (cube, real) GPU tensors as in step(); ``masks`` optional sequence.
+        Returns (coeffs (nb, deg+1), moments, [FusionOutput per tile]) - the outputs own their buffers."""
+        torch = nat.require_gpu()
+        tiles = list(tiles)
+        if not tiles:
+            raise ValueError("fuse_mosaic needs at least one tile")
+        masks = list(masks) if masks is not None else [None] * len(tiles)
+        if len(masks) != len(tiles):
+            raise ValueError("masks must match tiles")
+        total = None
+        pseudos = []
+        for (cube, real), mask in zip(tiles, masks):
+            npix = cube.numel() // cube.shape[-1]
+            real2, real_layout = self._real_image(real, npix)
+            pseudo, mom = eng.srf_integrate_moments(cube, self.table, real2, self.deg, self.ws, mask, self.min_valid,
+                                                    self.min_valid, out=None, reduce=True, layout=self.layout,
+                                                    real_layout=real_layout, scale=self.tile_scale, nodata=self.tile_nodata)
+            total = mom.clone() if total is None else total + mom          # tile order: a fixed summation order
+            pseudos.append(pseudo)
+        if self._exchanges():
+            total, coeffs = exchange_moments(total, self._solve, self.group, self.coeff_sync)
+            coeffs = coeffs.clone()                    # _solve writes into the plan's workspace
+        else:
+            coeffs = eng.poly_solve(total, self.deg, self.min_count)
+        outs = []
+        for pseudo, mask in zip(pseudos, masks):
+            matched = eng.poly_apply(pseudo, coeffs, mask if self.apply_mask else None, None, self.clip, self.layout,
+                                     nb=self.table.nb)
+            outs.append(FusionOutput(self.names, pseudo, total, coeffs, matched, self.layout))
+        return coeffs, total, outs
+
     # ---- host -> device tile feed -------------------------------------------------------------------
     # SURVEY.md 8-f3: once K1 runs at TB/s the host -> device feed of the 1.2 GB cube is the bottleneck of an
     # end-to-end run over tiles that live in host memory (the reference reads them from GeoTIFF / ENVI files).

@@ -1283,3 +1283,37 @@ def test_chol_solve_vs_numpy(torch_gpu):
     nat.check(lib.hsr_chol_solve_f64(_ptr(Aid), 64, 64, _ptr(Bid), 1, 1, _ptr(cw), _ptr(info), _stream(torch)))
     assert int(info.item()) == 41
     assert lib.hsr_chol_solve_f64(_ptr(Abig), n + 7, 40, _ptr(Bbig), T + 2, T, _ptr(cw), _ptr(info), _stream(torch)) == 2   # n % 32 != 0
+
+
+def test_fuse_mosaic_equals_one_big_tile(torch_gpu):
+    """A global fit over several tiles of different sizes on one GPU (moments added in tile order, one solve, K3 per
+    tile) is the fit of the tiles laid end to end."""
+    torch = torch_gpu
+    from s2_emit import SpectralFusion
+    srf = onp.synthetic_srf()
+    w, good = onp.synthetic_wavelengths()
+    plan = SpectralFusion(w, srf, good, deg=3, coeff_sync="local")
+    tiles, cubes, reals = [], [], []
+    for i, (H, W) in enumerate(((40, 36), (64, 20), (17, 90))):
+        R = onp.synthetic_cube(H, W, seed=300 + i)
+        ps = onp.pseudo_s2_srf_integral(R, w, srf, good)
+        real = onp.synthetic_real_planes(np.stack([ps[k] for k in plan.names]).astype(np.float32), seed=i)
+        real = np.clip(real + 0.02 * i, 0, 1).astype(np.float32)
+        tiles.append((torch.from_numpy(R).cuda(), torch.from_numpy(real).cuda()))
+        cubes.append(R.reshape(-1, R.shape[-1]))
+        reals.append(real.reshape(real.shape[0], -1))
+    coeffs, moments, outs = plan.fuse_mosaic(tiles)
+    big = plan.step(torch.from_numpy(np.concatenate(cubes, 0)).cuda(), torch.from_numpy(np.concatenate(reals, 1)).cuda(),
+                    reuse_buffers=False)
+    np.testing.assert_allclose(moments.cpu().numpy(), big.moments.cpu().numpy(), rtol=1e-12)
+    xs = np.linspace(0.0, 0.6, 40)
+    for b in range(coeffs.shape[0]):
+        np.testing.assert_allclose(np.polyval(coeffs[b].cpu().numpy(), xs), np.polyval(big.coeffs[b].cpu().numpy(), xs),
+                                   rtol=1e-6, atol=1e-9)
+    got = np.concatenate([o.matched.cpu().numpy() for o in outs], 0)
+    np.testing.assert_allclose(got[:, :len(plan.names)], big.matched.cpu().numpy()[:, :len(plan.names)], rtol=0, atol=1e-6)
+    # and differs from per-tile fits (the tiles do not share one polynomial)
+    solo = plan.step(*tiles[2], reuse_buffers=False)
+    assert not torch.allclose(solo.coeffs, coeffs)
+    with pytest.raises(ValueError):
+        plan.fuse_mosaic([])

@@ -7,8 +7,6 @@ names are API surface kept for drop-in use: plain host NumPy, 
 """
 from __future__ import annotations
 
-from typing import Optional
-
 import numpy as np
 
 from . import _engine as eng

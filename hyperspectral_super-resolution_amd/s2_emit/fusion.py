@@ -16,7 +16,7 @@ rank owns whole spatial tiles and only (nb x (3deg+2)) doubles cross the fabric 
 from __future__ import annotations
 
 from dataclasses import dataclass
-from typing import Dict, List, Optional, Sequence, Tuple
+from typing import Dict, List, Optional, Tuple
 
 import numpy as np
 

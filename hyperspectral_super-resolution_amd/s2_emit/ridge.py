@@ -10,7 +10,6 @@ the prediction is one fused expand + float32-MFMA + sigmoid kernel (``hsr_polyfe
 """
 from __future__ import annotations
 
-import ctypes as C
 from typing import Optional
 
 import numpy as np

@@ -23,7 +23,7 @@ third-party arithmetic (requirements.txt:3) and are called directly, exactly as 
 from __future__ import annotations
 
 from itertools import combinations_with_replacement
-from typing import Dict, Optional, Sequence, Tuple
+from typing import Dict, Optional, Tuple
 
 import numpy as np
 

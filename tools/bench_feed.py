@@ -3,7 +3,7 @@ pinned host memory (1024 x 1024 x 285 tiles, deg 3).  H2D of tile i+1 overlaps K
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "hyperspectral_super-resolution_amd"))
-import numpy as np, torch
+import torch
 from s2_emit import SpectralFusion, _engine as eng
 from s2_emit.synthetic import device_problem
 

@@ -8,7 +8,6 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "hyperspectral_super-resolution_amd"))
 
-import numpy as np
 import torch
 import s2_emit
 

@@ -1317,3 +1317,36 @@ def test_fuse_mosaic_equals_one_big_tile(torch_gpu):
     assert not torch.allclose(solo.coeffs, coeffs)
     with pytest.raises(ValueError):
         plan.fuse_mosaic([])
+
+
+def test_u16_single_buffer_kernel_matches_ring(torch_gpu):
+    """The single-buffer uint16 K1 (taken when two tile buffers do not fit, or with the ring switched off) gives the
+    same bits as the double-buffered one; B = 400 does not fit the ring at all and must still be right."""
+    torch = torch_gpu
+    from s2_emit import _engine as eng, _native as nat
+    srf = onp.synthetic_srf()
+    w, good = onp.synthetic_wavelengths()
+    table = eng.build_srf_table(w, srf, good)
+    rng = np.random.default_rng(8)
+    u = rng.integers(0, 6000, (64 * 30 + 17, 285)).astype(np.uint16)
+    u[5, 5] = 65535
+    ud = torch.from_numpy(u).cuda()
+    real = torch.rand((table.nb, u.shape[0]), device="cuda")
+    res = []
+    try:
+        for ring in (1, 0):
+            nat.check(nat.load().hsr_set_srf_u16_ring(ring))
+            ws = eng.MomentWorkspace("cuda", table.nb, 3)
+            p, m = eng.srf_integrate_moments(ud, table, real, 3, ws, None, 0.0, 0.0, layout="pixmajor", real_layout="planar")
+            res.append((p[:, :table.nb].cpu().numpy(), m.cpu().numpy().copy()))
+    finally:
+        nat.check(nat.load().hsr_set_srf_u16_ring(1))
+    np.testing.assert_array_equal(res[0][0], res[1][0])
+    np.testing.assert_array_equal(res[0][1], res[1][1])
+    B = 400
+    w4 = np.linspace(400, 2400, B).astype(np.float32)
+    t4 = eng.build_srf_table(w4, srf, None)
+    u4 = rng.integers(0, 6000, (64 * 5, B)).astype(np.uint16)
+    a = eng.srf_integrate(torch.from_numpy(u4).cuda(), t4, layout="planar")
+    b = eng.srf_integrate(eng.tile_decode_u16(torch.from_numpy(u4).cuda()), t4, layout="planar")
+    np.testing.assert_array_equal(a.cpu().numpy(), b.cpu().numpy())

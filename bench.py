@@ -46,7 +46,16 @@ def parse_args():
     ap.add_argument("--bands", type=int, default=285)
     ap.add_argument("--deg", type=int, default=3)
     ap.add_argument("--coeff-sync", default="allreduce", choices=["local", "allreduce", "broadcast"])
-    ap.add_argument("--cpu-rows", type=int, default=1024, help="rows of the cube the CPU baseline processes")
+    ap.add_argument("--cpu-rows", type=int, default=256,
+                    help="rows of the cube the single-thread CPU baseline processes (the all-cores run takes the whole cube)")
+    ap.add_argument("--cpu-workers", type=int, default=0,
+                    help="processes of the row-sharded all-cores CPU run (0 = min(16, os.cpu_count()): a 1-GPU box's CPU share)")
+    ap.add_argument("--tiles-per-gpu", type=int, default=1,
+                    help="tiles resident per GPU; > 1 runs the mosaic step (K1+K2 per tile, ONE fit over all tiles of all "
+                         "ranks, K3 per tile): BASELINE configs[3]/[4] (4 / 8 tiles) on however many GPUs there are")
+    ap.add_argument("--k1-launches", type=int, default=24,
+                    help="extra event-bracketed launches of the K1+K2 kernel after the timed region, so that roofline.frac "
+                         "rests on >= 20 launches whatever --steps is")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-probe", action="store_true")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
@@ -58,8 +67,6 @@ def parse_args():
                     help="one-tile-deep software pipeline (exchange of tile i under K1 of tile i+1); auto = on for N > 1")
     ap.add_argument("--reserve-cus", type=int, default=8,
                     help="CUs left free of persistent K1 workgroups in pipelined mode (side-stream tail of the previous tile)")
-    ap.add_argument("--simulate-rccl-failure", action="store_true",
-                    help="rehearsal only: raise inside the RCCL set-up to exercise the gloo fallback")
     ap.add_argument("--force-exchange", action="store_true",
                     help="rehearsal only (N = 1): create a one-rank RCCL group and run the multi-GPU code path - "
                          "pipelined submit() with the collective on the side stream - to measure its launch cost on one GPU")
@@ -83,52 +90,120 @@ def _claim_stdout() -> int:
     return saved
 
 
-def cpu_baseline(args):
-    """Oracle ('port' of the reference's NumPy path) on a bounded slab: rows x W x B, same generator."""
+def _noop(_):
+    return os.getpid()
+
+
+def _cpu_slab(job):
+    """Worker of the all-cores CPU run: SRF integration (the reference's 13 float64 passes) of rows [r0, r1)."""
     import numpy as np
+    from multiprocessing import shared_memory
     from oracle import oracle_np as onp
-    rows = min(args.cpu_rows, args.height)
+    name, shape, r0, r1 = job
+    shm = shared_memory.SharedMemory(name=name)
+    try:
+        R = np.ndarray(shape, dtype=np.float32, buffer=shm.buf)[r0:r1]
+        srf = onp.synthetic_srf()
+        w, good = onp.synthetic_wavelengths(shape[2])
+        ps = onp.pseudo_s2_srf_integral(R, w, srf, good)
+        return r0, np.stack([v for v in ps.values() if v is not None]).astype(np.float32)      # poly_regression.py:104
+    finally:
+        shm.close()
+
+
+def start_cpu_pool(args):
+    """Fork the CPU workers BEFORE anything touches the GPU (a forked child of a process with a live HIP runtime is
+    not something to rely on); they sleep until cpu_baseline() hands them row slabs through shared memory."""
+    import multiprocessing as mp
+    from concurrent.futures import ProcessPoolExecutor
+    n = args.cpu_workers if args.cpu_workers > 0 else min(16, os.cpu_count() or 1)
+    pool = ProcessPoolExecutor(max_workers=n, mp_context=mp.get_context("fork"))
+    pids = set(pool.map(_noop, range(4 * n)))
+    return pool, n, len(pids)
+
+
+def cpu_baseline(args, pool, nworkers, cube_host, real_host, gpu_pseudo, gpu_matched):
+    """The oracle ('port' of the reference's NumPy path: 13 full-cube float64 SRF passes, np.polyfit, np.polyval) on the
+    SAME cube the GPU processed:
+      * single thread (NumPy elementwise is single-threaded: the reference's actual behaviour) on the first --cpu-rows rows;
+      * row-sharded over the host cores (ProcessPoolExecutor) on the whole cube, SURVEY.md 8(d) - its outputs are the
+        full-size parity reference for the GPU's pseudo / matched images (max_rel_err)."""
+    import numpy as np
+    from multiprocessing import shared_memory
+    from oracle import oracle_np as onp
+    H, W, B = cube_host.shape
     srf = onp.synthetic_srf()
-    w, good = onp.synthetic_wavelengths(args.bands)
-    R = onp.synthetic_cube(rows, args.width, args.bands, seed=0)
-    ps = onp.pseudo_s2_srf_integral(R[:4], w, srf, good)
-    names = [k for k, v in ps.items() if v is not None]
-    nb = len(names)
-    real = np.clip(np.random.default_rng(1).random((nb, rows, args.width)), 0.01, 1).astype(np.float32)
+    w, good = onp.synthetic_wavelengths(B)
+    rows = min(args.cpu_rows, H)
     t0 = time.perf_counter()
-    onp.fuse_lsq_reference(R, w, srf, good, real, args.deg)
-    dt = time.perf_counter() - t0
-    return {"value": rows * args.width * args.bands / dt / 1e6, "unit": "Mpixel*bands/s", "cores": 1,
-            "kind": "port", "host_cores": os.cpu_count(),
-            "sample": f"{rows}x{args.width}x{args.bands} row slab of the same synthetic cube, SRF (13 float64 passes) + "
-                      f"deg-{args.deg} np.polyfit per band + np.polyval apply, single-thread NumPy, {dt:.1f} s"}
+    onp.fuse_lsq_reference(cube_host[:rows], w, srf, good, real_host[:, :rows], args.deg)
+    dt1 = time.perf_counter() - t0
+    out = {"value": round(rows * W * B / dt1 / 1e6, 2), "unit": "Mpixel*bands/s", "cores": 1, "kind": "port",
+           "host_cores": os.cpu_count(),
+           "sample": f"first {rows} rows of the {H}x{W}x{B} cube the GPU processed: SRF (13 float64 passes) + deg-{args.deg} "
+                     f"np.polyfit per band + np.polyval apply, single-thread NumPy, {dt1:.1f} s"}
+    # all cores, whole cube
+    shm = shared_memory.SharedMemory(create=True, size=cube_host.nbytes)
+    try:
+        np.ndarray(cube_host.shape, dtype=np.float32, buffer=shm.buf)[...] = cube_host
+        slab = max(8, min(64, H // max(1, 2 * nworkers)))
+        jobs = [(shm.name, cube_host.shape, r0, min(H, r0 + slab)) for r0 in range(0, H, slab)]
+        t0 = time.perf_counter()
+        parts = dict(pool.map(_cpu_slab, jobs))
+        pseudo = np.concatenate([parts[r0] for r0 in sorted(parts)], axis=1)               # (nb, H, W) float32
+        valid = np.ones(pseudo.shape[1:], dtype=bool)
+        coeffs, _ = onp.fit_per_band_poly(pseudo, real_host, valid, args.deg, 0.0, 50)
+        matched = onp.apply_poly_planes(pseudo, coeffs, None, clip=True)
+        dtn = time.perf_counter() - t0
+    finally:
+        shm.close()
+        shm.unlink()
+    out["all_cores"] = {"value": round(H * W * B / dtn / 1e6, 1), "cores": nworkers, "seconds": round(dtn, 2),
+                        "sample": f"whole {H}x{W}x{B} cube, SRF row-sharded over {nworkers} processes ({slab}-row slabs), "
+                                  f"polyfit + polyval in the parent"}
+
+    def rel(got, ref):          # the tests' measure: |got - ref| / max(|ref|, 1e-3 max|ref|)
+        ref = ref.astype(np.float64)
+        scale = np.maximum(np.abs(ref), 1e-3 * np.abs(ref).max() + 1e-30)
+        return float(np.max(np.abs(got.astype(np.float64) - ref) / scale))
+    err = {"pseudo": rel(gpu_pseudo, pseudo), "matched": rel(gpu_matched, matched),
+           "pixels_checked": int(H * W), "reference": "oracle (all-cores run above), full size"}
+    return out, err
 
 
 def main():
     args = parse_args()
     real_stdout = _claim_stdout()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    want_cpu = world == 1 and rank == 0 and not args.no_cpu_baseline and args.tiles_per_gpu == 1 and args.cube == "f32"
+    pool = nworkers = None
+    if want_cpu:
+        pool, nworkers, _ = start_cpu_pool(args)          # forked before the GPU is initialised
     import torch
     import torch.distributed as dist
     from s2_emit import SpectralFusion
     from s2_emit import _engine as eng
     from s2_emit.synthetic import device_problem
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if args.gpus > 1 and world == 1:
         raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if args.same_device:
-        if args.backend != "gloo" and not args.simulate_rccl_failure:
+        if args.backend != "gloo":
             raise SystemExit("--same-device is a rehearsal mode and needs --backend gloo (RCCL wants one GPU per rank)")
         local_rank = 0
+    ndev = torch.cuda.device_count()           # does not initialise the GPU
+    if local_rank >= ndev:
+        raise SystemExit(f"[bench] rank {rank}: local rank {local_rank} needs cuda:{local_rank}, but only {ndev} device(s) are visible. "
+                         f"--gpus N needs N visible GPUs on this node (rehearse the control flow of more ranks than GPUs with "
+                         f"--backend gloo --same-device).")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if args.force_exchange and world != 1:
         raise SystemExit("--force-exchange is a one-process rehearsal")
-    backend_note = ""
     if world > 1 or args.force_exchange:
         def rccl_options():
             # RCCL's internal stream must not share a hardware queue with the stream K1 runs on (streams of the default
@@ -140,51 +215,47 @@ def main():
             dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29531", rank=0, world_size=1, device_id=device,
                                     pg_options=rccl_options())
         elif args.backend == "nccl":
-            try:
-                if args.simulate_rccl_failure:
-                    raise RuntimeError("simulated")
-                dist.init_process_group("nccl", device_id=device, pg_options=rccl_options())     # "nccl" is RCCL on ROCm
-                probe = torch.ones(1, device=device)
-                dist.all_reduce(probe)                                 # the communicator really works, on every rank
-                torch.cuda.synchronize()
-                if int(probe.item()) != world:
-                    raise RuntimeError(f"all-reduce of ones gave {probe.item()} on {world} ranks")
-            except Exception as exc:       # keep the scaling run alive: gloo moves the 1 KB of moments through the host
-                sys.stderr.write(f"[bench] RCCL unusable ({exc!r}); falling back to gloo for the exchange\n")
-                if dist.is_initialized():
-                    dist.destroy_process_group()
-                dist.init_process_group("gloo")
-                backend_note = f" (fallback to gloo after RCCL error: {type(exc).__name__})"
+            # No fallback: a backend chosen per rank after a partial RCCL failure would leave some ranks inside an RCCL
+            # collective and others in gloo (a hang), and a host-staged gloo number must not pass for an xGMI one.
+            dist.init_process_group("nccl", device_id=device, pg_options=rccl_options())     # "nccl" is RCCL on ROCm
+            probe = torch.ones(1, device=device)
+            dist.all_reduce(probe)                                 # the communicator really works, on every rank
+            torch.cuda.synchronize()
+            if int(probe.item()) != world:
+                raise SystemExit(f"[bench] RCCL all-reduce of ones gave {probe.item()} on {world} ranks")
         else:
             dist.init_process_group("gloo")
 
     H, W, B = args.height, args.width, args.bands
-    prob = device_problem(H, W, B, deg=args.deg, seed=rank, device=device)
+    ntl = max(1, args.tiles_per_gpu)
+    probs = [device_problem(H, W, B, deg=args.deg, seed=rank * ntl + i, device=device) for i in range(ntl)]
+    prob = probs[0]
+    pipelined = ntl == 1 and (args.pipeline == "on" or (args.pipeline == "auto" and (world > 1 or args.force_exchange)))
     plan = SpectralFusion(prob.emit_w, prob.srf, prob.good_mask, deg=args.deg, min_valid=0.0, min_count=50,
                           clip=True, device=device, group=None,
                           coeff_sync=args.coeff_sync if (world > 1 or args.force_exchange) else "local",
-                          force_exchange=args.force_exchange)
+                          force_exchange=args.force_exchange,
+                          reserved_cus=args.reserve_cus if pipelined else 0)   # CUs kept free for the side stream
     real = prob.real            # (H, W, row) band-last, like the cube and the reference's (H, W, C) images
     cube = prob.cube
     if args.cube == "u16":      # quantise once, outside the timed region (the writer's arithmetic, on the device)
-        cube = eng.tile_encode_u16(prob.cube)
-        prob.cube = None
+        for pr in probs:
+            pr.cube_u16 = eng.tile_encode_u16(pr.cube)
+            pr.cube = None
+        cube = prob.cube_u16
+    tiles = [((pr.cube_u16 if args.cube == "u16" else pr.cube), pr.real) for pr in probs]
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    pipelined = args.pipeline == "on" or (args.pipeline == "auto" and (world > 1 or args.force_exchange))
-    if pipelined:      # keep a few CUs free of persistent K1 workgroups for the side stream (fit kernels, RCCL, K3)
-        from s2_emit import _native as nat
-        nat.check(nat.load().hsr_set_srf_reserved_cus(args.reserve_cus))
-
     def run_step(k1_events=None):
+        if ntl > 1:
+            return plan.fuse_mosaic(tiles, k1_events=k1_events)
         if pipelined:
-            plan.submit(cube, real, k1_events=k1_events)
-        else:
-            plan.step(cube, real, k1_events=k1_events)
+            return plan.submit(cube, real, k1_events=k1_events)
+        return plan.step(cube, real, k1_events=k1_events)
 
     for _ in range(max(args.warmup, 1)):    # always one untimed pass: code-object load and LDS attributes are setup, not a step
         run_step()
@@ -209,22 +280,43 @@ def main():
     dt = time.perf_counter() - t0
     gc.enable()
 
-    k1_ms = sum(a.elapsed_time(b) for a, b in ev.values()) / max(1, len(ev))
+    # the same K1+K2 launch, event-bracketed every time, outside the timed region: >= 20 launches for roofline.frac
+    ev2 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(max(0, args.k1_launches))]
+    for pair in ev2:
+        out = run_step(pair)
+    if pipelined:
+        out = plan.flush()
+    else:
+        out = run_step()
+    barrier()
+    in_region = [a.elapsed_time(b) for a, b in ev.values()]
+    extra = [a.elapsed_time(b) for a, b in ev2]
+    k1_all = in_region + extra
+    k1_ms = sum(k1_all) / max(1, len(k1_all))
     tt = torch.tensor([dt], dtype=torch.float64, device=device)
     if world > 1:
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
     dt_max = float(tt.item())
 
     if rank == 0:
+        nb = len(prob.names)
         npb = H * W * B
-        value = world * npb * args.steps / dt_max / 1e6
-        cube_bytes = npb * (4 if args.cube == "f32" else 2)
+        value = world * ntl * npb * args.steps / dt_max / 1e6
+        esz = 4 if args.cube == "f32" else 2
+        cube_bytes = npb * esz
+        full_bytes = H * W * (esz * B + 16 * nb)        # + pseudo write, real read, apply read + write (no mask in this run)
         achieved = cube_bytes / (k1_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": "srf_kernel<deg,fast> (K1+K2 fused)" if args.cube == "f32" else "srf_u16_ring_kernel<deg> (K1+K2 fused, uint16 tile decode)", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": None, "algorithmic_bytes": cube_bytes, "kernel_ms": round(k1_ms, 4),
-                "kernel_launches_timed": len(ev),
-                "step_frac_of_peak": round(cube_bytes * args.steps / dt_max / 1e9 / HBM_PEAK_GBS, 4)}
+                "kernel_launches_timed": len(k1_all),
+                "kernel_ms_in_timed_region": round(sum(in_region) / max(1, len(in_region)), 4), "launches_in_timed_region": len(in_region),
+                "kernel_ms_after_region": round(sum(extra) / max(1, len(extra)), 4) if extra else None,
+                "agrees_with": "profiles/r02_kernel_stats.csv (rocprofv3 --kernel-trace --stats of this command): average duration of "
+                               "the srf_kernel / srf_u16_ring_kernel row; HIP-event brackets add ~10 us of record overhead per launch",
+                "step_frac_of_peak": round(ntl * cube_bytes * args.steps / dt_max / 1e9 / HBM_PEAK_GBS, 4),
+                "total_fraction": round(ntl * full_bytes * args.steps / dt_max / 1e9 / HBM_PEAK_GBS, 4),
+                "total_bytes_per_step": ntl * full_bytes}
         tf = os.path.join(ROOT, "profiles", "traffic.json")
         if os.path.isfile(tf):
             try:
@@ -233,23 +325,36 @@ def main():
             except Exception:
                 pass
         if not args.no_probe:
-            roof["measured_read_peak"] = round(eng.probe_read_bandwidth(1 << 30, 10, device) / 1e9, 1)
+            # ceiling of K1's own load shape on this box (non-temporal LDS-DMA, nothing computed) and a plain stream
+            roof["measured_read_peak"] = round(eng.probe_read_bandwidth(1 << 30, 10, device, mode=0) / 1e9, 1)
+            roof["measured_plain_read"] = round(eng.probe_read_bandwidth(1 << 30, 10, device, mode=1) / 1e9, 1)
+        degraded = world > 1 and args.backend != "nccl"
         line = {"metric": "Mpixel*bands/s fused (SRF + deg-%d per-band LSQ fit + apply)" % args.deg,
                 "value": round(value, 1), "unit": "Mpixel*bands/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": round(dt_max / args.steps * 1e3, 4),
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f32" if args.cube == "f32" else "u16->f32",
                 "data": "synthetic",
-                "config": {"workload": f"{H}x{W}x{B} EMIT-like cube{' stored as uint16 x 10000 tiles (decode fused into K1)' if args.cube == 'u16' else ''} + {len(prob.names)} real-S2 planes per GPU, "
-                                       f"deg-{args.deg} per-band least squares over all valid pixels "
-                                       f"(BASELINE.json configs[2]; one tile per GPU for N>1)",
-                           "tiles_per_gpu": 1, "coeff_sync": (args.coeff_sync if world > 1 else "none") +
+                "config": {"workload": f"{H}x{W}x{B} EMIT-like cube{' stored as uint16 x 10000 tiles (decode fused into K1)' if args.cube == 'u16' else ''} + {nb} real-S2 planes, "
+                                       f"{ntl} tile{'s' if ntl > 1 else ''} per GPU, deg-{args.deg} per-band least squares over all valid pixels "
+                                       + ("(BASELINE.json configs[2]; one tile per GPU for N>1)" if ntl == 1 else
+                                          f"of all {world * ntl} tiles: ONE global fit per step (BASELINE.json configs[3]/[4] mosaic)"),
+                           "tiles_per_gpu": ntl, "coeff_sync": (args.coeff_sync if world > 1 else "none") +
                            (f" (rehearsal: one-rank RCCL {args.coeff_sync} forced)" if args.force_exchange else ""),
                            "pipeline": f"one tile deep, {args.reserve_cus} CUs reserved" if pipelined else "off",
-                           "backend": (args.backend if world > 1 else "none") + backend_note +
+                           "backend": (args.backend if world > 1 else "none") +
                            (" (rehearsal: all ranks on cuda:0)" if args.same_device else "")},
                 "roofline": roof}
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(args)
+        if degraded:
+            line["degraded"] = True         # exchange over gloo (host staged): a rehearsal, not an RCCL/xGMI measurement
+        if want_cpu:
+            fo = out if not isinstance(out, tuple) else out[2][0]
+            cube_host = prob.cube.cpu().numpy()
+            real_host = prob.real_planes.cpu().numpy()
+            gp = fo.planes("pseudo").cpu().numpy().reshape(nb, H, W)
+            gm = fo.planes("matched").cpu().numpy().reshape(nb, H, W)
+            line["cpu_baseline"], line["max_rel_err"] = cpu_baseline(args, pool, nworkers, cube_host, real_host, gp, gm)
+            pool.shutdown()
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
     if world > 1 or args.force_exchange:
         dist.barrier()

@@ -41,6 +41,33 @@ __global__ __launch_bounds__(256) void probe_read_kernel(const float4* __restric
   if ((threadIdx.x & 63) == 0) atomicAdd(&sink[blockIdx.x & 63], acc);
 }
 
+// The load shape of K1 with nothing else: 512 persistent workgroups of 512 threads (2 per CU), each streaming
+// 72 KiB slabs (workgroup b takes slabs b, b + grid, ...) HBM -> LDS with non-temporal global_load_lds_dwordx4,
+// one barrier per slab, nothing read back.  What this kernel reaches is the ceiling of K1's staging structure on
+// this box (round 1 lab: 6.9 TB/s); a plain global_load stream (mode 1) reads 5.6 TB/s.
+constexpr int kProbeSlab = 72 * 1024;
+__global__ __launch_bounds__(512, 4) void probe_lds_dma_kernel(const char* __restrict__ src, int64_t n16, float* __restrict__ sink) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char psmem[];
+  typedef __attribute__((address_space(1))) const void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const int lane = threadIdx.x & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  constexpr int kChunks = kProbeSlab / 16;
+  const int64_t nslabs = (n16 + kChunks - 1) / kChunks;
+  for (int64_t sl = blockIdx.x; sl < nslabs; sl += gridDim.x) {
+    const int64_t base = sl * kChunks;
+    const int64_t left = n16 - base;
+    const int nch = left < kChunks ? (int)left : kChunks;
+    for (int c0 = wave * 64; c0 < nch; c0 += 512) {
+      const int c = c0 + lane;
+      if (c < nch)
+        __builtin_amdgcn_global_load_lds((gptr_t)(src + (base + c) * 16), (lptr_t)(psmem + (size_t)c0 * 16), 16, 0, kGldsStream);
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && blockIdx.x == 0) sink[0] = reinterpret_cast<const float*>(psmem)[0];   // keeps the LDS image observable
+}
+
 }  // namespace hsr
 
 extern "C" int hsr_abi_version(void) { return HSR_ABI_VERSION; }
@@ -49,18 +76,31 @@ extern "C" const char* hsr_last_error(void) { return hsr::g_error; }
 
 extern "C" int hsr_moment_count(int32_t deg) { return deg >= 1 && deg <= HSR_MAX_DEG ? hsr::moment_count(deg) : -1; }
 
-extern "C" int hsr_partial_slots(int64_t npix) { return hsr::partial_slots(npix); }
-
 extern "C" size_t hsr_partials_bytes(int32_t nb, int32_t deg) {
   if (nb < 1 || nb > HSR_MAX_BANDS || deg < 1 || deg > HSR_MAX_DEG) return 0;
   return (size_t)nb * hsr::moment_count(deg) * HSR_MAX_PARTIALS * sizeof(double);
 }
 
-extern "C" int hsr_probe_read(const void* buf_dev, int64_t bytes, float* sink_dev, hsr_stream_t stream) {
+extern "C" int hsr_probe_read(const void* buf_dev, int64_t bytes, int32_t mode, float* sink_dev, hsr_stream_t stream) {
   HSR_REQUIRE(buf_dev && sink_dev && bytes >= 16, HSR_ERR_INVALID, "hsr_probe_read: bad argument");
   HSR_REQUIRE(((uintptr_t)buf_dev & 15) == 0, HSR_ERR_INVALID, "hsr_probe_read: buffer not 16-byte aligned");
-  hipLaunchKernelGGL(hsr::probe_read_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream,
-                     (const float4*)buf_dev, bytes / 16, sink_dev);
-  HSR_LAUNCH_CHECK("probe_read_kernel");
+  HSR_REQUIRE(mode == 0 || mode == 1, HSR_ERR_INVALID, "hsr_probe_read: mode must be 0 (LDS-DMA nt) or 1 (global_load)");
+  if (mode == 1) {
+    hipLaunchKernelGGL(hsr::probe_read_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream,
+                       (const float4*)buf_dev, bytes / 16, sink_dev);
+    HSR_LAUNCH_CHECK("probe_read_kernel");
+    return HSR_OK;
+  }
+  static thread_local bool configured = false;
+  if (!configured) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hsr::probe_lds_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              hsr::kProbeSlab);
+    (void)hipGetLastError();
+    configured = true;
+  }
+  const int64_t nslabs = (bytes + hsr::kProbeSlab - 1) / hsr::kProbeSlab;
+  hipLaunchKernelGGL(hsr::probe_lds_dma_kernel, dim3((unsigned)(nslabs < 512 ? nslabs : 512)), dim3(512), hsr::kProbeSlab,
+                     (hipStream_t)stream, (const char*)buf_dev, bytes / 16, sink_dev);
+  HSR_LAUNCH_CHECK("probe_lds_dma_kernel");
   return HSR_OK;
 }

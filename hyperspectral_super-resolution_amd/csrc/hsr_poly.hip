@@ -318,6 +318,31 @@ __global__ __launch_bounds__(1024) void reduce_solve_kernel(const double* __rest
   if (threadIdx.x == 0) solve_band(mom, deg, min_count, coeffs + (size_t)b * (deg + 1));
 }
 
+// Batch form (hsr_moments_reduce_solve_batched): workgroup (band, tile) - the tile's slot block starts at
+// slot0 * nb * M in the batch workspace and has its own slot count.  Same row_sum tree, same solve -> same bits as the
+// single-tile launch on that tile.
+__global__ __launch_bounds__(1024) void reduce_solve_batched_kernel(const hsr_batch_tile* __restrict__ tiles,
+                                                                    const double* __restrict__ partials, int nb, int deg,
+                                                                    long long min_count, double* __restrict__ moments,
+                                                                    double* __restrict__ coeffs) {
+  __shared__ double mom[3 * HSR_MAX_DEG + 2];
+  const int M = moment_count(deg);
+  const int b = blockIdx.x, tile = blockIdx.y;
+  const int64_t slot0 = tiles[tile].slot0;
+  const int slots = tiles[tile].slots;
+  const double* part = partials + (size_t)slot0 * nb * M;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int m = wave; m < M; m += 16) {
+    const double s = row_sum(part + ((size_t)b * M + m) * slots, slots, lane);
+    if (lane == 0) {
+      mom[m] = s;
+      moments[((size_t)tile * nb + b) * M + m] = s;
+    }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) solve_band(mom, deg, min_count, coeffs + ((size_t)tile * nb + b) * (deg + 1));
+}
+
 // ------------------------------------------------------------------------------------------------
 // K3: polynomial apply
 // ------------------------------------------------------------------------------------------------
@@ -391,11 +416,93 @@ __global__ __launch_bounds__(256) void apply_planar_kernel(const ApplyArgs a) {
 }
 
 // pixel-major (band-last) images, the layout of the reference API (H, W, C) and of the fused path:
-// a pure contiguous stream.  VEC4: rows of ps floats with ps % 4 == 0, 16 bytes per lane (4 channels
-// of one pixel); channels >= nb of a padded row pass through unchanged.
-template <int Q>  // Q > 0: rows of 4*Q floats, 16 bytes per lane; Q == 0: scalar, any row stride
-__global__ __launch_bounds__(256) void apply_pixmajor_kernel(const ApplyArgs a) {
-  constexpr bool VEC4 = Q > 0;
+// a pure contiguous stream.  Rows of 4*Q floats, 16 bytes per lane (4 channels of one pixel); channels >= nb of a
+// padded row pass through unchanged.
+//
+// apply_rows_kernel<Q, N>: the grid stride is a multiple of Q float4s, so a lane keeps its channel group
+// (tid % Q) for the whole launch and holds the 4 x N coefficients of its channels (N = deg + 1 <= 5) and their
+// stretch limits in registers.  The first version kept the table in LDS and read N doubles per element at
+// cs + ch * n: lanes of a wave sit on Q channel groups whose rows collide in the banks - SQ_LDS_BANK_CONFLICT was
+// half of SQ_LDS_IDX_ACTIVE (profiles/r01_rocprof_summary.md) and the kernel ran at 4.3 TB/s.
+// BATCH: blockIdx.y = tile of a batch (hsr_poly_apply_batched), every tile with its own coefficients.
+template <int Q, int N, bool BATCH>
+__global__ __launch_bounds__(256) void apply_rows_kernel(const ApplyArgs a, const hsr_batch_tile* __restrict__ tiles,
+                                                         int use_mask) {
+  constexpr int U = 4;                  // independent 16-byte loads in flight per thread
+  const bool has_poly = a.coeffs != nullptr;
+  const bool st = a.lohi != nullptr;
+  const float* x = a.x;
+  float* out = a.out;
+  const uint8_t* mask = a.mask;
+  int64_t npix = a.npix;
+  const double* coeffs = a.coeffs;
+  if (BATCH) {
+    const hsr_batch_tile tl = tiles[blockIdx.y];
+    x = tl.pseudo_dev;
+    out = tl.matched_dev;
+    mask = use_mask ? tl.mask_dev : nullptr;
+    npix = tl.npix;
+    coeffs = a.coeffs + (size_t)blockIdx.y * a.nb * N;
+  }
+  const uint32_t nv = (uint32_t)(npix * Q);          // host guarantees npix * Q < 2^31
+  const uint32_t tid = blockIdx.x * 256u + threadIdx.x;
+  const uint32_t nthreads = gridDim.x * 256u;        // host: a multiple of Q
+  if (BATCH && tid >= nv) return;
+  float4 v[U];
+#pragma unroll
+  for (int u = 0; u < U; ++u) {          // first batch of loads goes out before the coefficient loads
+    const uint32_t i = tid + u * nthreads;
+    if (i < nv) v[u] = ld_stream(reinterpret_cast<const float4*>(x) + i);
+  }
+  const int c0 = (int)(tid % Q) * 4;     // first channel of this lane, fixed for the launch
+  double c[4][N], lo[4], hi[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int ch = c0 + j < a.nb ? c0 + j : 0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) c[j][k] = has_poly ? coeffs[ch * N + k] : 0.0;
+    lo[j] = st ? a.lohi[2 * ch] : 0.0;
+    hi[j] = st ? a.lohi[2 * ch + 1] : 0.0;
+  }
+  for (uint32_t i0 = tid; i0 < nv; i0 += nthreads * U) {
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t i = i0 + u * nthreads;
+      if (i >= nv) break;
+      const uint32_t p = i / Q;
+      const bool m = !mask || mask[p];
+      float r[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (c0 + j < a.nb) {
+          float xv = r[j];
+          if (st) xv = stretch_f64(xv, lo[j], hi[j]);
+          if (has_poly && m) {      // np.polyval: y = 0; y = y*x + c, separately rounded
+            const double xd = (double)xv;
+            double y = 0.0;
+#pragma unroll
+            for (int k = 0; k < N; ++k) y = __dadd_rn(__dmul_rn(y, xd), c[j][k]);
+            xv = (float)y;
+          }
+          r[j] = a.clip ? clip01(xv) : xv;
+        }
+      }
+      st_stream(reinterpret_cast<float4*>(out) + i, make_float4(r[0], r[1], r[2], r[3]));
+    }
+    // next batch (grid-stride; a single pass when the grid covers the image)
+    const uint32_t inext = i0 + nthreads * U;
+    if (inext < nv) {
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t i = inext + u * nthreads;
+        if (i < nv) v[u] = ld_stream(reinterpret_cast<const float4*>(x) + i);
+      }
+    }
+  }
+}
+
+// General pixel-major fallback: any row stride, any degree up to HSR_MAX_APPLY_DEG, coefficient table in LDS.
+__global__ __launch_bounds__(256) void apply_pixmajor_scalar_kernel(const ApplyArgs a) {
   __shared__ double cs[HSR_MAX_BANDS * (HSR_MAX_APPLY_DEG + 1)];
   __shared__ double lh[HSR_MAX_BANDS * 2];
   const int n = a.deg + 1;
@@ -403,64 +510,53 @@ __global__ __launch_bounds__(256) void apply_pixmajor_kernel(const ApplyArgs a) 
   const bool st = a.lohi != nullptr;
   const int64_t tid = (int64_t)blockIdx.x * 256 + threadIdx.x;
   const int64_t nthreads = (int64_t)gridDim.x * 256;
-  constexpr uint32_t q = VEC4 ? Q : 1;  // float4 per pixel row (compile-time: division by constant)
-  constexpr int U = 4;                  // independent 16-byte loads in flight per thread
-  const uint32_t nv = VEC4 ? (uint32_t)(a.npix * q) : 0u;   // host guarantees npix * q < 2^31
-  float4 v[U];
-  if (VEC4) {   // first batch of loads goes out BEFORE the coefficient staging and its barrier
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const uint32_t i = (uint32_t)tid + u * (uint32_t)nthreads;
-      if (i < nv) v[u] = ld_stream(reinterpret_cast<const float4*>(a.x) + i);
-    }
-  }
   if (has_poly)
     for (int i = threadIdx.x; i < a.nb * n; i += 256) cs[i] = a.coeffs[i];
   if (st)
     for (int i = threadIdx.x; i < a.nb * 2; i += 256) lh[i] = a.lohi[i];
   __syncthreads();
-  if (VEC4) {
-    for (uint32_t i0 = (uint32_t)tid; i0 < nv; i0 += (uint32_t)nthreads * U) {
+  const int64_t total = a.npix * a.nb;
+  for (int64_t e = tid; e < total; e += nthreads) {
+    const int64_t p = e / a.nb;
+    const int ch = (int)(e - p * a.nb);
+    float xv = a.x[p * a.x_ps + ch];
+    if (st) xv = stretch_f64(xv, lh[2 * ch], lh[2 * ch + 1]);
+    if (has_poly && (!a.mask || a.mask[p])) xv = poly_eval(xv, cs + ch * n, n);
+    a.out[p * a.out_ps + ch] = a.clip ? clip01(xv) : xv;
+  }
+}
+
+// rows of 4*Q floats with a degree above 4 (apply only; fits are <= 4): 16 bytes per lane, table in LDS
+template <int Q>
+__global__ __launch_bounds__(256) void apply_rows_lds_kernel(const ApplyArgs a) {
+  __shared__ double cs[HSR_MAX_BANDS * (HSR_MAX_APPLY_DEG + 1)];
+  __shared__ double lh[HSR_MAX_BANDS * 2];
+  const int n = a.deg + 1;
+  const bool has_poly = a.coeffs != nullptr;
+  const bool st = a.lohi != nullptr;
+  if (has_poly)
+    for (int i = threadIdx.x; i < a.nb * n; i += 256) cs[i] = a.coeffs[i];
+  if (st)
+    for (int i = threadIdx.x; i < a.nb * 2; i += 256) lh[i] = a.lohi[i];
+  __syncthreads();
+  const uint32_t nv = (uint32_t)(a.npix * Q);
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < nv; i += gridDim.x * 256u) {
+    const float4 v = ld_stream(reinterpret_cast<const float4*>(a.x) + i);
+    const uint32_t p = i / Q;
+    const int c0 = (int)(i - p * Q) * 4;
+    const bool m = !a.mask || a.mask[p];
+    float r[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const uint32_t i = i0 + u * (uint32_t)nthreads;
-        if (i >= nv) break;
-        const uint32_t p = i / q;
-        const int c0 = (int)(i - p * q) * 4;
-        const bool m = !a.mask || a.mask[p];
-        float r[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int ch = c0 + j;
-          if (ch < a.nb) {
-            float xv = r[j];
-            if (st) xv = stretch_f64(xv, lh[2 * ch], lh[2 * ch + 1]);
-            if (has_poly && m) xv = poly_eval(xv, cs + ch * n, n);
-            r[j] = a.clip ? clip01(xv) : xv;
-          }
-        }
-        st_stream(reinterpret_cast<float4*>(a.out) + i, make_float4(r[0], r[1], r[2], r[3]));
-      }
-      // next batch (grid-stride; a single pass when the grid covers the image)
-      const uint32_t inext = i0 + (uint32_t)nthreads * U;
-      if (inext < nv) {
-#pragma unroll
-        for (int u = 0; u < U; ++u) {
-          const uint32_t i = inext + u * (uint32_t)nthreads;
-          if (i < nv) v[u] = ld_stream(reinterpret_cast<const float4*>(a.x) + i);
-        }
+    for (int j = 0; j < 4; ++j) {
+      const int ch = c0 + j;
+      if (ch < a.nb) {
+        float xv = r[j];
+        if (st) xv = stretch_f64(xv, lh[2 * ch], lh[2 * ch + 1]);
+        if (has_poly && m) xv = poly_eval(xv, cs + ch * n, n);
+        r[j] = a.clip ? clip01(xv) : xv;
       }
     }
-  } else {
-    const int64_t total = a.npix * a.nb;
-    for (int64_t e = tid; e < total; e += nthreads) {
-      const int64_t p = e / a.nb;
-      const int ch = (int)(e - p * a.nb);
-      float xv = a.x[p * a.x_ps + ch];
-      if (st) xv = stretch_f64(xv, lh[2 * ch], lh[2 * ch + 1]);
-      if (has_poly && (!a.mask || a.mask[p])) xv = poly_eval(xv, cs + ch * n, n);
-      a.out[p * a.out_ps + ch] = a.clip ? clip01(xv) : xv;
-    }
+    st_stream(reinterpret_cast<float4*>(a.out) + i, make_float4(r[0], r[1], r[2], r[3]));
   }
 }
 
@@ -519,6 +615,30 @@ static inline int stream_grid(int64_t work_items, int per_block) {
   int64_t g = (work_items + per_block - 1) / per_block;
   if (g < 1) g = 1;
   return (int)(g > 2048 ? 2048 : g);  // 256 CUs x 8 blocks, grid-stride beyond
+}
+
+template <bool BATCH, int Q>
+static int launch_apply_rows_q(const ApplyArgs& a, const hsr_batch_tile* tiles, int use_mask, int deg, dim3 grid, hipStream_t s) {
+  switch (deg) {
+    case 0: hipLaunchKernelGGL((apply_rows_kernel<Q, 1, BATCH>), grid, dim3(256), 0, s, a, tiles, use_mask); break;
+    case 1: hipLaunchKernelGGL((apply_rows_kernel<Q, 2, BATCH>), grid, dim3(256), 0, s, a, tiles, use_mask); break;
+    case 2: hipLaunchKernelGGL((apply_rows_kernel<Q, 3, BATCH>), grid, dim3(256), 0, s, a, tiles, use_mask); break;
+    case 3: hipLaunchKernelGGL((apply_rows_kernel<Q, 4, BATCH>), grid, dim3(256), 0, s, a, tiles, use_mask); break;
+    case 4: hipLaunchKernelGGL((apply_rows_kernel<Q, 5, BATCH>), grid, dim3(256), 0, s, a, tiles, use_mask); break;
+    default: set_error("apply_rows: deg=%d", deg); return HSR_ERR_UNSUPPORTED;
+  }
+  return HSR_OK;
+}
+template <bool BATCH>
+static int launch_apply_rows(const ApplyArgs& a, const hsr_batch_tile* tiles, int use_mask, int q, int deg, dim3 grid, hipStream_t s) {
+  switch (q) {
+    case 1: return launch_apply_rows_q<BATCH, 1>(a, tiles, use_mask, deg, grid, s);
+    case 2: return launch_apply_rows_q<BATCH, 2>(a, tiles, use_mask, deg, grid, s);
+    case 3: return launch_apply_rows_q<BATCH, 3>(a, tiles, use_mask, deg, grid, s);
+    case 4: return launch_apply_rows_q<BATCH, 4>(a, tiles, use_mask, deg, grid, s);
+  }
+  set_error("apply_rows: rows of %d floats", 4 * q);
+  return HSR_ERR_UNSUPPORTED;
 }
 
 }  // namespace hsr
@@ -637,24 +757,32 @@ extern "C" int hsr_poly_apply(const float* x_dev, int64_t x_bs, int64_t x_ps, co
   if (npix == 0) return HSR_OK;
   ApplyArgs a{x_dev, x_bs, x_ps, mask_dev, coeffs_dev, lohi_dev, nb, deg, clip, npix, out_dev, out_bs, out_ps};
   hipStream_t s = (hipStream_t)stream;
+  int rc = HSR_OK;
   const bool aligned = ((((uintptr_t)x_dev) | ((uintptr_t)out_dev)) & 15) == 0;
   if (x_bs == 1 && out_bs == 1 && x_ps == out_ps && !(x_ps == 1 && nb > 1)) {  // pixel-major in and out, same rows
     const int64_t q = x_ps >> 2;
     if (aligned && (x_ps & 3) == 0 && q >= 1 && q <= 4 && npix * q < ((int64_t)1 << 31)) {
-      // one pass when it fits (4 x 16 B per thread): no grid-stride tail imbalance on a ~20 us kernel
+      // one pass when it fits (4 x 16 B per thread): no grid-stride tail imbalance on a ~20 us kernel.  The
+      // grid is a multiple of 3 workgroups so that the stride is a multiple of every Q (lane <-> channel group fixed).
       int64_t gb = (npix * q + 256 * 4 - 1) / (256 * 4);
-      if (gb > 8192) gb = 2048;
-      const dim3 grid((unsigned)(gb < 1 ? 1 : gb));
-      switch (q) {
-        case 1: hipLaunchKernelGGL(apply_pixmajor_kernel<1>, grid, dim3(256), 0, s, a); break;
-        case 2: hipLaunchKernelGGL(apply_pixmajor_kernel<2>, grid, dim3(256), 0, s, a); break;
-        case 3: hipLaunchKernelGGL(apply_pixmajor_kernel<3>, grid, dim3(256), 0, s, a); break;
-        default: hipLaunchKernelGGL(apply_pixmajor_kernel<4>, grid, dim3(256), 0, s, a); break;
+      if (gb > 8190) gb = 2046;
+      gb = (gb + 2) / 3 * 3;
+      const dim3 grid((unsigned)gb);
+      if (deg <= HSR_MAX_DEG) {
+        rc = launch_apply_rows<false>(a, nullptr, 0, (int)q, deg, grid, s);
+        if (rc != HSR_OK) return rc;
+      } else {
+        switch (q) {
+          case 1: hipLaunchKernelGGL(apply_rows_lds_kernel<1>, grid, dim3(256), 0, s, a); break;
+          case 2: hipLaunchKernelGGL(apply_rows_lds_kernel<2>, grid, dim3(256), 0, s, a); break;
+          case 3: hipLaunchKernelGGL(apply_rows_lds_kernel<3>, grid, dim3(256), 0, s, a); break;
+          default: hipLaunchKernelGGL(apply_rows_lds_kernel<4>, grid, dim3(256), 0, s, a); break;
+        }
       }
     } else {
-      hipLaunchKernelGGL(apply_pixmajor_kernel<0>, dim3(stream_grid(npix * nb, 256 * 4)), dim3(256), 0, s, a);
+      hipLaunchKernelGGL(apply_pixmajor_scalar_kernel, dim3(stream_grid(npix * nb, 256 * 4)), dim3(256), 0, s, a);
     }
-    HSR_LAUNCH_CHECK("apply_pixmajor_kernel");
+    HSR_LAUNCH_CHECK("apply_rows_kernel");
     return HSR_OK;
   }
   const bool vec = aligned && x_ps == 1 && out_ps == 1 && (x_bs & 3) == 0 && (out_bs & 3) == 0 &&
@@ -678,5 +806,38 @@ extern "C" int hsr_valid_mask(const float* x_dev, int64_t x_bs, int64_t x_ps, in
   hipLaunchKernelGGL(valid_mask_kernel, dim3(stream_grid(npix, 256)), dim3(256), 0, (hipStream_t)stream, x_dev,
                      x_bs, x_ps, nbx, pos_band, y_dev, y_bs, y_ps, y_dev ? nby : 0, mask_in_dev, npix, mask_out_dev);
   HSR_LAUNCH_CHECK("valid_mask_kernel");
+  return HSR_OK;
+}
+
+extern "C" int hsr_moments_reduce_solve_batched(const hsr_batch_tile* tiles_dev, int32_t ntiles, const double* partials_dev,
+                                                int32_t nb, int32_t deg, int64_t min_count, double* moments_dev,
+                                                double* coeffs_dev, hsr_stream_t stream) {
+  HSR_REQUIRE(tiles_dev && partials_dev && moments_dev && coeffs_dev, HSR_ERR_INVALID, "hsr_moments_reduce_solve_batched: NULL pointer");
+  HSR_REQUIRE(ntiles >= 1 && ntiles <= 65535, HSR_ERR_UNSUPPORTED, "hsr_moments_reduce_solve_batched: ntiles=%d outside [1,65535]", ntiles);
+  HSR_REQUIRE(nb >= 1 && nb <= HSR_MAX_BANDS && deg >= 1 && deg <= HSR_MAX_DEG, HSR_ERR_UNSUPPORTED,
+              "hsr_moments_reduce_solve_batched: nb=%d deg=%d", nb, deg);
+  hipLaunchKernelGGL(reduce_solve_batched_kernel, dim3(nb, ntiles), dim3(1024), 0, (hipStream_t)stream, tiles_dev, partials_dev,
+                     nb, deg, (long long)min_count, moments_dev, coeffs_dev);
+  HSR_LAUNCH_CHECK("reduce_solve_batched_kernel");
+  return HSR_OK;
+}
+
+extern "C" int hsr_poly_apply_batched(const hsr_batch_tile* tiles_dev, int32_t ntiles, int64_t max_npix, const double* coeffs_dev,
+                                      int32_t nb, int32_t deg, int32_t row, int32_t use_mask, int32_t clip, hsr_stream_t stream) {
+  HSR_REQUIRE(tiles_dev && coeffs_dev, HSR_ERR_INVALID, "hsr_poly_apply_batched: NULL pointer");
+  HSR_REQUIRE(ntiles >= 1 && ntiles <= 65535, HSR_ERR_UNSUPPORTED, "hsr_poly_apply_batched: ntiles=%d outside [1,65535]", ntiles);
+  HSR_REQUIRE(nb >= 1 && nb <= HSR_MAX_BANDS && deg >= 0 && deg <= HSR_MAX_DEG, HSR_ERR_UNSUPPORTED,
+              "hsr_poly_apply_batched: nb=%d deg=%d", nb, deg);
+  HSR_REQUIRE(row >= nb && (row & 3) == 0 && row <= HSR_MAX_BANDS, HSR_ERR_UNSUPPORTED,
+              "hsr_poly_apply_batched: row=%d must be a multiple of 4 in [nb,%d]", row, HSR_MAX_BANDS);
+  const int64_t q = row >> 2;
+  HSR_REQUIRE(max_npix >= 1 && max_npix * q < ((int64_t)1 << 31), HSR_ERR_UNSUPPORTED, "hsr_poly_apply_batched: max_npix=%lld", (long long)max_npix);
+  ApplyArgs a{nullptr, 1, row, nullptr, coeffs_dev, nullptr, nb, deg, clip, 0, nullptr, 1, row};
+  int64_t gb = (max_npix * q + 256 * 4 - 1) / (256 * 4);
+  if (gb > 2046) gb = 2046;
+  gb = (gb + 2) / 3 * 3;
+  int rc = launch_apply_rows<true>(a, tiles_dev, use_mask, (int)q, deg, dim3((unsigned)gb, (unsigned)ntiles), (hipStream_t)stream);
+  if (rc != HSR_OK) return rc;
+  HSR_LAUNCH_CHECK("apply_rows_kernel (batched)");
   return HSR_OK;
 }

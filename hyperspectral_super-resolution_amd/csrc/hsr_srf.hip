@@ -4,7 +4,7 @@
 // makes 13 full-cube float64 passes; here the cube is streamed from HBM exactly once.
 //
 // Data flow per workgroup (512 threads = 8 waves, 2 workgroups resident per CU):
-//   1. a tile of 64 consecutive pixels (64*B*4 bytes, one linear 16-byte-aligned slab because the
+//   1. a group of 64 consecutive pixels (64*B*4 bytes, one linear 16-byte-aligned slab because the
 //      cube is pixel-major) goes HBM -> LDS with global_load_lds_dwordx4 (no VGPR round trip,
 //      1 KiB per wave instruction, fully coalesced), marked non-temporal: the cube is read once,
 //      and without the hint the stream thrashes L2 against the output lines (-12 % on the kernel).
@@ -13,18 +13,24 @@
 //   3. lane = pixel, wave = band group: each band is a short dot product over its SRF support read
 //      from LDS with a row stride of B words (B odd -> bank-conflict free).  The weight taps of all
 //      bands (a few hundred floats, 16-byte aligned segments) are staged into LDS once per
-//      workgroup and read as broadcast ds_read_b128 - no scalar-load latency inside the tile loop
-//      (the first version fetched them with s_load per tile and spent ~5 us per tile waiting).
+//      workgroup and read as broadcast ds_read_b128 - no scalar-load latency inside the group loop
+//      (the first version fetched them with s_load per group and spent ~5 us per group waiting).
 //      Flagged pixels take the dense product so that 0*Inf -> NaN poisons exactly the bands the
 //      reference poisons (synth.py:41 multiplies all B samples of every band).
-//   4. output.  Pixel-major (band-last) output is staged in LDS as the tile's contiguous
-//      [pixel][band] slab and flushed with 16-byte stores in the next iteration, after that tile's
-//      DMA has been issued: one contiguous ~3 KB write per tile.  (Band-major planes are stored directly: nb scattered
-//      256-B segments per tile; measured 10 % slower on the whole kernel because of the write
+//   4. output.  Pixel-major (band-last) output is staged in LDS as the group's contiguous
+//      [pixel][band] slab and flushed with 16-byte stores in the next iteration, after that group's
+//      DMA has been issued: one contiguous ~3 KB write per group.  (Band-major planes are stored directly: nb scattered
+//      256-B segments per group; measured 10 % slower on the whole kernel because of the write
 //      pattern, although the planes are only 4 % of the bytes.)  With DEG > 0 the same lane
 //      also accumulates the Vandermonde power sums of (x = plane value, y = real S2 value) in
-//      float64 registers; they are reduced over the wave by a fixed butterfly and written to a
-//      per-workgroup slot (no float atomics -> bitwise reproducible).
+//      float64 registers; they are reduced over the wave by a fixed DPP tree and written to the
+//      partial slot of the work unit (no float atomics -> bitwise reproducible).
+// Work units.  A tile of G pixel groups owns S = min(G, resident workgroups) partial slots; unit (tile, s)
+// is the group sequence s, s+S, s+2S, ... accumulated in that order into slot s.  A single-tile launch
+// runs one unit per workgroup (grid = S).  A batch launch (hsr_srf_integrate_moments_batched) walks a
+// device table of units over many small tiles - workgroup b takes units b, b+grid, ... - and flushes the
+// finished unit's sums while the next group's DMA is in flight; per-tile results are bit-identical to the
+// single-tile launch because a tile's slot layout and every summation order depend on its npix only.
 // HBM-bound by construction: 4*B bytes in, 4*nb (+4*nb+1) bytes out/in per pixel, ~0.35 kflop.
 #include "hsr_common.h"
 
@@ -39,24 +45,24 @@ struct SrfBands {
 
 constexpr int kWeightCap = 1024;  // floats of LDS reserved for compact weight taps (4 KiB)
 
+// One (tile, slot) work unit: the public hsr_batch_unit record (include/hsr.h), 64 bytes.
+typedef hsr_batch_unit SrfUnit;
+static_assert(sizeof(SrfUnit) == 64 && sizeof(hsr_batch_tile) == 64, "batch records are 64 bytes");
+
 struct SrfArgs {
-  const float* cube;
-  int64_t npix;
-  int64_t ntiles;
+  SrfUnit one;            // single-tile launch: the tile (slot = blockIdx.x, part_dev = base of slot 0)
+  const SrfUnit* units;   // batch launch: the unit table (device)
+  int32_t nunits;
   int32_t B;
   int32_t ldsB;  // LDS row stride in words (odd)
   int32_t wtaps; // floats used in the LDS weight area (0: weights do not fit, read them from global)
   const float* wn;
   SrfBands bands;
   int32_t nb;
-  float* out;        // element (b, p) at out[b * out_bs + p * out_ps]
+  // element (b, p) of the output at pseudo_dev[b * out_bs + p * out_ps], of the target at real_dev[b * real_bs + p * real_ps]
   int64_t out_bs, out_ps;
-  const float* real;  // element (b, p) at real[b * real_bs + p * real_ps]
   int64_t real_bs, real_ps;
-  const uint8_t* mask;
   float min_x, min_y;
-  double* partials;
-  int32_t slots;
   // uint16 tiles (srf_u16_kernel): cube points at uint16 samples, x = float(u) * scale, u == nodata -> NaN
   int32_t u16;
   float scale;
@@ -92,12 +98,36 @@ constexpr int kScanBatch = 5;                       // ds_read_b128 in flight pe
 //  one 1024-thread workgroup per CU: 0.234 ms; P = 64: 0.2133 ms on the same box.)
 // Both keep 16 waves (4 per SIMD, <= 128 VGPRs) and ~146 KB of LDS tiles per CU; the smaller tile
 // gives the CU's memory pipe four queued customers instead of two (see DESIGN.md, K1 tuning).
-static int g_tile_pixels = 64;
-// CUs left without a persistent K1 workgroup so that small kernels on another stream (slot reduction,
-// RCCL exchange, solve) can run while K1 of the next tile owns the rest of the chip.
-static int g_reserved_cus = 0;
-// uint16 tiles: 1 = double-buffered kernel where it fits (default), 0 = single-buffer kernel (A/B switch)
-static int g_u16_ring = 1;
+// The geometry comes with every call (hsr_srf_options); the library keeps no tuning state.
+struct SrfTuning {
+  int tile_pixels;    // 64 or 32
+  int reserved_cus;   // CUs left without a persistent K1 workgroup (side-stream kernels of the previous tile's fit)
+  bool u16_ring;      // uint16 cubes: double-buffered kernel where it fits
+};
+
+static int srf_tuning(const hsr_srf_options* o, SrfTuning* t, const char* who) {
+  t->tile_pixels = 64;
+  t->reserved_cus = 0;
+  t->u16_ring = true;
+  if (o == nullptr) return HSR_OK;
+  HSR_REQUIRE(o->tile_pixels == 0 || o->tile_pixels == 64 || o->tile_pixels == 32, HSR_ERR_INVALID,
+              "%s: options.tile_pixels must be 0 (default), 64 or 32, got %d", who, o->tile_pixels);
+  HSR_REQUIRE(o->reserved_cus >= 0 && o->reserved_cus <= 128, HSR_ERR_INVALID, "%s: options.reserved_cus=%d outside [0,128]",
+              who, o->reserved_cus);
+  HSR_REQUIRE(o->reserved == 0, HSR_ERR_INVALID, "%s: options.reserved must be 0", who);
+  if (o->tile_pixels) t->tile_pixels = o->tile_pixels;
+  t->reserved_cus = o->reserved_cus;
+  t->u16_ring = o->u16_single_buffer == 0;
+  return HSR_OK;
+}
+
+// Partial slots of a tile of npix pixels: min(pixel groups, resident workgroups).
+static int srf_slots(int64_t npix, int P, int reserved_cus) {
+  int64_t groups = (npix + P - 1) / P;
+  if (groups < 1) groups = 1;
+  const int64_t cap = (int64_t)(256 - reserved_cus) * (P == 64 ? 2 : 4);  // CUs x resident workgroups
+  return (int)(groups < cap ? groups : cap);
+}
 
 typedef __attribute__((address_space(1))) const void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
@@ -121,6 +151,33 @@ __device__ __forceinline__ uint32_t load_u8_async(const uint8_t* p) {
   return v;
 }
 
+// ---- batch launches: the record of a workgroup's NEXT unit travels HBM -> LDS by a 64-byte LDS-DMA issued by 16
+// lanes of wave 0 right behind the group's own DMA: no destination register (an inline-asm load into a VGPR that is
+// used an iteration later can be copied by the compiler before it has landed), no SGPRs held across the iteration
+// (a prefetched record in SGPRs cost 16 of them at the SGPR limit and pushed a dozen VGPRs into scratch).  It is
+// read back with wave-uniform ds_reads + v_readfirstlane when the current unit ends.
+__device__ __forceinline__ const char* unit_record_addr(const SrfUnit* units, int64_t idx, int nunits, int lane) {
+  const int64_t i = idx < nunits ? idx : (int64_t)nunits - 1;      // clamped: always a valid address
+  return reinterpret_cast<const char*>(units + i) + (lane & 15) * 4;
+}
+__device__ __forceinline__ SrfUnit unit_from_lds(const uint32_t* us) {
+  uint32_t w[15];
+#pragma unroll
+  for (int i = 0; i < 15; ++i) w[i] = __builtin_amdgcn_readfirstlane(us[i]);
+  SrfUnit u;
+  u.cube_dev = reinterpret_cast<const void*>(((uint64_t)w[1] << 32) | w[0]);
+  u.real_dev = reinterpret_cast<const float*>(((uint64_t)w[3] << 32) | w[2]);
+  u.mask_dev = reinterpret_cast<const uint8_t*>(((uint64_t)w[5] << 32) | w[4]);
+  u.pseudo_dev = reinterpret_cast<float*>(((uint64_t)w[7] << 32) | w[6]);
+  u.part_dev = reinterpret_cast<double*>(((uint64_t)w[9] << 32) | w[8]);
+  u.npix = (int64_t)(((uint64_t)w[11] << 32) | w[10]);
+  u.slots = (int32_t)w[12];
+  u.slot = (int32_t)w[13];
+  u.ngroups = (int32_t)w[14];
+  u.reserved = 0;
+  return u;
+}
+
 // x*0 is NaN exactly when x is NaN or +-Inf; four of them chained cost 4 VALU ops.
 __device__ __forceinline__ bool any_nonfinite4(const float4& v) {
   float z = v.x * 0.0f;
@@ -130,7 +187,7 @@ __device__ __forceinline__ bool any_nonfinite4(const float4& v) {
   return z != z;
 }
 
-// Flush the staged [pixel][band] slab of the previous tile: contiguous in HBM, 16 bytes per lane.
+// Flush the staged [pixel][band] slab of the previous group: contiguous in HBM, 16 bytes per lane.
 template <int T>
 __device__ __forceinline__ void flush_stage(const float* ostage, float* out, int64_t pix0, int npx, int ops, int t) {
   const int n4 = (npx * ops) >> 2;  // ops is a multiple of 4
@@ -139,7 +196,84 @@ __device__ __forceinline__ void flush_stage(const float* ostage, float* out, int
   for (int i = t; i < n4; i += T) st_stream(dst + i, src[i]);
 }
 
-template <int DEG, bool FAST, bool WLDS, int P, bool OUTV>
+// ---- fixed-order sum of one double per pixel over the pixels of a group, without LDS ----------------------
+// v_add_f64 cannot take a DPP operand, so one tree level is two v_mov_b32_dpp (the halves of the double) and one
+// add.  (The first version used __shfl_xor = two ds_bpermute_b32 per level: fine once per launch, but a batch of
+// small tiles reduces once per 64-pixel group and 264 LDS-crossbar instructions per wave and group were as
+// expensive as the dot products.)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_f64(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  const int l2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);   // rows outside ROW_MASK read 0
+  const int h2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+  return __hiloint2double(h2, l2);
+}
+constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E;                 // quad_perm [1,0,3,2], [2,3,0,1]
+constexpr int kDppHalfMirror = 0x141, kDppRowMirror = 0x140;   // lane i <-> 7-i within 8, i <-> 15-i within 16
+constexpr int kDppBcast15 = 0x142, kDppBcast31 = 0x143;        // lane 15 of a row -> next row; lane 31 -> rows 2, 3
+
+// The tree, in pixels p of the group: ((p ^ 1) pairs) -> 4 -> 8 -> 16 -> 32 (-> 64).  Every kernel reduces in this
+// tree, so float32 K1, uint16 K1 and the batch kernels give the same bits:
+//   LANE_IS_PIXEL (float32 kernels): lane = pixel.  Levels: xor 1, xor 2, half mirror, row mirror, row 1 += row 0 and
+//     row 3 += row 2 (row_bcast:15), then (P = 64) rows 2, 3 += lane 31 (row_bcast:31).  Result in lane P - 1 (+ 32k).
+//   uint16 kernels: lanes 0..31 hold the even pixels, lanes 32..63 the odd ones (see srf_u16_kernel).  Level 1 is
+//     then lane ^ 32 (v_permlane32_swap), levels 2..5 the four in-row steps, level 6 row_bcast:15.  Result in lane 63.
+template <int P, bool LANE_IS_PIXEL>
+__device__ __forceinline__ double group_sum(double v) {
+  if (LANE_IS_PIXEL) {
+    v += dpp_f64<kDppXor1, 0xf>(v);
+    v += dpp_f64<kDppXor2, 0xf>(v);
+    v += dpp_f64<kDppHalfMirror, 0xf>(v);
+    v += dpp_f64<kDppRowMirror, 0xf>(v);
+    v += dpp_f64<kDppBcast15, 0xa>(v);
+    if (P == 64) v += dpp_f64<kDppBcast31, 0xc>(v);
+  } else {
+    const int lo = __double2loint(v), hi = __double2hiint(v);
+    const auto sl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);   // [0]: lower half in both halves, [1]: upper
+    const auto sh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    v = __hiloint2double(sh[0], sl[0]) + __hiloint2double(sh[1], sl[1]);      // even pixel + odd pixel
+    v += dpp_f64<kDppXor1, 0xf>(v);
+    v += dpp_f64<kDppXor2, 0xf>(v);
+    v += dpp_f64<kDppHalfMirror, 0xf>(v);
+    v += dpp_f64<kDppRowMirror, 0xf>(v);
+    v += dpp_f64<kDppBcast15, 0xa>(v);
+  }
+  return v;
+}
+
+// Reduce the per-lane power sums of a finished work unit, write them to its partial slot and clear them.
+template <int M, int P, bool LANE_IS_PIXEL>
+__device__ __forceinline__ void flush_moments(double (&acc_m)[2][M], const bool (&bval)[2], const int (&bidx)[2],
+                                              double* part, int slots, int lane) {
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    // opaque copy of the band index: otherwise LICM hoists the 2*M row offsets (bidx*M + m) out of the batch
+    // kernels' group loop and parks them in scratch
+    int bi = bidx[j];
+    asm volatile("" : "+v"(bi));
+    double* row = part + (size_t)bi * M * slots;
+#pragma unroll
+    for (int m = 0; m < M; ++m) {
+      const double sv = group_sum<P, LANE_IS_PIXEL>(acc_m[j][m]);
+      if (bval[j] && (lane % P) == P - 1) row[(size_t)m * slots] = sv;
+      acc_m[j][m] = 0.0;
+      // one moment at a time: left alone, the scheduler interleaves all 2*M trees for ILP and the batch kernels,
+      // which run this inside the group loop, spill ~150 VGPRs to scratch
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+}
+
+// Pad columns nb..ops-1 of the staged output slab: written once per workgroup with zeros, so that the whole rows the
+// flush stores are defined (hsr.h: padded rows are owned by the callee).
+template <int T>
+__device__ __forceinline__ void zero_stage_pad(float* ostage, int npixels, int nb, int ops, int t) {
+  const int padc = ops - nb;
+  if (padc <= 0) return;
+  for (int i = t; i < npixels * padc; i += T) ostage[(i / padc) * ops + nb + (i % padc)] = 0.0f;
+}
+
+template <int DEG, bool FAST, bool WLDS, int P, bool OUTV, bool BATCH>
 __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
   constexpr int T = 8 * P;
   constexpr int NW = T / 64;
@@ -148,18 +282,20 @@ __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
   const int B = a.B;
   const int ldsB = a.ldsB;
   uint32_t* flags = reinterpret_cast<uint32_t*>(smem + (size_t)P * ldsB * 4);
-  const float* wl = reinterpret_cast<const float*>(flags + 64);  // 16-byte aligned
+  uint32_t* ustage = flags + 64;                                  // [16] record of the next unit (batch launches)
+  const float* wl = reinterpret_cast<const float*>(flags + 64 + (BATCH ? 16 : 0));  // 16-byte aligned
   float* ostage = const_cast<float*>(wl) + (WLDS ? a.wtaps : 0);  // [P][out_ps] output slab (OUTV only)
   const int ops = (int)a.out_ps;
+  float* prev_out = nullptr;
   int64_t prev_pix0 = 0;
   int prev_npx = 0;
 
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int pl = t % P;     // pixel of this thread inside the tile
+  const int pl = t % P;     // pixel of this thread inside the group
   const int grp = t / P;    // band group 0..7 (wave-uniform for P = 64, per half-wave for P = 32)
-  const int nchunk = P * B / 4;  // 16-byte chunks of a full tile (P is a multiple of 4)
+  const int nchunk = P * B / 4;  // 16-byte chunks of a full group (P is a multiple of 4)
 
   // the (at most two) bands of this thread, fixed for the whole launch
   int bk0[kBandSlots], bkl[kBandSlots], bwo[kBandSlots], bidx[kBandSlots];
@@ -182,6 +318,7 @@ __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
       for (int i = t; i < kl; i += T) wlw[a.bands.woff[b] + i] = a.wn[(size_t)b * B + a.bands.k0[b] + i];
     }
   }
+  if (OUTV) zero_stage_pad<T>(ostage, P, a.nb, ops, t);
 
 #ifdef HSR_PHASE_STAMPS
   unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
@@ -195,30 +332,46 @@ __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
       for (int m = 0; m < M; ++m) acc_m[j][m] = 0.0;
   }
 
-  for (int64_t tileidx = blockIdx.x; tileidx < a.ntiles; tileidx += gridDim.x) {
-    const int64_t pix0 = tileidx * P;
-    const int64_t left = a.npix - pix0;
+  // work units of this workgroup: cu = the one being processed; batch launches stage the record of the next one
+  // (index nidx) in LDS, see unit_from_lds
+  SrfUnit cu;
+  if (BATCH) {
+    cu = a.units[blockIdx.x];
+  } else {
+    cu = a.one;
+    cu.slot = blockIdx.x;
+    cu.part_dev = a.one.part_dev + blockIdx.x;
+  }
+  int64_t nidx = (int64_t)blockIdx.x + gridDim.x;
+  int g = cu.slot;
+  bool pend = false;             // a finished unit's sums still sit in acc_m (batch launches)
+  double* pend_part = nullptr;
+  int pend_slots = 0;
+
+  for (bool more = true; more;) {
+    const int64_t pix0 = (int64_t)g * P;
+    const int64_t left = cu.npix - pix0;
     const int npx = left < P ? (int)left : P;
-    const float* src = a.cube + pix0 * B;
+    const float* src = reinterpret_cast<const float*>(cu.cube_dev) + pix0 * B;
     const bool pvalid = pl < npx;
 
     // operands of the fused fit (2 target values + 1 mask byte per thread).  hipcc drains vmcnt to 0
     // whenever ordinary VGPR loads and LDS-DMA mix (before the DMA issue if the loads come first, before
-    // the loads if they come second), which exposed one extra HBM round trip per tile (+20 us on the
+    // the loads if they come second), which exposed one extra HBM round trip per group (+20 us on the
     // kernel).  So these loads are issued from inline asm, invisible to the waitcnt pass, right after the
-    // DMA; they retire under the same wait as the tile (explicit vmcnt(0) after the barrier) and the
+    // DMA; they retire under the same wait as the group (explicit vmcnt(0) after the barrier) and the
     // registers are pinned there so that no use can be scheduled ahead of it.
     float yv[kBandSlots];
     uint32_t mraw = 1u;
     auto load_targets = [&]() {
       if (DEG > 0) {
-        const int64_t pc = pvalid ? pix0 + pl : a.npix - 1;   // clamped: always a valid address, no branch
+        const int64_t pc = pvalid ? pix0 + pl : cu.npix - 1;   // clamped: always a valid address, no branch
 #pragma unroll
         for (int j = 0; j < kBandSlots; ++j) {
           const int bb = bidx[j];
-          yv[j] = load_f32_async(a.real + bb * a.real_bs + pc * a.real_ps);
+          yv[j] = load_f32_async(cu.real_dev + bb * a.real_bs + pc * a.real_ps);
         }
-        if (a.mask != nullptr) mraw = load_u8_async(a.mask + pc);
+        if (cu.mask_dev != nullptr) mraw = load_u8_async(cu.mask_dev + pc);
       }
     };
     auto wait_targets = [&]() {
@@ -228,17 +381,29 @@ __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
         asm volatile("" : "+v"(yv[0]), "+v"(yv[1]), "+v"(mraw));
       }
     };
+    // everything that fills the wait for the DMA: targets, the next unit record, the previous group's output slab,
+    // the previous unit's sums
+    auto behind_the_dma = [&]() {
+      load_targets();
+      if (BATCH && wave == 0 && lane < 16)
+        __builtin_amdgcn_global_load_lds((gptr_t)unit_record_addr(a.units, nidx, a.nunits, lane), (lptr_t)ustage, 4, 0, 0);
+      if (OUTV) flush_stage<8 * P>(ostage, prev_out, prev_pix0, prev_npx, ops, t);   // no-op before the first group
+      if (BATCH && DEG > 0 && pend) {
+        flush_moments<M, P, true>(acc_m, bval, bidx, pend_part, pend_slots, lane);
+        pend = false;
+      }
+    };
 
     HSR_STAMP(st0);
     if (t < P) flags[t] = 0u;
 
-    const bool fast_tile = FAST && npx == P;
+    const bool fast_group = FAST && npx == P;
     // Order matters (measured, and checked in the .s): the DMA is issued FIRST - anything ahead of it is
     // dead time (flushing the previous slab first cost +12 us on the kernel); then the small target loads
     // (inline asm, see above); then the flush of the previous slab, whose ds_reads see the pending LDS-DMA
-    // and make hipcc wait vmcnt(0) - i.e. it runs once the tile (and the targets) have landed, just ahead
+    // and make hipcc wait vmcnt(0) - i.e. it runs once the group (and the targets) have landed, just ahead
     // of the barrier that waits for the same thing.
-    if (fast_tile) {
+    if (fast_group) {
       const char* srcb = reinterpret_cast<const char*>(src);
       for (int c0 = wave * 64; c0 < nchunk; c0 += T) {  // c0 is wave-uniform
         const int c = c0 + lane;
@@ -246,15 +411,16 @@ __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
           __builtin_amdgcn_global_load_lds((gptr_t)(srcb + (size_t)c * 16), (lptr_t)(smem + (size_t)c0 * 16),
                                            16, 0, kGldsStream);
       }
-      load_targets();
-      if (OUTV) flush_stage<8 * P>(ostage, a.out, prev_pix0, prev_npx, ops, t);
-      HSR_STAMP(st1);
-      __syncthreads();
-      wait_targets();
-      HSR_STAMP(st2);
+    }
+    behind_the_dma();   // one call site: with two, the batch kernels' copy is not inlined and acc_m lives in scratch
+    HSR_STAMP(st1);
+    __syncthreads();    // the group has landed (generic loader: flags zeroed before anybody sets one)
+    wait_targets();
+    HSR_STAMP(st2);
+    if (fast_group) {
       // non-finite sweep: kScanBatch independent ds_read_b128 in flight per thread (a serial
-      // read->wait->test loop cost 3.7k cycles per tile; batched it is LDS-bandwidth bound).
-      // Indices past the tile are clamped to its last chunk (a harmless re-read, no predication).
+      // read->wait->test loop cost 3.7k cycles per group; batched it is LDS-bandwidth bound).
+      // Indices past the group are clamped to its last chunk (a harmless re-read, no predication).
       const float4* t4 = reinterpret_cast<const float4*>(smem);
       for (int c0 = t; c0 < nchunk; c0 += T * kScanBatch) {
         float4 v[kScanBatch];
@@ -283,11 +449,7 @@ __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
       if (a.stamps) { stamp_acc[0] += st1 - st0; stamp_acc[1] += st2 - st1; stamp_acc[2] += st3 - st2; }
 #endif
     } else {
-      // generic loader: any 4-byte alignment, any B, ragged last tile.  One pixel row per wave step.
-      load_targets();
-      if (OUTV) flush_stage<8 * P>(ostage, a.out, prev_pix0, prev_npx, ops, t);
-      __syncthreads();  // flags zeroed before anybody sets one
-      wait_targets();
+      // generic loader: any 4-byte alignment, any B, ragged last group.  One pixel row per wave step.
       for (int pp = wave; pp < npx; pp += NW) {
         bool bad = false;
         for (int k = lane; k < B; k += 64) {
@@ -314,16 +476,19 @@ __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
         // so the sum is bit-identical to the exact-support sum.  One chunk = 4 broadcast
         // ds_read_b128 (weights) + 16 ds_read_b32 (samples, stride ldsB words: conflict-free)
         // issued together, then a 16-deep fma chain: no serial remainder loop.
+        // (batch kernels read 8 taps at a time: the unit bookkeeping needs the registers, and 16 + 16 operands in
+        // flight pushed a dozen loop invariants of the hot path into scratch; same taps, same order, same bits)
+        constexpr int CH = BATCH ? kTapChunk / 2 : kTapChunk;
         const float4* w4 = reinterpret_cast<const float4*>(wl + bwo[j]);
-        for (int i0 = 0; i0 < bkl[j]; i0 += kTapChunk) {
-          float4 ww[kTapChunk / 4];
-          float xv[kTapChunk];
+        for (int i0 = 0; i0 < bkl[j]; i0 += CH) {
+          float4 ww[CH / 4];
+          float xv[CH];
 #pragma unroll
-          for (int u = 0; u < kTapChunk / 4; ++u) ww[u] = w4[(i0 >> 2) + u];
+          for (int u = 0; u < CH / 4; ++u) ww[u] = w4[(i0 >> 2) + u];
 #pragma unroll
-          for (int u = 0; u < kTapChunk; ++u) xv[u] = vs[i0 + u];
+          for (int u = 0; u < CH; ++u) xv[u] = vs[i0 + u];
 #pragma unroll
-          for (int u = 0; u < kTapChunk / 4; ++u) {
+          for (int u = 0; u < CH / 4; ++u) {
             acc = fmaf(ww[u].x, xv[4 * u + 0], acc);
             acc = fmaf(ww[u].y, xv[4 * u + 1], acc);
             acc = fmaf(ww[u].z, xv[4 * u + 2], acc);
@@ -352,7 +517,7 @@ __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
       if (bval[j]) {
         const float acc = accv[j];
         if (OUTV) ostage[pl * ops + bidx[j]] = acc;
-        else if (pvalid) st_stream(a.out + bidx[j] * a.out_bs + (pix0 + pl) * a.out_ps, acc);
+        else if (pvalid) st_stream(cu.pseudo_dev + bidx[j] * a.out_bs + (pix0 + pl) * a.out_ps, acc);
         if (DEG > 0) {
           const float y = yv[j];
           const bool ok = pvalid && mraw != 0u && finite_f32(acc) && finite_f32(y) && acc > a.min_x && y > a.min_y;
@@ -371,8 +536,23 @@ __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
         }
       }
     }
+    prev_out = cu.pseudo_dev;
     prev_pix0 = pix0;
     prev_npx = npx;
+    // next group of this unit, or the next unit of this workgroup
+    g += cu.slots;
+    if (g >= cu.ngroups) {
+      pend = true;
+      pend_part = cu.part_dev;
+      pend_slots = cu.slots;
+      if (BATCH && nidx < a.nunits) {
+        cu = unit_from_lds(ustage);     // landed before the barrier that published this group
+        g = cu.slot;
+        nidx += gridDim.x;
+      } else {
+        more = false;
+      }
+    }
     HSR_STAMP(st5);
     // The tile and the flags are rewritten by the next iteration: an LDS-only hazard.  A plain
     // __syncthreads() here would also wait (vmcnt(0)) for the plane stores just issued.
@@ -384,26 +564,12 @@ __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
     }
 #endif
   }
-  if (OUTV) flush_stage<8 * P>(ostage, a.out, prev_pix0, prev_npx, ops, t);  // last tile (after the barrier)
+  if (OUTV) flush_stage<8 * P>(ostage, prev_out, prev_pix0, prev_npx, ops, t);  // last group (after the barrier)
 #ifdef HSR_PHASE_STAMPS
   if (a.stamps && lane == 0)
     for (int k = 0; k < 8; ++k) a.stamps[((size_t)blockIdx.x * NW + wave) * 8 + k] = stamp_acc[k];
 #endif
-
-  if (DEG > 0) {
-    // fixed butterfly over the P lanes that share a band (whole wave for P = 64, half wave for P = 32)
-#pragma unroll
-    for (int j = 0; j < kBandSlots; ++j) {
-#pragma unroll
-      for (int m = 0; m < M; ++m) {
-        double sv = acc_m[j][m];
-#pragma unroll
-        for (int off = (P < 64 ? P : 64) / 2; off >= 1; off >>= 1) sv += __shfl_xor(sv, off, 64);
-        if (bval[j] && (lane % P) == 0)
-          a.partials[((size_t)bidx[j] * M + m) * a.slots + blockIdx.x] = sv;
-      }
-    }
-  }
+  if (DEG > 0 && pend) flush_moments<M, P, true>(acc_m, bval, bidx, pend_part, pend_slots, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -413,28 +579,108 @@ __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
 // happens on the way out of LDS, one separately rounded multiply per tap, so that the planes and the
 // moments are bit-identical to hsr_tile_decode_u16 followed by the float32 kernel.  A pixel holding a
 // nodata sample decodes to NaN there, and 0 * NaN poisons every band: flagged pixels are NaN in all
-// bands.  64-pixel tiles (P*B*2 = 128*B bytes: always whole 16-byte chunks), 8 waves, lane = pixel.
-template <int DEG, bool FAST, bool OUTV>
+// bands.  64-pixel groups (P*B*2 = 128*B bytes: always whole 16-byte chunks), 8 waves.
+// lane -> pixel: lanes 0..31 take the even pixels of the group, lanes 32..63 the odd ones.  A pixel row is
+// 2*B bytes = B/2 dwords (142.5 for B = 285), so with lane = pixel neighbouring rows alternate between two
+// bank phases and 10 of 16 lane pairs collide; inside each half-wave the rows now start B dwords apart
+// (odd -> conflict-free, as in the float32 kernel).
+
+// Power sums of one (x, y) sample into the per-lane accumulators of a band.
+template <int DEG>
+__device__ __forceinline__ void moments_accumulate(double (&acc)[DEG > 0 ? moment_count(DEG) : 1], float x, float y) {
+  if (DEG == 0) return;
+  const double xd = (double)x, yd = (double)y;
+  acc[0] += 1.0;
+  acc[2 * DEG + 1] += yd;
+  double pw = 1.0;
+#pragma unroll
+  for (int k = 1; k <= 2 * DEG; ++k) {
+    pw *= xd;
+    acc[k] += pw;
+    if (k <= DEG) acc[2 * DEG + 1 + k] += pw * yd;
+  }
+}
+
+// nodata sweep of one group held in LDS: a 16-bit lane of (v ^ nodata:nodata) is zero exactly where the sample is nodata
+__device__ __forceinline__ void u16_nodata_sweep(const uint4* t4, int nchunk, int nsamples, int B, uint32_t nd2,
+                                                 uint32_t nodata, uint32_t* fl, int t) {
+  constexpr int T = 512;
+  for (int c0 = t; c0 < nchunk; c0 += T * kScanBatch) {
+    uint4 v[kScanBatch];
+#pragma unroll
+    for (int u = 0; u < kScanBatch; ++u) {
+      const int c = c0 + u * T;
+      v[u] = t4[c < nchunk ? c : nchunk - 1];
+    }
+    uint32_t hit = 0u;
+#pragma unroll
+    for (int u = 0; u < kScanBatch; ++u) {
+      const uint32_t w[4] = {v[u].x ^ nd2, v[u].y ^ nd2, v[u].z ^ nd2, v[u].w ^ nd2};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) hit |= (w[q] - 0x00010001u) & ~w[q] & 0x80008000u;
+    }
+    if (hit) {  // rare
+#pragma unroll
+      for (int u = 0; u < kScanBatch; ++u) {
+        const int c = c0 + u * T;
+        const int e = (c < nchunk ? c : nchunk - 1) * 8;
+        const uint32_t w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          if ((w[q] & 0xffffu) == (nodata & 0xffffu) && e + 2 * q < nsamples) fl[(e + 2 * q) / B] = 1u;
+          if ((w[q] >> 16) == (nodata & 0xffffu) && e + 2 * q + 1 < nsamples) fl[(e + 2 * q + 1) / B] = 1u;
+        }
+      }
+    }
+  }
+}
+
+// One band of one pixel from a uint16 group in LDS.  16 taps = 9 aligned dwords (two samples each; one extra because
+// odd sample offsets start in the middle of a dword) realigned per lane with v_alignbyte: 9 ds_read_b32 instead of
+// 16 ds_read_u16.  The ninth dword may lie past the row (next pixel / the flag words): its upper half is never used.
+__device__ __forceinline__ float u16_band_dot(const uint16_t* tile, int e0, const float4* w4, int klen, float scale) {
+  float acc = 0.0f;
+  const uint32_t sh = (uint32_t)(e0 & 1) * 2u;
+  const uint32_t* d32 = reinterpret_cast<const uint32_t*>(tile) + (e0 >> 1);
+  for (int i0 = 0; i0 < klen; i0 += kTapChunk) {
+    float4 ww[kTapChunk / 4];
+    uint32_t d[kTapChunk / 2 + 1];
+#pragma unroll
+    for (int u = 0; u < kTapChunk / 4; ++u) ww[u] = w4[(i0 >> 2) + u];
+#pragma unroll
+    for (int u = 0; u <= kTapChunk / 2; ++u) d[u] = d32[(i0 >> 1) + u];
+#pragma unroll
+    for (int u = 0; u < kTapChunk / 4; ++u) {
+      const uint32_t ea = __builtin_amdgcn_alignbyte(d[2 * u + 1], d[2 * u], sh);
+      const uint32_t eb = __builtin_amdgcn_alignbyte(d[2 * u + 2], d[2 * u + 1], sh);
+      acc = fmaf(ww[u].x, (float)(ea & 0xffffu) * scale, acc);
+      acc = fmaf(ww[u].y, (float)(ea >> 16) * scale, acc);
+      acc = fmaf(ww[u].z, (float)(eb & 0xffffu) * scale, acc);
+      acc = fmaf(ww[u].w, (float)(eb >> 16) * scale, acc);
+    }
+  }
+  return acc;
+}
+
+template <int DEG, bool FAST, bool OUTV, bool BATCH>
 __global__ __launch_bounds__(512, 4) void srf_u16_kernel(const SrfArgs a) {
   constexpr int P = 64, T = 512;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   uint16_t* tile = reinterpret_cast<uint16_t*>(smem);
   const int B = a.B;
   uint32_t* flags = reinterpret_cast<uint32_t*>(smem + (size_t)P * B * 2);
-  const float* wl = reinterpret_cast<const float*>(flags + 64);
+  uint32_t* ustage = flags + 64;                                  // [16] record of the next unit (batch launches)
+  const float* wl = reinterpret_cast<const float*>(flags + 64 + (BATCH ? 16 : 0));
   const bool wlds = a.wtaps > 0;
   float* ostage = const_cast<float*>(wl) + a.wtaps;
   const int ops = (int)a.out_ps;
+  float* prev_out = nullptr;
   int64_t prev_pix0 = 0;
   int prev_npx = 0;
 
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  // lane -> pixel: lanes 0..31 take the even pixels of the tile, lanes 32..63 the odd ones.  A pixel row is
-  // 2*B bytes = B/2 dwords (142.5 for B = 285), so with lane = pixel neighbouring rows alternate between two
-  // bank phases and 10 of 16 lane pairs collide; inside each half-wave the rows now start B dwords apart
-  // (odd -> conflict-free, as in the float32 kernel).
   const int pl = 2 * (lane & 31) + (lane >> 5), grp = wave;
   const float scale = a.scale;
   const uint32_t nd2 = (a.nodata & 0xffffu) * 0x00010001u;
@@ -458,6 +704,7 @@ __global__ __launch_bounds__(512, 4) void srf_u16_kernel(const SrfArgs a) {
       for (int i = t; i < kl; i += T) wlw[a.bands.woff[b] + i] = a.wn[(size_t)b * B + a.bands.k0[b] + i];
     }
   }
+  if (OUTV) zero_stage_pad<T>(ostage, P, a.nb, ops, t);
 
   constexpr int M = DEG > 0 ? moment_count(DEG) : 1;
   double acc_m[kBandSlots][M];
@@ -467,25 +714,38 @@ __global__ __launch_bounds__(512, 4) void srf_u16_kernel(const SrfArgs a) {
 #pragma unroll
       for (int m = 0; m < M; ++m) acc_m[j][m] = 0.0;
   }
-  const uint16_t* cube = reinterpret_cast<const uint16_t*>(a.cube);
 
-  for (int64_t tileidx = blockIdx.x; tileidx < a.ntiles; tileidx += gridDim.x) {
-    const int64_t pix0 = tileidx * P;
-    const int64_t left = a.npix - pix0;
+  SrfUnit cu;   // see srf_kernel
+  if (BATCH) {
+    cu = a.units[blockIdx.x];
+  } else {
+    cu = a.one;
+    cu.slot = blockIdx.x;
+    cu.part_dev = a.one.part_dev + blockIdx.x;
+  }
+  int64_t nidx = (int64_t)blockIdx.x + gridDim.x;
+  int g = cu.slot;
+  bool pend = false;
+  double* pend_part = nullptr;
+  int pend_slots = 0;
+
+  for (bool more = true; more;) {
+    const int64_t pix0 = (int64_t)g * P;
+    const int64_t left = cu.npix - pix0;
     const int npx = left < P ? (int)left : P;
-    const uint16_t* src = cube + pix0 * B;
+    const uint16_t* src = reinterpret_cast<const uint16_t*>(cu.cube_dev) + pix0 * B;
     const bool pvalid = pl < npx;
-    const int nchunk = (npx * B + 7) >> 3;  // 16-byte chunks (8 samples) holding the tile
+    const int nchunk = (npx * B + 7) >> 3;  // 16-byte chunks (8 samples) holding the group
 
     // targets of the fused fit: inline-asm loads right after the DMA (see srf_kernel for why)
     float yv[kBandSlots];
     uint32_t mraw = 1u;
     auto load_targets = [&]() {
       if (DEG > 0) {
-        const int64_t pc = pvalid ? pix0 + pl : a.npix - 1;
+        const int64_t pc = pvalid ? pix0 + pl : cu.npix - 1;
 #pragma unroll
-        for (int j = 0; j < kBandSlots; ++j) yv[j] = load_f32_async(a.real + bidx[j] * a.real_bs + pc * a.real_ps);
-        if (a.mask != nullptr) mraw = load_u8_async(a.mask + pc);
+        for (int j = 0; j < kBandSlots; ++j) yv[j] = load_f32_async(cu.real_dev + bidx[j] * a.real_bs + pc * a.real_ps);
+        if (cu.mask_dev != nullptr) mraw = load_u8_async(cu.mask_dev + pc);
       }
     };
     auto wait_targets = [&]() {
@@ -495,9 +755,20 @@ __global__ __launch_bounds__(512, 4) void srf_u16_kernel(const SrfArgs a) {
         asm volatile("" : "+v"(yv[0]), "+v"(yv[1]), "+v"(mraw));
       }
     };
+    auto behind_the_dma = [&]() {
+      load_targets();
+      if (BATCH && wave == 0 && lane < 16)
+        __builtin_amdgcn_global_load_lds((gptr_t)unit_record_addr(a.units, nidx, a.nunits, lane), (lptr_t)ustage, 4, 0, 0);
+      if (OUTV) flush_stage<T>(ostage, prev_out, prev_pix0, prev_npx, ops, t);
+      if (BATCH && DEG > 0 && pend) {
+        flush_moments<M, P, false>(acc_m, bval, bidx, pend_part, pend_slots, lane);
+        pend = false;
+      }
+    };
 
     if (t < P) flags[t] = 0u;
-    if (FAST && npx == P) {
+    const bool fast_group = FAST && npx == P;
+    if (fast_group) {
       const char* srcb = reinterpret_cast<const char*>(src);
       for (int c0 = wave * 64; c0 < nchunk; c0 += T) {
         const int c = c0 + lane;
@@ -505,130 +776,65 @@ __global__ __launch_bounds__(512, 4) void srf_u16_kernel(const SrfArgs a) {
           __builtin_amdgcn_global_load_lds((gptr_t)(srcb + (size_t)c * 16), (lptr_t)(smem + (size_t)c0 * 16),
                                            16, 0, kGldsStream);
       }
-      load_targets();
-      if (OUTV) flush_stage<T>(ostage, a.out, prev_pix0, prev_npx, ops, t);
+    }
+    behind_the_dma();   // one call site (see srf_kernel)
+    if (fast_group) {
       __syncthreads();
       wait_targets();
     } else {
-      // generic loader: any 2-byte alignment, ragged last tile; the tail of the last chunk is zeroed
-      load_targets();
-      if (OUTV) flush_stage<T>(ostage, a.out, prev_pix0, prev_npx, ops, t);
+      // generic loader: any 2-byte alignment, ragged last group; the tail of the last chunk is zeroed
       wait_targets();
       const int n = npx * B;
       for (int i = t; i < nchunk * 8; i += T) tile[i] = i < n ? ld_stream(src + i) : (uint16_t)0;
       __syncthreads();
     }
     if (has_nodata) {
-      // nodata sweep: a 16-bit lane of (v ^ nodata:nodata) is zero exactly where the sample is nodata
-      const uint4* t4 = reinterpret_cast<const uint4*>(smem);
-      for (int c0 = t; c0 < nchunk; c0 += T * kScanBatch) {
-        uint4 v[kScanBatch];
-#pragma unroll
-        for (int u = 0; u < kScanBatch; ++u) {
-          const int c = c0 + u * T;
-          v[u] = t4[c < nchunk ? c : nchunk - 1];
-        }
-        uint32_t hit = 0u;
-#pragma unroll
-        for (int u = 0; u < kScanBatch; ++u) {
-          const uint32_t w[4] = {v[u].x ^ nd2, v[u].y ^ nd2, v[u].z ^ nd2, v[u].w ^ nd2};
-#pragma unroll
-          for (int q = 0; q < 4; ++q) hit |= (w[q] - 0x00010001u) & ~w[q] & 0x80008000u;
-        }
-        if (hit) {  // rare
-#pragma unroll
-          for (int u = 0; u < kScanBatch; ++u) {
-            const int c = c0 + u * T;
-            const int e = (c < nchunk ? c : nchunk - 1) * 8;
-            const uint32_t w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              if ((w[q] & 0xffffu) == (a.nodata & 0xffffu) && e + 2 * q < npx * B) flags[(e + 2 * q) / B] = 1u;
-              if ((w[q] >> 16) == (a.nodata & 0xffffu) && e + 2 * q + 1 < npx * B) flags[(e + 2 * q + 1) / B] = 1u;
-            }
-          }
-        }
-      }
+      u16_nodata_sweep(reinterpret_cast<const uint4*>(smem), nchunk, npx * B, B, nd2, a.nodata, flags, t);
       __syncthreads();
     }
 
     const bool bad = flags[pl] != 0u;
-    const uint16_t* v = tile + pl * B;
 #pragma unroll
     for (int j = 0; j < kBandSlots; ++j) {
       float acc = 0.0f;
-      const uint16_t* vs = v + bk0[j];
       if (wlds) {
-        // 16 taps = 9 aligned dwords (two samples each; one extra because odd sample offsets start in the
-        // middle of a dword) realigned per lane with v_alignbyte: 9 ds_read_b32 instead of 16 ds_read_u16.
-        // The ninth dword may lie past the row (next pixel / the flag words): its upper half is never used.
-        const float4* w4 = reinterpret_cast<const float4*>(wl + bwo[j]);
-        const int e0 = pl * B + bk0[j];
-        const uint32_t sh = (uint32_t)(e0 & 1) * 2u;
-        const uint32_t* d32 = reinterpret_cast<const uint32_t*>(smem) + (e0 >> 1);
-        for (int i0 = 0; i0 < bkl[j]; i0 += kTapChunk) {
-          float4 ww[kTapChunk / 4];
-          uint32_t d[kTapChunk / 2 + 1];
-#pragma unroll
-          for (int u = 0; u < kTapChunk / 4; ++u) ww[u] = w4[(i0 >> 2) + u];
-#pragma unroll
-          for (int u = 0; u <= kTapChunk / 2; ++u) d[u] = d32[(i0 >> 1) + u];
-#pragma unroll
-          for (int u = 0; u < kTapChunk / 4; ++u) {
-            const uint32_t ea = __builtin_amdgcn_alignbyte(d[2 * u + 1], d[2 * u], sh);
-            const uint32_t eb = __builtin_amdgcn_alignbyte(d[2 * u + 2], d[2 * u + 1], sh);
-            acc = fmaf(ww[u].x, (float)(ea & 0xffffu) * scale, acc);
-            acc = fmaf(ww[u].y, (float)(ea >> 16) * scale, acc);
-            acc = fmaf(ww[u].z, (float)(eb & 0xffffu) * scale, acc);
-            acc = fmaf(ww[u].w, (float)(eb >> 16) * scale, acc);
-          }
-        }
+        acc = u16_band_dot(tile, pl * B + bk0[j], reinterpret_cast<const float4*>(wl + bwo[j]), bkl[j], scale);
       } else {
+        const uint16_t* vs = tile + pl * B + bk0[j];
         const float* ws = a.wn + (size_t)bidx[j] * B + bk0[j];
         for (int i = 0; i < bkl[j]; ++i) acc = fmaf(ws[i], (float)vs[i] * scale, acc);
       }
       if (bad) acc = __uint_as_float(0x7fc00000u);
       if (bval[j]) {
         if (OUTV) ostage[pl * ops + bidx[j]] = acc;
-        else if (pvalid) st_stream(a.out + bidx[j] * a.out_bs + (pix0 + pl) * a.out_ps, acc);
+        else if (pvalid) st_stream(cu.pseudo_dev + bidx[j] * a.out_bs + (pix0 + pl) * a.out_ps, acc);
         if (DEG > 0) {
           const float y = yv[j];
           const bool ok = pvalid && mraw != 0u && finite_f32(acc) && finite_f32(y) && acc > a.min_x && y > a.min_y;
-          if (ok) {
-            const double xd = (double)acc, yd = (double)y;
-            acc_m[j][0] += 1.0;
-            acc_m[j][2 * DEG + 1] += yd;
-            double pw = 1.0;
-#pragma unroll
-            for (int k = 1; k <= 2 * DEG; ++k) {
-              pw *= xd;
-              acc_m[j][k] += pw;
-              if (k <= DEG) acc_m[j][2 * DEG + 1 + k] += pw * yd;
-            }
-          }
+          if (ok) moments_accumulate<DEG>(acc_m[j], acc, y);
         }
       }
     }
+    prev_out = cu.pseudo_dev;
     prev_pix0 = pix0;
     prev_npx = npx;
-    lds_barrier();
-  }
-  if (OUTV) flush_stage<T>(ostage, a.out, prev_pix0, prev_npx, ops, t);
-
-  if (DEG > 0) {
-#pragma unroll
-    for (int j = 0; j < kBandSlots; ++j) {
-#pragma unroll
-      for (int m = 0; m < M; ++m) {
-        // bring the accumulator of pixel q to lane q first: the butterfly then adds in exactly the order of
-        // the float32 kernel (lane = pixel), so the partial sums are bit-identical to decode + float32 K1
-        double sv = __shfl(acc_m[j][m], (lane >> 1) + 32 * (lane & 1), 64);
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) sv += __shfl_xor(sv, off, 64);
-        if (bval[j] && lane == 0) a.partials[((size_t)bidx[j] * M + m) * a.slots + blockIdx.x] = sv;
+    g += cu.slots;
+    if (g >= cu.ngroups) {
+      pend = true;
+      pend_part = cu.part_dev;
+      pend_slots = cu.slots;
+      if (BATCH && nidx < a.nunits) {
+        cu = unit_from_lds(ustage);
+        g = cu.slot;
+        nidx += gridDim.x;
+      } else {
+        more = false;
       }
     }
+    lds_barrier();
   }
+  if (OUTV) flush_stage<T>(ostage, prev_out, prev_pix0, prev_npx, ops, t);
+  if (DEG > 0 && pend) flush_moments<M, P, false>(acc_m, bval, bidx, pend_part, pend_slots, lane);
 }
 
 // LDS-DMA issued from inline asm: the compiler's waitcnt pass then does not know a DMA is pending and does
@@ -637,21 +843,28 @@ __device__ __forceinline__ void glds16_nt_asm(const void* gaddr, uint32_t lds_ba
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off nt" ::"v"(gaddr), "s"(lds_base) : "memory");
 }
 
-// Double-buffered form of srf_u16_kernel for 16-byte aligned cubes (the normal case).  A uint16 tile is
-// half the bytes of a float32 one, so with one tile per workgroup only ~73 KB per CU were in flight and the
-// kernel was latency-bound (0.169 ms).  Here every workgroup owns two tile buffers (2 x 36.5 KB, the LDS
-// footprint of the float32 kernel): the DMA of tile k+1 and its fit targets are issued right after the
-// barrier that publishes tile k and land while tile k is swept and reduced.  Two barriers per tile; the
-// closing barrier of the single-buffer kernel is not needed because nothing of tile k is overwritten before
+__device__ __forceinline__ void glds4_asm(const void* gaddr, uint32_t lds_base) {
+  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(gaddr), "s"(lds_base) : "memory");
+}
+
+// Double-buffered form of srf_u16_kernel for 16-byte aligned cubes (the normal case).  A uint16 group is
+// half the bytes of a float32 one, so with one group per workgroup only ~73 KB per CU were in flight and the
+// kernel was latency-bound (0.169 ms).  Here every workgroup owns two group buffers (2 x 36.5 KB, the LDS
+// footprint of the float32 kernel): the DMA of group k+1 and its fit targets are issued right after the
+// barrier that publishes group k and land while group k is swept and reduced.  Two barriers per group; the
+// closing barrier of the single-buffer kernel is not needed because nothing of group k is overwritten before
 // the next top barrier.  Same arithmetic, same summation trees -> same bits as srf_u16_kernel.
-template <int DEG, bool OUTV>
+// Batch launches: the group after the last one of a unit is the first group of the workgroup's next unit, so three
+// unit records are alive: cu (being reduced), nu (being prefetched), nn (its record is on its way).
+template <int DEG, bool OUTV, bool BATCH>
 __global__ __launch_bounds__(512, 4) void srf_u16_ring_kernel(const SrfArgs a) {
   constexpr int P = 64, T = 512;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int B = a.B;
   const int tile_bytes = P * B * 2;   // 128*B: whole 16-byte chunks
   uint32_t* flags = reinterpret_cast<uint32_t*>(smem + 2 * (size_t)tile_bytes);   // [2][64]
-  const float* wl = reinterpret_cast<const float*>(flags + 128);
+  uint32_t* ustage = flags + 128;                                 // [2][16] records of the next unit (batch launches)
+  const float* wl = reinterpret_cast<const float*>(flags + 128 + (BATCH ? 32 : 0));
   const bool wlds = a.wtaps > 0;
   float* ostage = const_cast<float*>(wl) + a.wtaps;
   const int ops = (int)a.out_ps;
@@ -683,6 +896,7 @@ __global__ __launch_bounds__(512, 4) void srf_u16_ring_kernel(const SrfArgs a) {
       for (int i = t; i < kl; i += T) wlw[a.bands.woff[b] + i] = a.wn[(size_t)b * B + a.bands.k0[b] + i];
     }
   }
+  if (OUTV) zero_stage_pad<T>(ostage, P, a.nb, ops, t);
   constexpr int M = DEG > 0 ? moment_count(DEG) : 1;
   double acc_m[kBandSlots][M];
   if (DEG > 0) {
@@ -691,18 +905,17 @@ __global__ __launch_bounds__(512, 4) void srf_u16_ring_kernel(const SrfArgs a) {
 #pragma unroll
       for (int m = 0; m < M; ++m) acc_m[j][m] = 0.0;
   }
-  const uint16_t* cube = reinterpret_cast<const uint16_t*>(a.cube);
   const uint32_t lds0 = (uint32_t)(uintptr_t)(lptr_t)(smem);
 
-  // prefetch of one tile: LDS-DMA of the samples (full tiles only; the ragged last tile is filled by hand when
+  // prefetch of one group: LDS-DMA of the samples (full groups only; a ragged last group is filled by hand when
   // it is consumed) + the fit targets of this thread's pixel, all invisible to the compiler's waitcnt pass
   float yn[kBandSlots] = {0.0f, 0.0f};
   uint32_t mn = 1u;
-  auto prefetch = [&](int64_t tileidx, int buf) {
-    const int64_t pix0 = tileidx * P;
-    const int64_t left = a.npix - pix0;
+  auto prefetch = [&](const SrfUnit& u, int gg, int buf) {
+    const int64_t pix0 = (int64_t)gg * P;
+    const int64_t left = u.npix - pix0;
     if (left >= P) {
-      const char* srcb = reinterpret_cast<const char*>(cube + pix0 * B);
+      const char* srcb = reinterpret_cast<const char*>(reinterpret_cast<const uint16_t*>(u.cube_dev) + pix0 * B);
       for (int c0 = wave * 64; c0 < nchunk_full; c0 += T) {
         const int c = c0 + lane;
         if (c < nchunk_full)
@@ -710,21 +923,44 @@ __global__ __launch_bounds__(512, 4) void srf_u16_ring_kernel(const SrfArgs a) {
       }
     }
     if (DEG > 0) {
-      const int64_t pc = pl < left ? pix0 + pl : a.npix - 1;
+      const int64_t pc = pl < left ? pix0 + pl : u.npix - 1;
 #pragma unroll
-      for (int j = 0; j < kBandSlots; ++j) yn[j] = load_f32_async(a.real + bidx[j] * a.real_bs + pc * a.real_ps);
-      if (a.mask != nullptr) mn = load_u8_async(a.mask + pc);
+      for (int j = 0; j < kBandSlots; ++j) yn[j] = load_f32_async(u.real_dev + bidx[j] * a.real_bs + pc * a.real_ps);
+      mn = 1u;
+      if (u.mask_dev != nullptr) mn = load_u8_async(u.mask_dev + pc);
     }
   };
 
-  int64_t tileidx = blockIdx.x;
-  if (tileidx < a.ntiles) prefetch(tileidx, 0);
+  SrfUnit cu;
+  if (BATCH) {
+    cu = a.units[blockIdx.x];
+  } else {
+    cu = a.one;
+    cu.slot = blockIdx.x;
+    cu.part_dev = a.one.part_dev + blockIdx.x;
+  }
+  int g = cu.slot;
+  prefetch(cu, g, 0);
+  int64_t nidx = (int64_t)blockIdx.x + gridDim.x;   // index of the unit after cu
+  // the record of unit nidx is in ustage[cur] at the top barrier of every iteration: an LDS-DMA like the samples,
+  // issued one iteration earlier into the other half (srf_kernel explains why not through registers)
+  auto fetch_record = [&](int64_t idx, int buf) {
+    if (BATCH && wave == 0 && lane < 16)
+      glds4_asm(unit_record_addr(a.units, idx, a.nunits, lane),
+                __builtin_amdgcn_readfirstlane(lds0 + (uint32_t)((const unsigned char*)(ustage + 16 * buf) - smem)));
+  };
+  fetch_record(nidx, 0);
   int cur = 0;
+  float* prev_out = nullptr;
   int64_t prev_pix0 = 0;
   int prev_npx = 0;
-  for (; tileidx < a.ntiles; tileidx += gridDim.x, cur ^= 1) {
-    const int64_t pix0 = tileidx * P;
-    const int64_t left = a.npix - pix0;
+  bool pend = false;
+  double* pend_part = nullptr;
+  int pend_slots = 0;
+
+  for (bool more = true; more; cur ^= 1) {
+    const int64_t pix0 = (int64_t)g * P;
+    const int64_t left = cu.npix - pix0;
     const int npx = left < P ? (int)left : P;
     const bool pvalid = pl < npx;
     const int nchunk = (npx * B + 7) >> 3;
@@ -732,7 +968,7 @@ __global__ __launch_bounds__(512, 4) void srf_u16_ring_kernel(const SrfArgs a) {
     uint32_t* fl = flags + 64 * cur;
 
     if (t < P) fl[t] = 0u;
-    // everything this wave issued one iteration ago has landed: tile k, its targets, the flush of tile k-2
+    // everything this wave issued one iteration ago has landed: group k, its targets, the flush of group k-2
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     float yv[kBandSlots];
     uint32_t mraw;
@@ -741,49 +977,33 @@ __global__ __launch_bounds__(512, 4) void srf_u16_ring_kernel(const SrfArgs a) {
     yv[0] = yn[0];
     yv[1] = yn[1];
     mraw = mn;
-    if (npx < P) {  // ragged last tile: plain copy, tail of the last chunk zeroed
-      const uint16_t* src = cube + pix0 * B;
+    if (npx < P) {  // ragged last group: plain copy, tail of the last chunk zeroed
+      const uint16_t* src = reinterpret_cast<const uint16_t*>(cu.cube_dev) + pix0 * B;
       const int n = npx * B;
       for (int i = t; i < nchunk * 8; i += T) tile[i] = i < n ? src[i] : (uint16_t)0;
     }
-    __syncthreads();   // tile k (every wave's share of the DMA) and the staged planes of tile k-1 are visible
+    __syncthreads();   // group k (every wave's share of the DMA) and the staged planes of group k-1 are visible
 
-    const int64_t nxt = tileidx + gridDim.x;
-    if (nxt < a.ntiles) prefetch(nxt, cur ^ 1);   // buffer cur^1 was last read before the barrier above
-    if (OUTV) flush_stage<T>(ostage, a.out, prev_pix0, prev_npx, ops, t);
-
-    if (has_nodata) {
-      const uint4* t4 = reinterpret_cast<const uint4*>(tile);
-      for (int c0 = t; c0 < nchunk; c0 += T * kScanBatch) {
-        uint4 v[kScanBatch];
-#pragma unroll
-        for (int u = 0; u < kScanBatch; ++u) {
-          const int c = c0 + u * T;
-          v[u] = t4[c < nchunk ? c : nchunk - 1];
-        }
-        uint32_t hit = 0u;
-#pragma unroll
-        for (int u = 0; u < kScanBatch; ++u) {
-          const uint32_t w[4] = {v[u].x ^ nd2, v[u].y ^ nd2, v[u].z ^ nd2, v[u].w ^ nd2};
-#pragma unroll
-          for (int q = 0; q < 4; ++q) hit |= (w[q] - 0x00010001u) & ~w[q] & 0x80008000u;
-        }
-        if (hit) {  // rare
-#pragma unroll
-          for (int u = 0; u < kScanBatch; ++u) {
-            const int c = c0 + u * T;
-            const int e = (c < nchunk ? c : nchunk - 1) * 8;
-            const uint32_t w[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              if ((w[q] & 0xffffu) == (a.nodata & 0xffffu) && e + 2 * q < npx * B) fl[(e + 2 * q) / B] = 1u;
-              if ((w[q] >> 16) == (a.nodata & 0xffffu) && e + 2 * q + 1 < npx * B) fl[(e + 2 * q + 1) / B] = 1u;
-            }
-          }
-        }
-      }
+    // group k+1: the next group of this unit, or the first group of the workgroup's next unit.
+    // Buffer cur^1 was last read before the barrier above.
+    const int g2 = g + cu.slots;
+    const bool same_unit = g2 < cu.ngroups;
+    const bool next_unit = BATCH && !same_unit && nidx < a.nunits;
+    if (same_unit) {
+      prefetch(cu, g2, cur ^ 1);
+    } else if (next_unit) {
+      const SrfUnit nu = unit_from_lds(ustage + 16 * cur);
+      prefetch(nu, nu.slot, cur ^ 1);
     }
-    // flags of tile k complete; also orders the flush reads of the staged slab before the writes below
+    fetch_record(next_unit ? nidx + gridDim.x : nidx, cur ^ 1);
+    if (OUTV) flush_stage<T>(ostage, prev_out, prev_pix0, prev_npx, ops, t);
+    if (BATCH && DEG > 0 && pend) {
+      flush_moments<M, P, false>(acc_m, bval, bidx, pend_part, pend_slots, lane);
+      pend = false;
+    }
+
+    if (has_nodata) u16_nodata_sweep(reinterpret_cast<const uint4*>(tile), nchunk, npx * B, B, nd2, a.nodata, fl, t);
+    // flags of group k complete; also orders the flush reads of the staged slab before the writes below
     lds_barrier();
 
     const bool bad = fl[pl] != 0u;
@@ -791,27 +1011,7 @@ __global__ __launch_bounds__(512, 4) void srf_u16_ring_kernel(const SrfArgs a) {
     for (int j = 0; j < kBandSlots; ++j) {
       float acc = 0.0f;
       if (wlds) {
-        const float4* w4 = reinterpret_cast<const float4*>(wl + bwo[j]);
-        const int e0 = pl * B + bk0[j];
-        const uint32_t sh = (uint32_t)(e0 & 1) * 2u;
-        const uint32_t* d32 = reinterpret_cast<const uint32_t*>(tile) + (e0 >> 1);
-        for (int i0 = 0; i0 < bkl[j]; i0 += kTapChunk) {
-          float4 ww[kTapChunk / 4];
-          uint32_t d[kTapChunk / 2 + 1];
-#pragma unroll
-          for (int u = 0; u < kTapChunk / 4; ++u) ww[u] = w4[(i0 >> 2) + u];
-#pragma unroll
-          for (int u = 0; u <= kTapChunk / 2; ++u) d[u] = d32[(i0 >> 1) + u];
-#pragma unroll
-          for (int u = 0; u < kTapChunk / 4; ++u) {
-            const uint32_t ea = __builtin_amdgcn_alignbyte(d[2 * u + 1], d[2 * u], sh);
-            const uint32_t eb = __builtin_amdgcn_alignbyte(d[2 * u + 2], d[2 * u + 1], sh);
-            acc = fmaf(ww[u].x, (float)(ea & 0xffffu) * scale, acc);
-            acc = fmaf(ww[u].y, (float)(ea >> 16) * scale, acc);
-            acc = fmaf(ww[u].z, (float)(eb & 0xffffu) * scale, acc);
-            acc = fmaf(ww[u].w, (float)(eb >> 16) * scale, acc);
-          }
-        }
+        acc = u16_band_dot(tile, pl * B + bk0[j], reinterpret_cast<const float4*>(wl + bwo[j]), bkl[j], scale);
       } else {
         const uint16_t* vs = tile + pl * B + bk0[j];
         const float* ws = a.wn + (size_t)bidx[j] * B + bk0[j];
@@ -820,162 +1020,167 @@ __global__ __launch_bounds__(512, 4) void srf_u16_ring_kernel(const SrfArgs a) {
       if (bad) acc = __uint_as_float(0x7fc00000u);
       if (bval[j]) {
         if (OUTV) ostage[pl * ops + bidx[j]] = acc;
-        else if (pvalid) st_stream(a.out + bidx[j] * a.out_bs + (pix0 + pl) * a.out_ps, acc);
+        else if (pvalid) st_stream(cu.pseudo_dev + bidx[j] * a.out_bs + (pix0 + pl) * a.out_ps, acc);
         if (DEG > 0) {
           const float y = yv[j];
           const bool ok = pvalid && mraw != 0u && finite_f32(acc) && finite_f32(y) && acc > a.min_x && y > a.min_y;
-          if (ok) {
-            const double xd = (double)acc, yd = (double)y;
-            acc_m[j][0] += 1.0;
-            acc_m[j][2 * DEG + 1] += yd;
-            double pw = 1.0;
-#pragma unroll
-            for (int k = 1; k <= 2 * DEG; ++k) {
-              pw *= xd;
-              acc_m[j][k] += pw;
-              if (k <= DEG) acc_m[j][2 * DEG + 1 + k] += pw * yd;
-            }
-          }
+          if (ok) moments_accumulate<DEG>(acc_m[j], acc, y);
         }
       }
     }
+    prev_out = cu.pseudo_dev;
     prev_pix0 = pix0;
     prev_npx = npx;
-  }
-  if (OUTV) {
-    __syncthreads();
-    flush_stage<T>(ostage, a.out, prev_pix0, prev_npx, ops, t);
-  }
-
-  if (DEG > 0) {
-#pragma unroll
-    for (int j = 0; j < kBandSlots; ++j) {
-#pragma unroll
-      for (int m = 0; m < M; ++m) {
-        double sv = __shfl(acc_m[j][m], (lane >> 1) + 32 * (lane & 1), 64);
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) sv += __shfl_xor(sv, off, 64);
-        if (bval[j] && lane == 0) a.partials[((size_t)bidx[j] * M + m) * a.slots + blockIdx.x] = sv;
+    if (same_unit) {
+      g = g2;
+    } else {
+      pend = true;
+      pend_part = cu.part_dev;
+      pend_slots = cu.slots;
+      if (next_unit) {
+        cu = unit_from_lds(ustage + 16 * cur);   // decoded again rather than held in 15 SGPRs across the dot products
+        g = cu.slot;
+        nidx += gridDim.x;
+      } else {
+        more = false;
       }
     }
   }
+  if (OUTV) {
+    __syncthreads();
+    flush_stage<T>(ostage, prev_out, prev_pix0, prev_npx, ops, t);
+  }
+  if (DEG > 0 && pend) flush_moments<M, P, false>(acc_m, bval, bidx, pend_part, pend_slots, lane);
 }
 
-template <int DEG, bool OUTV>
-static int launch_srf_u16_ring(const SrfArgs& a, hipStream_t stream) {
-  const size_t lds = (size_t)2 * 64 * a.B * 2 + 128 * sizeof(uint32_t) + (size_t)a.wtaps * 4 + (OUTV ? (size_t)64 * a.out_ps * 4 : 0);
-  auto kern = srf_u16_ring_kernel<DEG, OUTV>;
-  static thread_local size_t configured = 0;
-  if (lds > configured) {
+template <typename K>
+static void ensure_dynamic_lds(K kern, size_t lds, size_t* configured) {
+  if (lds > *configured) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipGetLastError();
-    configured = lds;
+    *configured = lds;
   }
-  hipLaunchKernelGGL(kern, dim3(a.slots), dim3(512), lds, stream, a);
+}
+
+template <int DEG, bool OUTV, bool BATCH>
+static int launch_srf_u16_ring(const SrfArgs& a, int grid, hipStream_t stream) {
+  const size_t lds = (size_t)2 * 64 * a.B * 2 + 128 * sizeof(uint32_t) + (size_t)a.wtaps * 4 + (OUTV ? (size_t)64 * a.out_ps * 4 : 0);
+  auto kern = srf_u16_ring_kernel<DEG, OUTV, BATCH>;
+  static thread_local size_t configured = 0;
+  ensure_dynamic_lds(kern, lds, &configured);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, a);
   HSR_LAUNCH_CHECK("srf_u16_ring_kernel");
   return HSR_OK;
 }
 
-template <int DEG, bool FAST, bool OUTV>
-static int launch_srf_u16(const SrfArgs& a, hipStream_t stream) {
+template <int DEG, bool FAST, bool OUTV, bool BATCH>
+static int launch_srf_u16(const SrfArgs& a, int grid, hipStream_t stream) {
   const size_t lds = (size_t)64 * a.B * 2 + 64 * sizeof(uint32_t) + (size_t)a.wtaps * 4 + (OUTV ? (size_t)64 * a.out_ps * 4 : 0);
-  auto kern = srf_u16_kernel<DEG, FAST, OUTV>;
+  auto kern = srf_u16_kernel<DEG, FAST, OUTV, BATCH>;
   static thread_local size_t configured = 0;
-  if (lds > configured) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipGetLastError();
-    configured = lds;
-  }
-  hipLaunchKernelGGL(kern, dim3(a.slots), dim3(512), lds, stream, a);
+  ensure_dynamic_lds(kern, lds, &configured);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, a);
   HSR_LAUNCH_CHECK("srf_u16_kernel");
   return HSR_OK;
 }
 
-template <int DEG>
-static int dispatch_u16_deg(const SrfArgs& a, bool fast, hipStream_t s) {
-  const bool outv = a.out_bs == 1 && (a.out_ps & 3) == 0 && a.out_ps <= HSR_MAX_BANDS && (((uintptr_t)a.out) & 15) == 0;
-  // two tile buffers must fit twice per CU next to the weights and the output slab: B <= ~300 spectral samples
-  const size_t ring_lds = (size_t)2 * 64 * a.B * 2 + 512 + (size_t)a.wtaps * 4 + (outv ? (size_t)64 * a.out_ps * 4 : 0);
-  if (fast && g_u16_ring && ring_lds <= 80 * 1024)
-    return outv ? launch_srf_u16_ring<DEG, true>(a, s) : launch_srf_u16_ring<DEG, false>(a, s);
-  if (outv) return fast ? launch_srf_u16<DEG, true, true>(a, s) : launch_srf_u16<DEG, false, true>(a, s);
-  return fast ? launch_srf_u16<DEG, true, false>(a, s) : launch_srf_u16<DEG, false, false>(a, s);
+static bool out_rows_vectorised(const SrfArgs& a, const float* out) {
+  return a.out_bs == 1 && (a.out_ps & 3) == 0 && a.out_ps <= HSR_MAX_BANDS && (((uintptr_t)out) & 15) == 0;
 }
 
-static int dispatch_u16(const SrfArgs& a, int deg, bool fast, hipStream_t s) {
+// two group buffers must fit twice per CU next to the weights and the output slab: B <= ~300 spectral samples
+static bool u16_ring_fits(const SrfArgs& a, bool outv) {
+  const size_t ring_lds = (size_t)2 * 64 * a.B * 2 + 512 + (size_t)a.wtaps * 4 + (outv ? (size_t)64 * a.out_ps * 4 : 0);
+  return ring_lds <= 80 * 1024;
+}
+
+template <int DEG>
+static int dispatch_u16_deg(const SrfArgs& a, bool fast, bool ring, int grid, hipStream_t s) {
+  const bool outv = out_rows_vectorised(a, a.one.pseudo_dev);
+  if (fast && ring && u16_ring_fits(a, outv))
+    return outv ? launch_srf_u16_ring<DEG, true, false>(a, grid, s) : launch_srf_u16_ring<DEG, false, false>(a, grid, s);
+  if (outv) return fast ? launch_srf_u16<DEG, true, true, false>(a, grid, s) : launch_srf_u16<DEG, false, true, false>(a, grid, s);
+  return fast ? launch_srf_u16<DEG, true, false, false>(a, grid, s) : launch_srf_u16<DEG, false, false, false>(a, grid, s);
+}
+
+static int dispatch_u16(const SrfArgs& a, int deg, bool fast, bool ring, int grid, hipStream_t s) {
   switch (deg) {
-    case 0: return dispatch_u16_deg<0>(a, fast, s);
-    case 1: return dispatch_u16_deg<1>(a, fast, s);
-    case 2: return dispatch_u16_deg<2>(a, fast, s);
-    case 3: return dispatch_u16_deg<3>(a, fast, s);
-    case 4: return dispatch_u16_deg<4>(a, fast, s);
+    case 0: return dispatch_u16_deg<0>(a, fast, ring, grid, s);
+    case 1: return dispatch_u16_deg<1>(a, fast, ring, grid, s);
+    case 2: return dispatch_u16_deg<2>(a, fast, ring, grid, s);
+    case 3: return dispatch_u16_deg<3>(a, fast, ring, grid, s);
+    case 4: return dispatch_u16_deg<4>(a, fast, ring, grid, s);
   }
   set_error("hsr_srf_integrate_moments_u16: deg=%d outside [1,%d]", deg, HSR_MAX_DEG);
   return HSR_ERR_UNSUPPORTED;
 }
 
-template <int DEG, bool FAST, bool WLDS, int P, bool OUTV>
-static int launch_srf(const SrfArgs& a, hipStream_t stream) {
+template <int DEG, bool FAST, bool WLDS, int P, bool OUTV, bool BATCH>
+static int launch_srf(const SrfArgs& a, int grid, hipStream_t stream) {
   const size_t lds = (size_t)P * a.ldsB * 4 + 64 * sizeof(uint32_t) + (WLDS ? (size_t)a.wtaps * 4 : 0) +
                      (OUTV ? (size_t)P * a.out_ps * 4 : 0);
-  auto kern = srf_kernel<DEG, FAST, WLDS, P, OUTV>;
+  auto kern = srf_kernel<DEG, FAST, WLDS, P, OUTV, BATCH>;
   static thread_local size_t configured = 0;
-  if (lds > configured) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    (void)hipGetLastError();
-    configured = lds;
-  }
+  ensure_dynamic_lds(kern, lds, &configured);
 #ifdef HSR_PHASE_STAMPS
   const_cast<SrfArgs&>(a).stamps = g_stamp_buffer;
 #endif
-  hipLaunchKernelGGL(kern, dim3(a.slots), dim3(8 * P), lds, stream, a);
+  hipLaunchKernelGGL(kern, dim3(grid), dim3(8 * P), lds, stream, a);
   HSR_LAUNCH_CHECK("srf_kernel");
   return HSR_OK;
 }
 
 template <int DEG, int P>
-static int dispatch_fast(const SrfArgs& a, bool fast, hipStream_t s) {
+static int dispatch_fast(const SrfArgs& a, bool fast, int grid, hipStream_t s) {
   // pixel-major output with a 16-byte friendly row: stage the slab in LDS and flush it vectorised
-  const bool outv = a.out_bs == 1 && (a.out_ps & 3) == 0 && a.out_ps <= HSR_MAX_BANDS &&
-                    (((uintptr_t)a.out) & 15) == 0;
-  if (a.wtaps == 0) return launch_srf<DEG, false, false, 64, false>(a, s);  // rare fallback: one generic kernel
-  if (outv) return fast ? launch_srf<DEG, true, true, P, true>(a, s) : launch_srf<DEG, false, true, P, true>(a, s);
-  return fast ? launch_srf<DEG, true, true, P, false>(a, s) : launch_srf<DEG, false, true, P, false>(a, s);
+  const bool outv = out_rows_vectorised(a, a.one.pseudo_dev);
+  if (a.wtaps == 0) return launch_srf<DEG, false, false, 64, false, false>(a, grid, s);  // rare fallback: one generic kernel
+  if (outv) return fast ? launch_srf<DEG, true, true, P, true, false>(a, grid, s) : launch_srf<DEG, false, true, P, true, false>(a, grid, s);
+  return fast ? launch_srf<DEG, true, true, P, false, false>(a, grid, s) : launch_srf<DEG, false, true, P, false, false>(a, grid, s);
 }
 
 template <int P>
-static int dispatch_deg(const SrfArgs& a, int deg, bool fast, hipStream_t s) {
+static int dispatch_deg(const SrfArgs& a, int deg, bool fast, int grid, hipStream_t s) {
   switch (deg) {
-    case 0: return dispatch_fast<0, P>(a, fast, s);
-    case 1: return dispatch_fast<1, P>(a, fast, s);
-    case 2: return dispatch_fast<2, P>(a, fast, s);
-    case 3: return dispatch_fast<3, P>(a, fast, s);
-    case 4: return dispatch_fast<4, P>(a, fast, s);
+    case 0: return dispatch_fast<0, P>(a, fast, grid, s);
+    case 1: return dispatch_fast<1, P>(a, fast, grid, s);
+    case 2: return dispatch_fast<2, P>(a, fast, grid, s);
+    case 3: return dispatch_fast<3, P>(a, fast, grid, s);
+    case 4: return dispatch_fast<4, P>(a, fast, grid, s);
   }
   set_error("hsr_srf_integrate_moments: deg=%d outside [1,%d]", deg, HSR_MAX_DEG);
   return HSR_ERR_UNSUPPORTED;
 }
 
-int srf_partial_slots(int64_t npix) {
-  const int P = g_tile_pixels;
-  int64_t tiles = (npix + P - 1) / P;
-  if (tiles < 1) tiles = 1;
-  const int64_t cap = (int64_t)(256 - g_reserved_cus) * (P == 64 ? 2 : 4);  // CUs x resident workgroups
-  return (int)(tiles < cap ? tiles : cap);
+// batch launches: pixel-major rows staged in LDS, weights in LDS, 64-pixel groups
+template <int DEG>
+static int dispatch_batch_deg(const SrfArgs& a, bool fast, bool ring, int grid, hipStream_t s) {
+  if (a.u16) {
+    if (fast && ring && u16_ring_fits(a, true)) return launch_srf_u16_ring<DEG, true, true>(a, grid, s);
+    return fast ? launch_srf_u16<DEG, true, true, true>(a, grid, s) : launch_srf_u16<DEG, false, true, true>(a, grid, s);
+  }
+  return fast ? launch_srf<DEG, true, true, 64, true, true>(a, grid, s) : launch_srf<DEG, false, true, 64, true, true>(a, grid, s);
 }
 
-static int srf_common(SrfArgs& a, const int32_t* k0, const int32_t* klen, int32_t deg, hipStream_t stream) {
-  HSR_REQUIRE(a.cube && a.wn && a.out && k0 && klen, HSR_ERR_INVALID, "hsr_srf_integrate: NULL pointer");
-  HSR_REQUIRE(a.npix >= 0, HSR_ERR_INVALID, "hsr_srf_integrate: npix < 0");
+static int dispatch_batch(const SrfArgs& a, int deg, bool fast, bool ring, int grid, hipStream_t s) {
+  switch (deg) {
+    case 0: return dispatch_batch_deg<0>(a, fast, ring, grid, s);
+    case 1: return dispatch_batch_deg<1>(a, fast, ring, grid, s);
+    case 2: return dispatch_batch_deg<2>(a, fast, ring, grid, s);
+    case 3: return dispatch_batch_deg<3>(a, fast, ring, grid, s);
+    case 4: return dispatch_batch_deg<4>(a, fast, ring, grid, s);
+  }
+  set_error("hsr_srf_integrate_moments_batched: deg=%d outside [0,%d]", deg, HSR_MAX_DEG);
+  return HSR_ERR_UNSUPPORTED;
+}
+
+// Band table of a launch: validated supports, LDS weight segments, band -> (group, slot) assignment.
+static int srf_prepare_bands(SrfArgs& a, const int32_t* k0, const int32_t* klen) {
+  HSR_REQUIRE(a.wn && k0 && klen, HSR_ERR_INVALID, "hsr_srf_integrate: NULL pointer");
   HSR_REQUIRE(a.B >= 1 && a.B <= HSR_MAX_SPECTRAL, HSR_ERR_UNSUPPORTED,
               "hsr_srf_integrate: B=%d outside [1,%d]", a.B, HSR_MAX_SPECTRAL);
   HSR_REQUIRE(a.nb >= 1 && a.nb <= HSR_MAX_BANDS, HSR_ERR_UNSUPPORTED,
               "hsr_srf_integrate: nb=%d outside [1,%d]", a.nb, HSR_MAX_BANDS);
-  HSR_REQUIRE((a.out_ps == 1 && a.out_bs >= a.npix) || (a.out_bs == 1 && a.out_ps >= a.nb), HSR_ERR_INVALID,
-              "hsr_srf_integrate: output strides (%lld, %lld) are neither band-major nor pixel-major",
-              (long long)a.out_bs, (long long)a.out_ps);
-  HSR_REQUIRE(((uintptr_t)a.cube & (a.u16 ? 1 : 3)) == 0, HSR_ERR_INVALID, "hsr_srf_integrate: cube not %d-byte aligned",
-              a.u16 ? 2 : 4);
   for (int b = 0; b < a.nb; ++b) {
     HSR_REQUIRE(k0[b] >= 0 && klen[b] >= 0 && k0[b] + klen[b] <= a.B, HSR_ERR_INVALID,
                 "hsr_srf_integrate: support of band %d = [%d,%d) outside [0,%d)", b, k0[b], k0[b] + klen[b], a.B);
@@ -1029,64 +1234,67 @@ static int srf_common(SrfArgs& a, const int32_t* k0, const int32_t* klen, int32_
       load[best] += a.bands.klen[order[i]] + 1;
     }
   }
-  if (a.npix == 0) return HSR_OK;
-  if (a.u16) {  // 64-pixel tiles, two resident workgroups per CU
-    a.ntiles = (a.npix + 63) / 64;
-    const int64_t cap = (int64_t)(256 - g_reserved_cus) * 2;
-    a.slots = (int)(a.ntiles < cap ? a.ntiles : cap);
-    return dispatch_u16(a, deg, (((uintptr_t)a.cube & 15) == 0), stream);
-  }
-  int P = g_tile_pixels;
-  if (a.wtaps == 0) P = 64;  // the generic fallback kernel exists for 64-pixel tiles only
-  a.ntiles = (a.npix + P - 1) / P;
-  a.slots = srf_partial_slots(a.npix);
-  if (a.wtaps == 0) { int64_t tl = a.ntiles; a.slots = (int)(tl < 512 ? tl : 512); }
   a.ldsB = (a.B & 1) ? a.B : a.B + 1;
-  const bool fast = (a.B & 1) && (((uintptr_t)a.cube & 15) == 0);
-  return P == 64 ? dispatch_deg<64>(a, deg, fast, stream) : dispatch_deg<32>(a, deg, fast, stream);
+  return HSR_OK;
+}
+
+static int srf_common(SrfArgs& a, const int32_t* k0, const int32_t* klen, int32_t deg, const hsr_srf_options* opts,
+                      hipStream_t stream) {
+  SrfTuning tn;
+  int rc = srf_tuning(opts, &tn, "hsr_srf_integrate");
+  if (rc != HSR_OK) return rc;
+  HSR_REQUIRE(a.one.cube_dev && a.one.pseudo_dev, HSR_ERR_INVALID, "hsr_srf_integrate: NULL pointer");
+  HSR_REQUIRE(a.one.npix >= 0, HSR_ERR_INVALID, "hsr_srf_integrate: npix < 0");
+  rc = srf_prepare_bands(a, k0, klen);
+  if (rc != HSR_OK) return rc;
+  HSR_REQUIRE((a.out_ps == 1 && a.out_bs >= a.one.npix) || (a.out_bs == 1 && a.out_ps >= a.nb), HSR_ERR_INVALID,
+              "hsr_srf_integrate: output strides (%lld, %lld) are neither band-major nor pixel-major",
+              (long long)a.out_bs, (long long)a.out_ps);
+  HSR_REQUIRE(((uintptr_t)a.one.cube_dev & (a.u16 ? 1 : 3)) == 0, HSR_ERR_INVALID, "hsr_srf_integrate: cube not %d-byte aligned",
+              a.u16 ? 2 : 4);
+  if (a.one.npix == 0) return HSR_OK;
+  int P = a.u16 ? 64 : tn.tile_pixels;
+  if (a.wtaps == 0) P = 64;  // the generic fallback kernel exists for 64-pixel groups only
+  a.one.ngroups = (int32_t)((a.one.npix + P - 1) / P);
+  a.one.slots = srf_slots(a.one.npix, P, tn.reserved_cus);
+  if (!a.u16 && a.wtaps == 0) a.one.slots = a.one.ngroups < 512 ? a.one.ngroups : 512;
+  a.one.slot = 0;
+  a.nunits = a.one.slots;
+  const bool aligned = (((uintptr_t)a.one.cube_dev) & 15) == 0;
+  if (a.u16) return dispatch_u16(a, deg, aligned, tn.u16_ring, a.one.slots, stream);
+  const bool fast = (a.B & 1) && aligned;
+  return P == 64 ? dispatch_deg<64>(a, deg, fast, a.one.slots, stream) : dispatch_deg<32>(a, deg, fast, a.one.slots, stream);
 }
 
 }  // namespace hsr
 
-extern "C" int hsr_set_srf_tile(int32_t pixels) {
-  HSR_REQUIRE(pixels == 64 || pixels == 32, HSR_ERR_INVALID, "hsr_set_srf_tile: pixels must be 64 or 32, got %d", pixels);
-  hsr::g_tile_pixels = pixels;
-  return HSR_OK;
-}
-
-extern "C" int hsr_get_srf_tile(void) { return hsr::g_tile_pixels; }
-
-extern "C" int hsr_set_srf_u16_ring(int32_t on) {
-  hsr::g_u16_ring = on != 0;
-  return HSR_OK;
-}
-
-extern "C" int hsr_set_srf_reserved_cus(int32_t cus) {
-  HSR_REQUIRE(cus >= 0 && cus <= 128, HSR_ERR_INVALID, "hsr_set_srf_reserved_cus: %d outside [0,128]", cus);
-  hsr::g_reserved_cus = cus;
-  return HSR_OK;
+extern "C" int hsr_partial_slots(int64_t npix, const hsr_srf_options* opts) {
+  hsr::SrfTuning tn;
+  if (hsr::srf_tuning(opts, &tn, "hsr_partial_slots") != HSR_OK) return -1;
+  return hsr::srf_slots(npix, tn.tile_pixels, tn.reserved_cus);
 }
 
 extern "C" int hsr_srf_integrate(const float* cube_dev, int64_t npix, int32_t B, const float* wn_dev,
                                  const int32_t* k0, const int32_t* klen, int32_t nb, float* out_dev,
-                                 int64_t out_bs, int64_t out_ps, hsr_stream_t stream) {
+                                 int64_t out_bs, int64_t out_ps, const hsr_srf_options* opts, hsr_stream_t stream) {
   hsr::SrfArgs a{};
-  a.cube = cube_dev;
-  a.npix = npix;
+  a.one.cube_dev = cube_dev;
+  a.one.npix = npix;
+  a.one.pseudo_dev = out_dev;
   a.B = B;
   a.wn = wn_dev;
   a.nb = nb;
-  a.out = out_dev;
   a.out_bs = out_bs;
   a.out_ps = out_ps;
-  return hsr::srf_common(a, k0, klen, 0, (hipStream_t)stream);
+  return hsr::srf_common(a, k0, klen, 0, opts, (hipStream_t)stream);
 }
 
 extern "C" int hsr_srf_integrate_moments(const float* cube_dev, int64_t npix, int32_t B, const float* wn_dev,
                                          const int32_t* k0, const int32_t* klen, int32_t nb, float* out_dev,
                                          int64_t out_bs, int64_t out_ps, const float* real_dev, int64_t real_bs,
                                          int64_t real_ps, const uint8_t* mask_dev, float min_x, float min_y, int32_t deg,
-                                         double* partials_dev, int32_t* slots_out, hsr_stream_t stream) {
+                                         double* partials_dev, int32_t* slots_out, const hsr_srf_options* opts,
+                                         hsr_stream_t stream) {
   HSR_REQUIRE(deg >= 1 && deg <= HSR_MAX_DEG, HSR_ERR_UNSUPPORTED, "hsr_srf_integrate_moments: deg=%d outside [1,%d]",
               deg, HSR_MAX_DEG);
   HSR_REQUIRE(real_dev && partials_dev, HSR_ERR_INVALID, "hsr_srf_integrate_moments: NULL pointer");
@@ -1095,43 +1303,44 @@ extern "C" int hsr_srf_integrate_moments(const float* cube_dev, int64_t npix, in
               (long long)real_bs, (long long)real_ps);
   HSR_REQUIRE(npix > 0, HSR_ERR_INVALID, "hsr_srf_integrate_moments: npix must be > 0");
   hsr::SrfArgs a{};
-  a.cube = cube_dev;
-  a.npix = npix;
+  a.one.cube_dev = cube_dev;
+  a.one.npix = npix;
+  a.one.pseudo_dev = out_dev;
+  a.one.real_dev = real_dev;
+  a.one.mask_dev = mask_dev;
+  a.one.part_dev = partials_dev;
   a.B = B;
   a.wn = wn_dev;
   a.nb = nb;
-  a.out = out_dev;
   a.out_bs = out_bs;
   a.out_ps = out_ps;
-  a.real = real_dev;
   a.real_bs = real_bs;
   a.real_ps = real_ps;
-  a.mask = mask_dev;
   a.min_x = min_x;
   a.min_y = min_y;
-  a.partials = partials_dev;
-  int rc = hsr::srf_common(a, k0, klen, deg, (hipStream_t)stream);
-  if (rc == HSR_OK && slots_out) *slots_out = a.slots;
+  int rc = hsr::srf_common(a, k0, klen, deg, opts, (hipStream_t)stream);
+  if (rc == HSR_OK && slots_out) *slots_out = a.one.slots;
   return rc;
 }
 
 extern "C" int hsr_srf_integrate_u16(const uint16_t* cube_dev, int64_t npix, int32_t B, float scale, int32_t nodata,
                                      const float* wn_dev, const int32_t* k0, const int32_t* klen, int32_t nb,
-                                     float* out_dev, int64_t out_bs, int64_t out_ps, hsr_stream_t stream) {
+                                     float* out_dev, int64_t out_bs, int64_t out_ps, const hsr_srf_options* opts,
+                                     hsr_stream_t stream) {
   HSR_REQUIRE(nodata <= 0xffff, HSR_ERR_INVALID, "hsr_srf_integrate_u16: nodata=%d is not a uint16 value (negative = none)", nodata);
   hsr::SrfArgs a{};
-  a.cube = reinterpret_cast<const float*>(cube_dev);
+  a.one.cube_dev = cube_dev;
+  a.one.npix = npix;
+  a.one.pseudo_dev = out_dev;
   a.u16 = 1;
   a.scale = scale;
   a.nodata = nodata < 0 ? 0x10000u : (uint32_t)nodata;
-  a.npix = npix;
   a.B = B;
   a.wn = wn_dev;
   a.nb = nb;
-  a.out = out_dev;
   a.out_bs = out_bs;
   a.out_ps = out_ps;
-  return hsr::srf_common(a, k0, klen, 0, (hipStream_t)stream);
+  return hsr::srf_common(a, k0, klen, 0, opts, (hipStream_t)stream);
 }
 
 extern "C" int hsr_srf_integrate_moments_u16(const uint16_t* cube_dev, int64_t npix, int32_t B, float scale,
@@ -1139,7 +1348,8 @@ extern "C" int hsr_srf_integrate_moments_u16(const uint16_t* cube_dev, int64_t n
                                              const int32_t* klen, int32_t nb, float* out_dev, int64_t out_bs,
                                              int64_t out_ps, const float* real_dev, int64_t real_bs, int64_t real_ps,
                                              const uint8_t* mask_dev, float min_x, float min_y, int32_t deg,
-                                             double* partials_dev, int32_t* slots_out, hsr_stream_t stream) {
+                                             double* partials_dev, int32_t* slots_out, const hsr_srf_options* opts,
+                                             hsr_stream_t stream) {
   HSR_REQUIRE(deg >= 1 && deg <= HSR_MAX_DEG, HSR_ERR_UNSUPPORTED, "hsr_srf_integrate_moments_u16: deg=%d outside [1,%d]",
               deg, HSR_MAX_DEG);
   HSR_REQUIRE(real_dev && partials_dev, HSR_ERR_INVALID, "hsr_srf_integrate_moments_u16: NULL pointer");
@@ -1149,25 +1359,143 @@ extern "C" int hsr_srf_integrate_moments_u16(const uint16_t* cube_dev, int64_t n
   HSR_REQUIRE(npix > 0, HSR_ERR_INVALID, "hsr_srf_integrate_moments_u16: npix must be > 0");
   HSR_REQUIRE(nodata <= 0xffff, HSR_ERR_INVALID, "hsr_srf_integrate_moments_u16: nodata=%d is not a uint16 value (negative = none)", nodata);
   hsr::SrfArgs a{};
-  a.cube = reinterpret_cast<const float*>(cube_dev);
+  a.one.cube_dev = cube_dev;
+  a.one.npix = npix;
+  a.one.pseudo_dev = out_dev;
+  a.one.real_dev = real_dev;
+  a.one.mask_dev = mask_dev;
+  a.one.part_dev = partials_dev;
   a.u16 = 1;
   a.scale = scale;
   a.nodata = nodata < 0 ? 0x10000u : (uint32_t)nodata;
-  a.npix = npix;
   a.B = B;
   a.wn = wn_dev;
   a.nb = nb;
-  a.out = out_dev;
   a.out_bs = out_bs;
   a.out_ps = out_ps;
-  a.real = real_dev;
   a.real_bs = real_bs;
   a.real_ps = real_ps;
-  a.mask = mask_dev;
   a.min_x = min_x;
   a.min_y = min_y;
-  a.partials = partials_dev;
-  int rc = hsr::srf_common(a, k0, klen, deg, (hipStream_t)stream);
-  if (rc == HSR_OK && slots_out) *slots_out = a.slots;
+  int rc = hsr::srf_common(a, k0, klen, deg, opts, (hipStream_t)stream);
+  if (rc == HSR_OK && slots_out) *slots_out = a.one.slots;
   return rc;
+}
+
+// ---- batched small tiles ---------------------------------------------------------------------------------------
+extern "C" size_t hsr_batch_partials_bytes(int64_t nunits, int32_t nb, int32_t deg) {
+  if (nunits < 1 || nb < 1 || nb > HSR_MAX_BANDS || deg < 0 || deg > HSR_MAX_DEG) return 0;
+  return (size_t)nunits * nb * (deg > 0 ? hsr::moment_count(deg) : 1) * sizeof(double);
+}
+
+extern "C" int hsr_batch_plan(hsr_batch_tile* tiles, int32_t ntiles, int32_t nb, int32_t deg, double* partials_dev,
+                              const hsr_srf_options* opts, hsr_batch_unit* units_out, int64_t units_capacity,
+                              hsr_batch_info* info) {
+  HSR_REQUIRE(tiles && info && ntiles >= 1, HSR_ERR_INVALID, "hsr_batch_plan: NULL pointer or no tiles");
+  HSR_REQUIRE(nb >= 1 && nb <= HSR_MAX_BANDS && deg >= 0 && deg <= HSR_MAX_DEG, HSR_ERR_UNSUPPORTED,
+              "hsr_batch_plan: nb=%d deg=%d", nb, deg);
+  hsr::SrfTuning tn;
+  int rc = hsr::srf_tuning(opts, &tn, "hsr_batch_plan");
+  if (rc != HSR_OK) return rc;
+  const int M = deg > 0 ? hsr::moment_count(deg) : 1;
+  int64_t slot0 = 0, pixels = 0, max_npix = 0;
+  int aligned = 1;
+  for (int32_t t = 0; t < ntiles; ++t) {
+    hsr_batch_tile& tl = tiles[t];
+    HSR_REQUIRE(tl.npix > 0 && tl.npix < ((int64_t)1 << 37), HSR_ERR_INVALID, "hsr_batch_plan: tile %d has npix=%lld", t, (long long)tl.npix);
+    HSR_REQUIRE(tl.cube_dev && tl.pseudo_dev, HSR_ERR_INVALID, "hsr_batch_plan: tile %d has a NULL cube or output", t);
+    HSR_REQUIRE(deg == 0 || tl.real_dev, HSR_ERR_INVALID, "hsr_batch_plan: tile %d has no real-S2 target (deg > 0)", t);
+    HSR_REQUIRE((((uintptr_t)tl.pseudo_dev) & 15) == 0 && (tl.matched_dev == nullptr || (((uintptr_t)tl.matched_dev) & 15) == 0),
+                HSR_ERR_INVALID, "hsr_batch_plan: tile %d: image rows must be 16-byte aligned", t);
+    tl.ngroups = (int32_t)((tl.npix + 63) / 64);
+    tl.slots = hsr::srf_slots(tl.npix, 64, tn.reserved_cus);     // batches always use 64-pixel groups
+    tl.slot0 = slot0;
+    slot0 += tl.slots;
+    pixels += tl.npix;
+    if (tl.npix > max_npix) max_npix = tl.npix;
+    if (((uintptr_t)tl.cube_dev) & 15) aligned = 0;
+  }
+  HSR_REQUIRE(slot0 < ((int64_t)1 << 31), HSR_ERR_UNSUPPORTED, "hsr_batch_plan: %lld work units exceed 2^31", (long long)slot0);
+  info->nunits = slot0;
+  info->total_pixels = pixels;
+  info->max_npix = max_npix;
+  info->ntiles = ntiles;
+  info->aligned16 = aligned;
+  if (units_out == nullptr) return HSR_OK;
+  HSR_REQUIRE(units_capacity >= slot0, HSR_ERR_INVALID, "hsr_batch_plan: unit table holds %lld records, %lld needed",
+              (long long)units_capacity, (long long)slot0);
+  HSR_REQUIRE(deg == 0 || partials_dev, HSR_ERR_INVALID, "hsr_batch_plan: partials_dev is NULL (deg > 0)");
+  // Units in descending order of their group count (stable; ties keep tile order), dealt round-robin to the
+  // workgroups by the kernel (workgroup b runs units b, b + grid, ...): long units first, short ones fill the tail.
+  int32_t maxg = 0;
+  for (int32_t t = 0; t < ntiles; ++t) {
+    const int32_t per = (tiles[t].ngroups + tiles[t].slots - 1) / tiles[t].slots;
+    if (per > maxg) maxg = per;
+  }
+  int64_t n = 0;
+  // a tile's units have ceil or floor(ngroups / slots) groups: two passes per distinct length would be exact; lengths
+  // are small integers, so bucket by length from the longest down
+  for (int32_t len = maxg; len >= 1; --len) {
+    for (int32_t t = 0; t < ntiles; ++t) {
+      const hsr_batch_tile& tl = tiles[t];
+      for (int32_t s = 0; s < tl.slots; ++s) {
+        const int32_t groups = (tl.ngroups - s + tl.slots - 1) / tl.slots;
+        if (groups != len) continue;
+        hsr_batch_unit& u = units_out[n++];
+        u.cube_dev = tl.cube_dev;
+        u.real_dev = tl.real_dev;
+        u.mask_dev = tl.mask_dev;
+        u.pseudo_dev = tl.pseudo_dev;
+        u.part_dev = partials_dev ? partials_dev + (size_t)tl.slot0 * nb * M + s : nullptr;
+        u.npix = tl.npix;
+        u.slots = tl.slots;
+        u.slot = s;
+        u.ngroups = tl.ngroups;
+        u.reserved = 0;
+      }
+    }
+  }
+  return HSR_OK;
+}
+
+extern "C" int hsr_srf_integrate_moments_batched(const hsr_batch_unit* units_dev, const hsr_batch_info* info,
+                                                 int32_t cube_dtype, float scale, int32_t nodata, int32_t B,
+                                                 const float* wn_dev, const int32_t* k0, const int32_t* klen, int32_t nb,
+                                                 int32_t out_row, int32_t real_row, float min_x, float min_y,
+                                                 int32_t deg, const hsr_srf_options* opts, hsr_stream_t stream) {
+  HSR_REQUIRE(units_dev && info, HSR_ERR_INVALID, "hsr_srf_integrate_moments_batched: NULL pointer");
+  HSR_REQUIRE(info->nunits >= 1 && info->nunits < ((int64_t)1 << 31), HSR_ERR_INVALID,
+              "hsr_srf_integrate_moments_batched: nunits=%lld", (long long)info->nunits);
+  HSR_REQUIRE(cube_dtype == 0 || cube_dtype == 2, HSR_ERR_INVALID, "hsr_srf_integrate_moments_batched: cube_dtype must be 0 (float32) or 2 (uint16)");
+  HSR_REQUIRE(deg >= 0 && deg <= HSR_MAX_DEG, HSR_ERR_UNSUPPORTED, "hsr_srf_integrate_moments_batched: deg=%d outside [0,%d]", deg, HSR_MAX_DEG);
+  HSR_REQUIRE(nodata <= 0xffff, HSR_ERR_INVALID, "hsr_srf_integrate_moments_batched: nodata=%d is not a uint16 value (negative = none)", nodata);
+  HSR_REQUIRE(out_row >= nb && (out_row & 3) == 0 && out_row <= HSR_MAX_BANDS, HSR_ERR_UNSUPPORTED,
+              "hsr_srf_integrate_moments_batched: out_row=%d must be a multiple of 4 in [nb,%d]", out_row, HSR_MAX_BANDS);
+  HSR_REQUIRE(deg == 0 || real_row >= nb, HSR_ERR_INVALID, "hsr_srf_integrate_moments_batched: real_row=%d < nb", real_row);
+  hsr::SrfTuning tn;
+  int rc = hsr::srf_tuning(opts, &tn, "hsr_srf_integrate_moments_batched");
+  if (rc != HSR_OK) return rc;
+  hsr::SrfArgs a{};
+  a.units = units_dev;
+  a.nunits = (int32_t)info->nunits;
+  a.u16 = cube_dtype == 2;
+  a.scale = scale;
+  a.nodata = nodata < 0 ? 0x10000u : (uint32_t)nodata;
+  a.B = B;
+  a.wn = wn_dev;
+  a.nb = nb;
+  a.out_bs = 1;
+  a.out_ps = out_row;
+  a.real_bs = 1;
+  a.real_ps = real_row;
+  a.min_x = min_x;
+  a.min_y = min_y;
+  rc = hsr::srf_prepare_bands(a, k0, klen);
+  if (rc != HSR_OK) return rc;
+  HSR_REQUIRE(a.wtaps > 0, HSR_ERR_UNSUPPORTED,
+              "hsr_srf_integrate_moments_batched: the SRF supports do not fit the LDS weight area (B=%d)", B);
+  const int64_t cap = (int64_t)(256 - tn.reserved_cus) * 2;
+  const int grid = (int)(info->nunits < cap ? info->nunits : cap);
+  const bool fast = info->aligned16 && (a.u16 || (B & 1));
+  return hsr::dispatch_batch(a, deg, fast, tn.u16_ring, grid, (hipStream_t)stream);
 }

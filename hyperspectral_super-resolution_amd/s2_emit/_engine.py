@@ -23,8 +23,50 @@ from ._native import PIXMAJOR, PLANAR
 _NEG_INF = float("-inf")
 
 
-def _stream(torch):
-    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+class _launch:
+    """Context of one or a few library calls on the device that owns ``t``: makes that device current for the HIP
+    launch (kernels go to the CURRENT device, whatever device the pointers belong to) and yields the stream torch
+    has current on THAT device.  A plan built for cuda:1 in a process whose current device is cuda:0 therefore
+    launches on cuda:1, on cuda:1's stream."""
+    __slots__ = ("dev", "guard")
+
+    def __init__(self, t):
+        self.dev = t.device if hasattr(t, "device") else t
+        self.guard = None
+
+    def __enter__(self):
+        import torch
+        if self.dev.type != "cuda":
+            raise ValueError(f"expected a GPU tensor, got one on {self.dev}")
+        idx = self.dev.index if self.dev.index is not None else torch.cuda.current_device()
+        if idx != torch.cuda.current_device():
+            self.guard = torch.cuda.device(idx)
+            self.guard.__enter__()
+        return C.c_void_p(torch.cuda.current_stream(idx).cuda_stream)
+
+    def __exit__(self, *exc):
+        if self.guard is not None:
+            self.guard.__exit__(*exc)
+        return False
+
+
+def _stream(torch, t=None):
+    """Stream for callers that do not switch devices themselves (ridge.py, _ot.py): the current stream of the current
+    device - and a loud error if ``t`` lives on another device instead of a launch on the wrong GPU."""
+    cur = torch.cuda.current_device()
+    if t is not None and t.is_cuda and t.device.index not in (None, cur):
+        raise ValueError(f"tensor on {t.device} but the current device is cuda:{cur}: wrap the call in "
+                         f"torch.cuda.device({t.device.index})")
+    return C.c_void_p(torch.cuda.current_stream(cur).cuda_stream)
+
+
+def srf_options(tile_pixels: int = 0, reserved_cus: int = 0, u16_single_buffer: bool = False):
+    """hsr_srf_options for one call / one plan (None everywhere means the defaults)."""
+    return nat.SrfOptions(int(tile_pixels), int(reserved_cus), 1 if u16_single_buffer else 0, 0)
+
+
+def _opt(opts):
+    return C.byref(opts) if opts is not None else None
 
 
 def _ptr(t):
@@ -160,9 +202,10 @@ def tile_encode_u16(x, scale: float = TILE_SCALE, src_nodata=None, nodata_u16: i
     if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous()):
         raise ValueError("x must be a contiguous float32 tensor on the GPU")
     out = torch.empty(x.shape, dtype=torch.uint16, device=x.device)
-    nat.check(lib.hsr_tile_encode_u16(_ptr(x), x.numel(), float(scale), int(src_nodata is not None),
-                                      float(src_nodata) if src_nodata is not None else 0.0, int(nodata_u16),
-                                      _ptr(out), _stream(torch)), "hsr_tile_encode_u16")
+    with _launch(x) as st:
+        nat.check(lib.hsr_tile_encode_u16(_ptr(x), x.numel(), float(scale), int(src_nodata is not None),
+                                          float(src_nodata) if src_nodata is not None else 0.0, int(nodata_u16),
+                                          _ptr(out), st), "hsr_tile_encode_u16")
     return out
 
 
@@ -173,8 +216,9 @@ def tile_decode_u16(u, scale=None, nodata: Optional[int] = TILE_NODATA):
     if not (u.is_cuda and u.dtype == torch.uint16 and u.is_contiguous()):
         raise ValueError("u must be a contiguous uint16 tensor on the GPU")
     out = torch.empty(u.shape, dtype=torch.float32, device=u.device)
-    nat.check(lib.hsr_tile_decode_u16(_ptr(u), u.numel(), _decode_scale(scale), -1 if nodata is None else int(nodata),
-                                      _ptr(out), _stream(torch)), "hsr_tile_decode_u16")
+    with _launch(u) as st:
+        nat.check(lib.hsr_tile_decode_u16(_ptr(u), u.numel(), _decode_scale(scale), -1 if nodata is None else int(nodata),
+                                          _ptr(out), st), "hsr_tile_decode_u16")
     return out
 
 
@@ -183,7 +227,8 @@ def _i32arr(a):
     return a, a.ctypes.data_as(C.POINTER(C.c_int32))
 
 
-def srf_integrate(cube, table: SrfTable, out=None, layout: str = PLANAR, scale=None, nodata: Optional[int] = TILE_NODATA):
+def srf_integrate(cube, table: SrfTable, out=None, layout: str = PLANAR, scale=None, nodata: Optional[int] = TILE_NODATA,
+                  opts=None):
     """K1.  cube (..., B) float32 on the GPU -> pseudo-S2 image in ``layout`` (float32).
     A uint16 cube is taken as a tile in the reference's storage format and decoded inside the kernel
     (``scale`` default 1e-4, ``nodata`` default 65535, None = no nodata value)."""
@@ -202,13 +247,14 @@ def srf_integrate(cube, table: SrfTable, out=None, layout: str = PLANAR, scale=N
         k0a, k0p = _i32arr(table.k0[b0:b1])              # keep the arrays alive across the call
         kla, klp = _i32arr(table.klen[b0:b1])
         dst = img[b0:b1] if layout == PLANAR else img[:, b0:]
-        if c2.dtype == torch.uint16:
-            nat.check(lib.hsr_srf_integrate_u16(_ptr(c2), npix, B, _decode_scale(scale), -1 if nodata is None else int(nodata),
-                                                _ptr(wn[b0:b1]), k0p, klp, b1 - b0, _ptr(dst), bs, ps, _stream(torch)),
-                      "hsr_srf_integrate_u16")
-        else:
-            nat.check(lib.hsr_srf_integrate(_ptr(c2), npix, B, _ptr(wn[b0:b1]), k0p, klp, b1 - b0,
-                                            _ptr(dst), bs, ps, _stream(torch)), "hsr_srf_integrate")
+        with _launch(c2) as st:
+            if c2.dtype == torch.uint16:
+                nat.check(lib.hsr_srf_integrate_u16(_ptr(c2), npix, B, _decode_scale(scale), -1 if nodata is None else int(nodata),
+                                                    _ptr(wn[b0:b1]), k0p, klp, b1 - b0, _ptr(dst), bs, ps, _opt(opts), st),
+                          "hsr_srf_integrate_u16")
+            else:
+                nat.check(lib.hsr_srf_integrate(_ptr(c2), npix, B, _ptr(wn[b0:b1]), k0p, klp, b1 - b0,
+                                                _ptr(dst), bs, ps, _opt(opts), st), "hsr_srf_integrate")
     return img
 
 
@@ -230,7 +276,7 @@ class MomentWorkspace:
 def srf_integrate_moments(cube, table: SrfTable, real, deg: int, ws: MomentWorkspace, mask=None,
                           min_x=_NEG_INF, min_y=_NEG_INF, out=None, events=None, reduce=True,
                           layout: str = PIXMAJOR, real_layout: Optional[str] = None, scale=None,
-                          nodata: Optional[int] = TILE_NODATA):
+                          nodata: Optional[int] = TILE_NODATA, opts=None):
     """K1+K2 fused: pseudo-S2 image and the per-band Vandermonde moments in one cube pass.
     A uint16 cube is decoded inside the kernel (see srf_integrate).
     ``real``: real-S2 image in ``real_layout`` (default: same as ``layout``).
@@ -256,33 +302,173 @@ def srf_integrate_moments(cube, table: SrfTable, real, deg: int, ws: MomentWorks
     k0a, k0p = _i32arr(table.k0)                 # keep the arrays alive across the call
     kla, klp = _i32arr(table.klen)
     slots = C.c_int32(0)
-    if events is not None:
-        events[0].record()
-    if c2.dtype == torch.uint16:
-        nat.check(lib.hsr_srf_integrate_moments_u16(_ptr(c2), npix, B, _decode_scale(scale),
-                                                    -1 if nodata is None else int(nodata), _ptr(wn), k0p, klp, nb,
-                                                    _ptr(img), bs, ps, _ptr(real), rbs, rps, _ptr(mask), min_x, min_y,
-                                                    deg, _ptr(ws.partials), C.byref(slots), _stream(torch)),
-                  "hsr_srf_integrate_moments_u16")
-    else:
-        nat.check(lib.hsr_srf_integrate_moments(_ptr(c2), npix, B, _ptr(wn), k0p, klp, nb, _ptr(img), bs, ps,
-                                                _ptr(real), rbs, rps, _ptr(mask), min_x, min_y, deg,
-                                                _ptr(ws.partials), C.byref(slots), _stream(torch)),
-                  "hsr_srf_integrate_moments")
-    if events is not None:
-        events[1].record()
+    with _launch(c2) as st:
+        if events is not None:
+            events[0].record(torch.cuda.current_stream(c2.device))
+        if c2.dtype == torch.uint16:
+            nat.check(lib.hsr_srf_integrate_moments_u16(_ptr(c2), npix, B, _decode_scale(scale),
+                                                        -1 if nodata is None else int(nodata), _ptr(wn), k0p, klp, nb,
+                                                        _ptr(img), bs, ps, _ptr(real), rbs, rps, _ptr(mask), min_x, min_y,
+                                                        deg, _ptr(ws.partials), C.byref(slots), _opt(opts), st),
+                      "hsr_srf_integrate_moments_u16")
+        else:
+            nat.check(lib.hsr_srf_integrate_moments(_ptr(c2), npix, B, _ptr(wn), k0p, klp, nb, _ptr(img), bs, ps,
+                                                    _ptr(real), rbs, rps, _ptr(mask), min_x, min_y, deg,
+                                                    _ptr(ws.partials), C.byref(slots), _opt(opts), st),
+                      "hsr_srf_integrate_moments")
+        if events is not None:
+            events[1].record(torch.cuda.current_stream(c2.device))
     ws.slots = slots.value
     if not reduce:                      # caller continues with moments_reduce_solve / moments_reduce
         return img, None
     return img, moments_reduce(ws)
 
 
+# ---------------------------------------------------------------------------------------------
+# batched small tiles (hsr.h "batched small tiles"; the reference's 100 x 100 tile pairs,
+# tiles_helpers/utils.py:223-305)
+# ---------------------------------------------------------------------------------------------
+class TileBatch:
+    """Device tables and workspaces of one batch of tiles for the three batched launches.
+
+    ``cubes`` / ``reals`` / ``masks``: per-tile GPU tensors - cube (H, W, B) or (npix, B) float32 / uint16,
+    real (H, W, C >= nb) or (npix, C) float32 band-last (all tiles with the same C), mask uint8 (npix) or None.
+    Output rows are ``padded_row(nb)`` floats.  The tables hold raw pointers: the batch keeps the tensors alive."""
+
+    def __init__(self, cubes, reals, masks, table: SrfTable, deg: int, opts=None, in_place: bool = False):
+        torch = nat.require_gpu()
+        lib = nat.load()
+        T = len(cubes)
+        if T < 1:
+            raise ValueError("a batch needs at least one tile")
+        if reals is not None and len(reals) != T:
+            raise ValueError("reals must match cubes")
+        masks = list(masks) if masks is not None else [None] * T
+        if len(masks) != T:
+            raise ValueError("masks must match cubes")
+        self.table, self.deg, self.nb, self.T = table, int(deg), table.nb, T
+        self.M = 3 * deg + 2 if deg > 0 else 1
+        self.row = padded_row(self.nb)
+        dev = cubes[0].device
+        self.device = dev
+        self.cubes = [_as_cube2d(c) for c in cubes]
+        dts = {c.dtype for c in self.cubes}
+        if len(dts) != 1:
+            raise ValueError("all cubes of a batch must have the same dtype")
+        self.u16 = self.cubes[0].dtype == torch.uint16
+        self.npix = [int(c.shape[0]) for c in self.cubes]
+        for c in self.cubes:
+            if c.shape[1] != table.B:
+                raise ValueError(f"emit_w must be (B,) matching R bands. Got {(table.B,)} vs {c.shape[1]}")
+            if c.device != dev:
+                raise ValueError("all tiles of a batch must live on one GPU")
+        self.reals, self.real_row = None, 0
+        if deg > 0:
+            if reals is None:
+                raise ValueError("deg > 0 needs the real-S2 targets")
+            self.reals = []
+            for r, n in zip(reals, self.npix):
+                r2 = r.reshape(-1, r.shape[-1])
+                if not (r2.is_cuda and r2.dtype == torch.float32 and r2.is_contiguous() and r2.shape[0] == n and r2.shape[1] >= self.nb):
+                    raise ValueError("real targets must be contiguous float32 band-last GPU tensors (npix, C >= nb)")
+                self.reals.append(r2)
+            rows = {int(r.shape[1]) for r in self.reals}
+            if len(rows) != 1:
+                raise ValueError("all real targets of a batch must have the same number of channels")
+            self.real_row = rows.pop()
+        self.masks = []
+        for m, n in zip(masks, self.npix):
+            if m is not None:
+                m = m.reshape(-1)
+                if m.dtype == torch.bool:
+                    m = m.view(torch.uint8)
+                if not (m.is_cuda and m.dtype == torch.uint8 and m.numel() == n and m.is_contiguous()):
+                    raise ValueError("mask must be a contiguous uint8 tensor with one byte per pixel")
+            self.masks.append(m)
+        total = sum(self.npix)
+        self.offsets = np.concatenate([[0], np.cumsum(self.npix)]).astype(np.int64)
+        self.pseudo = torch.empty((total, self.row), dtype=torch.float32, device=dev)
+        self.matched = self.pseudo if in_place else torch.empty((total, self.row), dtype=torch.float32, device=dev)
+        tiles = (nat.BatchTile * T)()
+        esz = 4 * self.row
+        for i in range(T):
+            tl = tiles[i]
+            tl.cube_dev = self.cubes[i].data_ptr()
+            tl.real_dev = self.reals[i].data_ptr() if self.reals is not None else None
+            tl.mask_dev = self.masks[i].data_ptr() if self.masks[i] is not None else None
+            tl.pseudo_dev = self.pseudo.data_ptr() + int(self.offsets[i]) * esz
+            tl.matched_dev = self.matched.data_ptr() + int(self.offsets[i]) * esz
+            tl.npix = self.npix[i]
+        self.opts = opts
+        info = nat.BatchInfo()
+        nat.check(lib.hsr_batch_plan(tiles, T, self.nb, self.deg, None, _opt(opts), None, 0, C.byref(info)), "hsr_batch_plan")
+        nunits = int(info.nunits)
+        self.partials = torch.empty(max(1, lib.hsr_batch_partials_bytes(nunits, self.nb, self.deg) // 8), dtype=torch.float64, device=dev)
+        units = (C.c_uint8 * (nat.BATCH_RECORD_BYTES * nunits))()
+        nat.check(lib.hsr_batch_plan(tiles, T, self.nb, self.deg, _ptr(self.partials), _opt(opts), units, nunits, C.byref(info)),
+                  "hsr_batch_plan")
+        self.info = info
+        self.tiles_dev = torch.frombuffer(bytearray(bytes(tiles)), dtype=torch.uint8).to(dev)
+        self.units_dev = torch.frombuffer(bytearray(bytes(units)), dtype=torch.uint8).to(dev)
+        self.slots = [int(tiles[i].slots) for i in range(T)]
+        self.moments = torch.zeros((T, self.nb, self.M), dtype=torch.float64, device=dev)
+        self.coeffs = torch.zeros((T, self.nb, max(deg, 0) + 1), dtype=torch.float64, device=dev)
+
+    def tile_rows(self, i: int, image: str = "matched"):
+        """(npix_i, row) view of tile i inside the batch's pseudo / matched image."""
+        img = getattr(self, image)
+        return img[int(self.offsets[i]): int(self.offsets[i + 1])]
+
+
+def batch_srf_integrate_moments(tb: TileBatch, min_x=_NEG_INF, min_y=_NEG_INF, scale=None,
+                                nodata: Optional[int] = TILE_NODATA, events=None):
+    """K1 (+K2) of every tile of the batch in ONE launch -> tb.pseudo, partial sums in tb.partials."""
+    torch = nat.require_gpu()
+    lib = nat.load()
+    wn = tb.table.device_weights(tb.device)
+    k0a, k0p = _i32arr(tb.table.k0)
+    kla, klp = _i32arr(tb.table.klen)
+    with _launch(tb.pseudo) as st:
+        if events is not None:
+            events[0].record(torch.cuda.current_stream(tb.device))
+        nat.check(lib.hsr_srf_integrate_moments_batched(_ptr(tb.units_dev), C.byref(tb.info), 2 if tb.u16 else 0,
+                                                        _decode_scale(scale), -1 if nodata is None else int(nodata),
+                                                        tb.table.B, _ptr(wn), k0p, klp, tb.nb, tb.row, tb.real_row,
+                                                        min_x, min_y, tb.deg, _opt(tb.opts), st),
+                  "hsr_srf_integrate_moments_batched")
+        if events is not None:
+            events[1].record(torch.cuda.current_stream(tb.device))
+    return tb.pseudo
+
+
+def batch_reduce_solve(tb: TileBatch, min_count: int):
+    """Per-tile slot reduction + np.polyfit solve in one launch -> (tb.moments (T,nb,M), tb.coeffs (T,nb,deg+1))."""
+    lib = nat.load()
+    with _launch(tb.pseudo) as st:
+        nat.check(lib.hsr_moments_reduce_solve_batched(_ptr(tb.tiles_dev), tb.T, _ptr(tb.partials), tb.nb, tb.deg,
+                                                       int(min_count), _ptr(tb.moments), _ptr(tb.coeffs), st),
+                  "hsr_moments_reduce_solve_batched")
+    return tb.moments, tb.coeffs
+
+
+def batch_poly_apply(tb: TileBatch, use_mask: bool = False, clip: bool = True, coeffs=None):
+    """K3 of every tile with its own coefficients in one launch -> tb.matched."""
+    lib = nat.load()
+    co = tb.coeffs if coeffs is None else coeffs
+    with _launch(tb.pseudo) as st:
+        nat.check(lib.hsr_poly_apply_batched(_ptr(tb.tiles_dev), tb.T, int(tb.info.max_npix), _ptr(co), tb.nb,
+                                             int(co.shape[-1]) - 1, tb.row, 1 if use_mask else 0, 1 if clip else 0, st),
+                  "hsr_poly_apply_batched")
+    return tb.matched
+
+
 def moments_reduce(ws: MomentWorkspace):
     """Fixed-order reduction of the partial slots of the last moments launch -> ws.moments."""
     torch = nat.require_gpu()
     lib = nat.load()
-    nat.check(lib.hsr_moments_reduce(_ptr(ws.partials), ws.slots, ws.nb, ws.deg, _ptr(ws.moments),
-                                     _stream(torch)), "hsr_moments_reduce")
+    with _launch(ws.partials) as st:
+        nat.check(lib.hsr_moments_reduce(_ptr(ws.partials), ws.slots, ws.nb, ws.deg, _ptr(ws.moments),
+                                         st), "hsr_moments_reduce")
     return ws.moments
 
 
@@ -290,9 +476,10 @@ def moments_reduce_solve(ws: MomentWorkspace, min_count: int):
     """Reduce + np.polyfit solve in one launch (no exchange in between) -> (ws.moments, ws.coeffs)."""
     torch = nat.require_gpu()
     lib = nat.load()
-    nat.check(lib.hsr_moments_reduce_solve(_ptr(ws.partials), ws.slots, ws.nb, ws.deg, int(min_count),
-                                           _ptr(ws.moments), _ptr(ws.coeffs), _stream(torch)),
-              "hsr_moments_reduce_solve")
+    with _launch(ws.partials) as st:
+        nat.check(lib.hsr_moments_reduce_solve(_ptr(ws.partials), ws.slots, ws.nb, ws.deg, int(min_count),
+                                               _ptr(ws.moments), _ptr(ws.coeffs), st),
+                  "hsr_moments_reduce_solve")
     return ws.moments, ws.coeffs
 
 
@@ -306,9 +493,10 @@ def poly_moments(x, y, deg: int, ws: MomentWorkspace, mask=None, min_x=_NEG_INF,
     if ny != npix or x.dtype != torch.float32 or y.dtype != torch.float32:
         raise ValueError("x and y must be float32 images of the same shape")
     slots = C.c_int32(0)
-    nat.check(lib.hsr_poly_moments(_ptr(x), xbs, xps, _ptr(y), ybs, yps, _ptr(mask), npix, n, deg,
-                                   min_x, min_y, _ptr(lohi_x), _ptr(lohi_y), _ptr(ws.partials),
-                                   C.byref(slots), _stream(torch)), "hsr_poly_moments")
+    with _launch(x) as st:
+        nat.check(lib.hsr_poly_moments(_ptr(x), xbs, xps, _ptr(y), ybs, yps, _ptr(mask), npix, n, deg,
+                                       min_x, min_y, _ptr(lohi_x), _ptr(lohi_y), _ptr(ws.partials),
+                                       C.byref(slots), st), "hsr_poly_moments")
     ws.slots = slots.value
     return moments_reduce(ws)
 
@@ -324,8 +512,9 @@ def poly_moments_f64(x, y, deg: int, ws: MomentWorkspace):
     xs = x.stride(0) if nb > 1 else max(int(x.stride(0)), npix)
     ys = y.stride(0) if nb > 1 else max(int(y.stride(0)), npix)
     slots = C.c_int32(0)
-    nat.check(lib.hsr_poly_moments_f64(_ptr(x), xs, _ptr(y), ys, npix, nb, deg,
-                                       _ptr(ws.partials), C.byref(slots), _stream(torch)), "hsr_poly_moments_f64")
+    with _launch(x) as st:
+        nat.check(lib.hsr_poly_moments_f64(_ptr(x), xs, _ptr(y), ys, npix, nb, deg,
+                                           _ptr(ws.partials), C.byref(slots), st), "hsr_poly_moments_f64")
     ws.slots = slots.value
     return moments_reduce(ws)
 
@@ -336,8 +525,9 @@ def poly_solve(moments, deg: int, min_count: int, out=None):
     lib = nat.load()
     nb = moments.shape[0]
     coeffs = out if out is not None else torch.empty((nb, deg + 1), dtype=torch.float64, device=moments.device)
-    nat.check(lib.hsr_poly_solve(_ptr(moments), nb, deg, int(min_count), _ptr(coeffs), _stream(torch)),
-              "hsr_poly_solve")
+    with _launch(moments) as st:
+        nat.check(lib.hsr_poly_solve(_ptr(moments), nb, deg, int(min_count), _ptr(coeffs), st),
+                  "hsr_poly_solve")
     return coeffs
 
 
@@ -365,8 +555,9 @@ def poly_apply(x, coeffs, mask=None, lohi=None, clip=True, layout: str = PLANAR,
             raise ValueError("coeffs must be a contiguous (nb, deg+1) float64 tensor")
     o = out if out is not None else torch.empty_like(x, memory_format=torch.contiguous_format)
     obs, ops, _, _ = _img(o, layout, n)
-    nat.check(lib.hsr_poly_apply(_ptr(x), xbs, xps, _ptr(mask), _ptr(coeffs), n, deg, npix, _ptr(lohi),
-                                 1 if clip else 0, _ptr(o), obs, ops, _stream(torch)), "hsr_poly_apply")
+    with _launch(x) as st:
+        nat.check(lib.hsr_poly_apply(_ptr(x), xbs, xps, _ptr(mask), _ptr(coeffs), n, deg, npix, _ptr(lohi),
+                                     1 if clip else 0, _ptr(o), obs, ops, st), "hsr_poly_apply")
     return o
 
 
@@ -393,14 +584,17 @@ def percentile_limits(x, mask=None, pmin=2.0, pmax=98.0, layout: str = PLANAR, n
         import torch.distributed as dist
         distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
     if not distributed and _reduce is None:
-        nat.check(lib.hsr_percentile_limits(_ptr(x), xbs, xps, _ptr(mask), npix, n, float(pmin), float(pmax),
-                                            _ptr(work), _ptr(lohi), _stream(torch)), "hsr_percentile_limits")
+        with _launch(x) as st:
+            nat.check(lib.hsr_percentile_limits(_ptr(x), xbs, xps, _ptr(mask), npix, n, float(pmin), float(pmax),
+                                                _ptr(work), _ptr(lohi), st), "hsr_percentile_limits")
         return lohi
     w32 = work.view(torch.int32)
-    nat.check(lib.hsr_percentile_begin(_ptr(work), n, _stream(torch)), "hsr_percentile_begin")
+    with _launch(x) as st:
+        nat.check(lib.hsr_percentile_begin(_ptr(work), n, st), "hsr_percentile_begin")
     for p in (1, 2, 3):
-        nat.check(lib.hsr_percentile_hist(p, _ptr(x), xbs, xps, _ptr(mask), npix, n, _ptr(work), _stream(torch)),
-                  "hsr_percentile_hist")
+        with _launch(x) as st:
+            nat.check(lib.hsr_percentile_hist(p, _ptr(x), xbs, xps, _ptr(mask), npix, n, _ptr(work), st),
+                      "hsr_percentile_hist")
         off, cnt = C.c_int64(0), C.c_int64(0)
         nat.check(lib.hsr_percentile_hist_region(p, n, C.byref(off), C.byref(cnt)), "hsr_percentile_hist_region")
         region = w32[off.value // 4: off.value // 4 + cnt.value]
@@ -409,8 +603,9 @@ def percentile_limits(x, mask=None, pmin=2.0, pmax=98.0, layout: str = PLANAR, n
         else:
             import torch.distributed as dist
             dist.all_reduce(region, op=dist.ReduceOp.SUM, group=group)
-        nat.check(lib.hsr_percentile_scan(p, n, float(pmin), float(pmax), _ptr(work), _ptr(lohi), _stream(torch)),
-                  "hsr_percentile_scan")
+        with _launch(x) as st:
+            nat.check(lib.hsr_percentile_scan(p, n, float(pmin), float(pmax), _ptr(work), _ptr(lohi), st),
+                      "hsr_percentile_scan")
     return lohi
 
 
@@ -424,8 +619,9 @@ def valid_mask(x, pos_band: int = -1, y=None, mask_in=None, layout: str = PLANAR
     if y is not None:
         ybs, yps, ny, _ = _img(y, layout, nby)
     out = torch.empty(npix, dtype=torch.uint8, device=x.device)
-    nat.check(lib.hsr_valid_mask(_ptr(x), xbs, xps, nx, pos_band, _ptr(y), ybs, yps, ny, _ptr(mask_in), npix,
-                                 _ptr(out), _stream(torch)), "hsr_valid_mask")
+    with _launch(x) as st:
+        nat.check(lib.hsr_valid_mask(_ptr(x), xbs, xps, nx, pos_band, _ptr(y), ybs, yps, ny, _ptr(mask_in), npix,
+                                     _ptr(out), st), "hsr_valid_mask")
     return out
 
 
@@ -444,8 +640,9 @@ def block_mean(fine, Hc: int, Wc: int, factor: int, scale: float = 1.0, layout: 
     ol = out_layout or layout
     out = alloc_image(torch, n, Hc * Wc, ol, fine.device)
     obs, ops, _, _ = _img(out, ol, n)
-    nat.check(lib.hsr_block_mean(_ptr(fine), dt, ibs, ips, n, Hc, Wc, factor, float(scale), _ptr(out), obs, ops,
-                                 _stream(torch)), "hsr_block_mean")
+    with _launch(fine) as st:
+        nat.check(lib.hsr_block_mean(_ptr(fine), dt, ibs, ips, n, Hc, Wc, factor, float(scale), _ptr(out), obs, ops,
+                                     st), "hsr_block_mean")
     return out
 
 
@@ -460,23 +657,28 @@ def bilinear_upsample(coarse, Hc: int, Wc: int, factor: int, layout: str = PLANA
     ol = out_layout or layout
     out = alloc_image(torch, n, Hc * factor * Wc * factor, ol, coarse.device)
     obs, ops, _, _ = _img(out, ol, n)
-    nat.check(lib.hsr_bilinear_upsample(_ptr(coarse), ibs, ips, n, Hc, Wc, factor, _ptr(out), obs, ops,
-                                        _stream(torch)), "hsr_bilinear_upsample")
+    with _launch(coarse) as st:
+        nat.check(lib.hsr_bilinear_upsample(_ptr(coarse), ibs, ips, n, Hc, Wc, factor, _ptr(out), obs, ops,
+                                            st), "hsr_bilinear_upsample")
     return out
 
 
-def probe_read_bandwidth(nbytes: int = 1 << 30, iters: int = 10, device="cuda:0") -> float:
-    """Measured pure-read HBM rate of this box in bytes/s (diagnostic for the roofline report)."""
+def probe_read_bandwidth(nbytes: int = 1 << 30, iters: int = 10, device="cuda:0", mode: int = 0) -> float:
+    """Measured pure-read HBM rate of this box in bytes/s (diagnostic for the roofline report).
+    mode 0: K1's own load shape (non-temporal LDS-DMA, 72 KiB slabs, 512 persistent workgroups) - a ceiling for K1;
+    mode 1: a plain 16-byte global_load stream."""
     torch = nat.require_gpu()
     lib = nat.load()
     buf = torch.empty(nbytes // 4, dtype=torch.float32, device=device).normal_()
     sink = torch.zeros(64, dtype=torch.float32, device=device)
-    for _ in range(2):
-        nat.check(lib.hsr_probe_read(_ptr(buf), nbytes, _ptr(sink), _stream(torch)))
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(iters):
-        nat.check(lib.hsr_probe_read(_ptr(buf), nbytes, _ptr(sink), _stream(torch)))
-    e1.record()
+    with _launch(buf) as st:
+        for _ in range(2):
+            nat.check(lib.hsr_probe_read(_ptr(buf), nbytes, mode, _ptr(sink), st))
+        cur = torch.cuda.current_stream(buf.device)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(cur)
+        for _ in range(iters):
+            nat.check(lib.hsr_probe_read(_ptr(buf), nbytes, mode, _ptr(sink), st))
+        e1.record(cur)
     e1.synchronize()
     return nbytes * iters / (e0.elapsed_time(e1) * 1e-3)

@@ -35,16 +35,37 @@ class HsrError(RuntimeError):
 _i32, _i64, _f32, _f64, _vp = C.c_int32, C.c_int64, C.c_float, C.c_double, C.c_void_p
 _pi32 = C.POINTER(C.c_int32)
 
+
+class SrfOptions(C.Structure):
+    """hsr_srf_options (include/hsr.h): per-call tuning of the K1 launches; the library keeps no tuning state."""
+    _fields_ = [("tile_pixels", _i32), ("reserved_cus", _i32), ("u16_single_buffer", _i32), ("reserved", _i32)]
+
+
+class BatchTile(C.Structure):
+    """hsr_batch_tile: one tile of a batch (64 bytes)."""
+    _fields_ = [("cube_dev", _vp), ("real_dev", _vp), ("mask_dev", _vp), ("pseudo_dev", _vp), ("matched_dev", _vp),
+                ("npix", _i64), ("slot0", _i64), ("slots", _i32), ("ngroups", _i32)]
+
+
+class BatchInfo(C.Structure):
+    """hsr_batch_info: what hsr_batch_plan found."""
+    _fields_ = [("nunits", _i64), ("total_pixels", _i64), ("max_npix", _i64), ("ntiles", _i32), ("aligned16", _i32)]
+
+
+BATCH_RECORD_BYTES = 64          # sizeof(hsr_batch_tile) == sizeof(hsr_batch_unit)
+assert C.sizeof(BatchTile) == BATCH_RECORD_BYTES
+_popt = C.POINTER(SrfOptions)
+
 # name -> (restype, argtypes); must list every symbol include/hsr.h declares
 SIGNATURES = {
     "hsr_abi_version": (C.c_int, []),
     "hsr_last_error": (C.c_char_p, []),
     "hsr_moment_count": (C.c_int, [_i32]),
-    "hsr_partial_slots": (C.c_int, [_i64]),
+    "hsr_partial_slots": (C.c_int, [_i64, _popt]),
     "hsr_partials_bytes": (C.c_size_t, [_i32, _i32]),
-    "hsr_srf_integrate": (C.c_int, [_vp, _i64, _i32, _vp, _pi32, _pi32, _i32, _vp, _i64, _i64, _vp]),
+    "hsr_srf_integrate": (C.c_int, [_vp, _i64, _i32, _vp, _pi32, _pi32, _i32, _vp, _i64, _i64, _popt, _vp]),
     "hsr_srf_integrate_moments": (C.c_int, [_vp, _i64, _i32, _vp, _pi32, _pi32, _i32, _vp, _i64, _i64,
-                                            _vp, _i64, _i64, _vp, _f32, _f32, _i32, _vp, _pi32, _vp]),
+                                            _vp, _i64, _i64, _vp, _f32, _f32, _i32, _vp, _pi32, _popt, _vp]),
     "hsr_poly_moments": (C.c_int, [_vp, _i64, _i64, _vp, _i64, _i64, _vp, _i64, _i32, _i32, _f32, _f32, _vp, _vp,
                                    _vp, _pi32, _vp]),
     "hsr_poly_moments_f64": (C.c_int, [_vp, _i64, _vp, _i64, _i64, _i32, _i32, _vp, _pi32, _vp]),
@@ -59,14 +80,19 @@ SIGNATURES = {
     "hsr_percentile_hist_region": (C.c_int, [_i32, _i32, C.POINTER(C.c_int64), C.POINTER(C.c_int64)]),
     "hsr_percentile_hist": (C.c_int, [_i32, _vp, _i64, _i64, _vp, _i64, _i32, _vp, _vp]),
     "hsr_percentile_scan": (C.c_int, [_i32, _i32, _f64, _f64, _vp, _vp, _vp]),
-    "hsr_set_srf_u16_ring": (C.c_int, [_i32]),
     "hsr_tile_encode_u16": (C.c_int, [_vp, _i64, _f32, _i32, _f32, _i32, _vp, _vp]),
     "hsr_tile_decode_u16": (C.c_int, [_vp, _i64, _f32, _i32, _vp, _vp]),
     "hsr_srf_integrate_u16": (C.c_int, [_vp, _i64, _i32, _f32, _i32, _vp, C.POINTER(_i32), C.POINTER(_i32), _i32,
-                                        _vp, _i64, _i64, _vp]),
+                                        _vp, _i64, _i64, _popt, _vp]),
     "hsr_srf_integrate_moments_u16": (C.c_int, [_vp, _i64, _i32, _f32, _i32, _vp, C.POINTER(_i32), C.POINTER(_i32),
                                                 _i32, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _f32, _f32, _i32, _vp,
-                                                C.POINTER(_i32), _vp]),
+                                                C.POINTER(_i32), _popt, _vp]),
+    "hsr_batch_partials_bytes": (C.c_size_t, [_i64, _i32, _i32]),
+    "hsr_batch_plan": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _popt, _vp, _i64, C.POINTER(BatchInfo)]),
+    "hsr_srf_integrate_moments_batched": (C.c_int, [_vp, C.POINTER(BatchInfo), _i32, _f32, _i32, _i32, _vp, _pi32, _pi32,
+                                                    _i32, _i32, _i32, _f32, _f32, _i32, _popt, _vp]),
+    "hsr_moments_reduce_solve_batched": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i64, _vp, _vp, _vp]),
+    "hsr_poly_apply_batched": (C.c_int, [_vp, _i32, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "hsr_ot_work_bytes": (_i64, [_i64, _i64]),
     "hsr_ot_begin": (C.c_int, [_vp, _i64, _vp, _i64, _f64, _vp, _vp]),
     "hsr_ot_iterate": (C.c_int, [_i64, _i64, _i32, _i32, _f64, _vp, _vp, _vp]),
@@ -85,10 +111,7 @@ SIGNATURES = {
                                        _vp, _i64, _vp]),
     "hsr_block_mean": (C.c_int, [_vp, _i32, _i64, _i64, _i32, _i32, _i32, _i32, _f32, _vp, _i64, _i64, _vp]),
     "hsr_bilinear_upsample": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _i64, _vp]),
-    "hsr_set_srf_tile": (C.c_int, [_i32]),
-    "hsr_get_srf_tile": (C.c_int, []),
-    "hsr_set_srf_reserved_cus": (C.c_int, [_i32]),
-    "hsr_probe_read": (C.c_int, [_vp, _i64, _vp, _vp]),
+    "hsr_probe_read": (C.c_int, [_vp, _i64, _i32, _vp, _vp]),
 }
 
 _lib: Optional[C.CDLL] = None

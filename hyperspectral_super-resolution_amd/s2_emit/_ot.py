@@ -77,7 +77,8 @@ def barycentric_targets_device(Xd, Yd, reg=0.05, numItermax=300, stopThr=1e-6, r
     work = torch.empty(int(lib.hsr_ot_work_bytes(ns, nt)), dtype=torch.uint8, device=Xd.device)
     ybar = torch.empty((ns, 3), dtype=torch.float64, device=Xd.device)
     info = torch.empty(6, dtype=torch.int32, device=Xd.device)
-    stream = torch.cuda.current_stream().cuda_stream
+    from ._engine import _stream
+    stream = _stream(torch, Xd)          # raises if Xd is not on the current device
     never = 0x7FFFFFFF
     if poll_every is None or poll_every <= 0:
         nat.check(lib.hsr_ot_sinkhorn_barycentric(Xd.data_ptr(), ns, Yd.data_ptr(), nt, float(reg), int(numItermax),

@@ -48,6 +48,25 @@ class FusionOutput:
         return img if self.layout == nat.PLANAR else img[:, :nb].t().contiguous()
 
 
+class BatchOutput:
+    """Result of SpectralFusion.step_batch: per-tile coefficients and the images of all tiles, tile after tile."""
+
+    def __init__(self, names, tb):
+        self.names, self._tb = list(names), tb
+        self.pseudo, self.matched = tb.pseudo, tb.matched          # (sum npix, row) float32, band-last rows
+        self.moments, self.coeffs = tb.moments, tb.coeffs          # (T, nb, 3deg+2), (T, nb, deg+1) float64
+        self.layout = nat.PIXMAJOR
+
+    def __len__(self):
+        return self._tb.T
+
+    def tile(self, i: int) -> FusionOutput:
+        """FusionOutput view of tile i (same fields as step())."""
+        tb = self._tb
+        return FusionOutput(self.names, tb.tile_rows(i, "pseudo"), tb.moments[i], tb.coeffs[i], tb.tile_rows(i, "matched"),
+                            nat.PIXMAJOR)
+
+
 def exchange_moments(moments, coeffs_solver, group=None, mode: str = "allreduce"):
     """C1: make every rank fit the same polynomial.  ``moments`` (nb, M) float64 tensor (CPU tensor
     with gloo, GPU tensor with RCCL); ``coeffs_solver(moments) -> coeffs`` tensor on the same device.
@@ -80,7 +99,8 @@ class SpectralFusion:
     def __init__(self, emit_w, srf_dict, good_mask=None, deg: int = 3, min_valid: Optional[float] = 0.0,
                  min_count: int = 50, clip: bool = True, apply_mask: bool = False, device=None,
                  group=None, coeff_sync: str = "allreduce", layout: str = nat.PIXMAJOR,
-                 force_exchange: bool = False, tile_scale=None, tile_nodata: Optional[int] = eng.TILE_NODATA):
+                 force_exchange: bool = False, tile_scale=None, tile_nodata: Optional[int] = eng.TILE_NODATA,
+                 reserved_cus: Optional[int] = None, tile_pixels: int = 0, u16_single_buffer: bool = False):
         torch = nat.require_gpu()
         # decode of uint16 cubes (the reference's tile format, tiles_helpers/utils.py:362-374): x = u * tile_scale
         # (default float32(1e-4)), u == tile_nodata -> NaN (None: no nodata value).  Ignored for float32 cubes.
@@ -102,6 +122,15 @@ class SpectralFusion:
             raise ValueError(f"layout must be {nat.PIXMAJOR!r} or {nat.PLANAR!r}")
         self.layout = layout
         self.force_exchange = bool(force_exchange)   # run the collective path even with one rank (tests)
+        # K1 launch geometry of THIS plan (hsr_srf_options travel with every call; the library has no tuning state, so
+        # two plans in one process cannot interfere).  reserved_cus: CUs left free of persistent K1 workgroups so that
+        # the side-stream kernels of submit() (slot reduction, RCCL exchange, solve) run under K1 of the next tile; by
+        # default 8 (one per XCD) for a plan that exchanges, 0 otherwise.  step(), submit() and step_batch() of one plan
+        # use the same geometry, hence the same partial-slot layout and bit-identical coefficients.
+        if reserved_cus is None:
+            reserved_cus = 8 if self._exchanges() else 0
+        self.opts = eng.srf_options(tile_pixels, reserved_cus, u16_single_buffer)
+        self._batches: Dict[tuple, object] = {}
         self._pipe = None                            # state of submit()/flush(), created on first use
         self.ws = eng.MomentWorkspace(self.device, self.table.nb, deg)
         self.table.device_weights(self.device)
@@ -157,7 +186,7 @@ class SpectralFusion:
         pseudo, _ = eng.srf_integrate_moments(cube, self.table, real, self.deg, self.ws, mask,
                                               self.min_valid, self.min_valid, out=pseudo, events=k1_events,
                                               reduce=False, layout=self.layout, real_layout=real_layout,
-                                              scale=self.tile_scale, nodata=self.tile_nodata)
+                                              scale=self.tile_scale, nodata=self.tile_nodata, opts=self.opts)
         if self._exchanges():
             moments = eng.moments_reduce(self.ws)
             moments, coeffs = exchange_moments(moments, self._solve, self.group, self.coeff_sync)
@@ -168,8 +197,41 @@ class SpectralFusion:
         return FusionOutput(self.names, pseudo, moments, coeffs, matched, self.layout)
 
 
+
+    # ---- a batch of independent tiles in three launches ---------------------------------------------------
+    def step_batch(self, cubes, reals, masks=None, k1_events=None) -> "BatchOutput":
+        """The hot path over T independent tiles - the reference's own workload: 100 x 100 EMIT tiles, one fit per
+        tile (tiles_helpers/utils.py:223-305, Spectral_matching.ipynb raw lines 293-294) - in THREE launches for the
+        whole batch instead of three per tile: batched K1+K2, batched slot reduction + solve, batched K3, every tile
+        with its own coefficients (coeff_sync "local" semantics; no collective).  Bit-identical to T step() calls.
+
+        cubes: sequence of (H,W,B)/(npix,B) GPU tensors (float32, or uint16 tiles), or one stacked (T,H,W,B) tensor;
+        reals: matching band-last real-S2 targets (H,W,C>=nb)/(npix,C) or one stacked (T,H,W,C) tensor;
+        masks: optional sequence of uint8 (npix) tensors / None.  The returned BatchOutput (and the batch's buffers)
+        are reused by the next step_batch() call on the same input tensors."""
+        torch = nat.require_gpu()
+        if hasattr(cubes, "dim"):
+            cubes = [cubes[i] for i in range(cubes.shape[0])] if cubes.dim() == 4 else [cubes]
+        if hasattr(reals, "dim"):
+            reals = [reals[i] for i in range(reals.shape[0])] if reals.dim() == 4 else [reals]
+        cubes, reals = list(cubes), list(reals)
+        masks = list(masks) if masks is not None else [None] * len(cubes)
+        key = tuple((c.data_ptr(), tuple(c.shape), r.data_ptr(), tuple(r.shape), 0 if m is None else m.data_ptr())
+                    for c, r, m in zip(cubes, reals, masks))
+        tb = self._batches.get(key)
+        if tb is None:
+            if len(self._batches) >= 4:           # a few live batch plans at most
+                self._batches.pop(next(iter(self._batches)))
+            tb = eng.TileBatch(cubes, reals, masks, self.table, self.deg, self.opts)
+            self._batches[key] = tb
+        eng.batch_srf_integrate_moments(tb, self.min_valid, self.min_valid, self.tile_scale, self.tile_nodata,
+                                        events=k1_events)
+        eng.batch_reduce_solve(tb, self.min_count)
+        eng.batch_poly_apply(tb, use_mask=self.apply_mask, clip=self.clip)
+        return BatchOutput(self.names, tb)
+
     # ---- one fit over several tiles on one GPU --------------------------------------------------------
-    def fuse_mosaic(self, tiles, masks=None):
+    def fuse_mosaic(self, tiles, masks=None, k1_events=None):
         """Global fit over a mosaic held by ONE GPU (BASELINE configs[4] on a single device, and the single-process
         twin of the multi-GPU step): K1+K2 per tile, the per-tile moments added in tile order, one solve (plus the
         exchange when a process group is active, so that ranks holding several tiles each still fit one polynomial),
@@ -184,12 +246,13 @@ class SpectralFusion:
             raise ValueError("masks must match tiles")
         total = None
         pseudos = []
-        for (cube, real), mask in zip(tiles, masks):
+        for ti, ((cube, real), mask) in enumerate(zip(tiles, masks)):
             npix = cube.numel() // cube.shape[-1]
             real2, real_layout = self._real_image(real, npix)
             pseudo, mom = eng.srf_integrate_moments(cube, self.table, real2, self.deg, self.ws, mask, self.min_valid,
-                                                    self.min_valid, out=None, reduce=True, layout=self.layout,
-                                                    real_layout=real_layout, scale=self.tile_scale, nodata=self.tile_nodata)
+                                                    self.min_valid, out=None, events=k1_events if ti == 0 else None,
+                                                    reduce=True, layout=self.layout,
+                                                    real_layout=real_layout, scale=self.tile_scale, nodata=self.tile_nodata, opts=self.opts)
             total = mom.clone() if total is None else total + mom          # tile order: a fixed summation order
             pseudos.append(pseudo)
         if self._exchanges():
@@ -326,7 +389,7 @@ class SpectralFusion:
     def _pipe_finish(self, slot) -> FusionOutput:
         """K3 of a submitted tile on the caller's stream, behind its fit."""
         torch = nat.require_gpu()
-        torch.cuda.current_stream().wait_event(slot["ev_fit"])
+        torch.cuda.current_stream(self.device).wait_event(slot["ev_fit"])
         ws = slot["ws"]
         eng.poly_apply(slot["pseudo"], ws.coeffs, slot["mask"] if self.apply_mask else None, None, self.clip,
                        self.layout, out=slot["matched"], nb=self.table.nb)
@@ -341,10 +404,10 @@ class SpectralFusion:
         st = self._pipe_state(npix)
         slot = st["slots"][st["n"] % 2]
         ws = slot["ws"]
-        main = torch.cuda.current_stream()
+        main = torch.cuda.current_stream(self.device)
         eng.srf_integrate_moments(cube, self.table, real, self.deg, ws, mask, self.min_valid, self.min_valid,
                                   out=slot["pseudo"], events=k1_events, reduce=False, layout=self.layout,
-                                  real_layout=real_layout, scale=self.tile_scale, nodata=self.tile_nodata)
+                                  real_layout=real_layout, scale=self.tile_scale, nodata=self.tile_nodata, opts=self.opts)
         slot["mask"] = mask
         prev = st["pending"]
         out = self._pipe_finish(prev) if prev is not None else None     # K3(i-1), directly behind K1(i) on this stream

@@ -153,10 +153,10 @@ class PolyRidge:
             Q[:, na + T:].zero_()
         nat.check(lib.hsr_polyfeat_expand_f64(_ptr(Xd), Xd.stride(0), Xd.stride(1) if n_in > 1 else 1, _ptr(mean),
                                               _ptr(scale), n, n_in, self.degree, _ptr(Q), Q.stride(0), na,
-                                              _stream(torch)), "hsr_polyfeat_expand_f64")
+                                              _stream(torch, Xd)), "hsr_polyfeat_expand_f64")
         work = torch.empty(max(1, lib.hsr_gram_work_bytes(na, na + tp, n) // 8), dtype=torch.float64, device=Xd.device)
         nat.check(lib.hsr_gram_f64(_ptr(Q), Q.stride(0), na, _ptr(Q), Q.stride(0), na + tp, n, _ptr(work), _ptr(G),
-                                   G.stride(0), _stream(torch)), "hsr_gram_f64")
+                                   G.stride(0), _stream(torch, Q)), "hsr_gram_f64")
         return G
 
     def solve_gram(self, G, mean, scale, n_in: int, T: int):
@@ -181,7 +181,7 @@ class PolyRidge:
         self._chol_info = torch.zeros(1, dtype=torch.int32, device=G.device)   # 0, or the first non-positive pivot
         cwork = torch.empty(lib.hsr_chol_work_bytes(npad) // 8, dtype=torch.float64, device=G.device)
         nat.check(lib.hsr_chol_solve_f64(_ptr(Gp), Gp.stride(0), npad, _ptr(Bp), Bp.stride(0), T, _ptr(cwork),
-                                         _ptr(self._chol_info), _stream(torch)), "hsr_chol_solve_f64")
+                                         _ptr(self._chol_info), _stream(torch, self._chol_info)), "hsr_chol_solve_f64")
         Wm = Bp[:nf]                                     # (nf, T)
         b = ybar - (s / cnt) @ Wm
         self.n_in, self.n_feat, self.n_targets = n_in, nf, T
@@ -227,7 +227,7 @@ class PolyRidge:
         out = torch.empty((self.n_targets, npix), dtype=torch.float32, device=x.device)
         nat.check(lib.hsr_polyfeat_predict(_ptr(x), x_ps, x_cs, _ptr(d["mean"]), _ptr(d["inv"]), npix, self.n_in,
                                            self.degree, _ptr(d["W"]), d["W"].stride(0), _ptr(d["b"]), self.n_targets,
-                                           activation, _ptr(out), out.stride(0), _stream(torch)), "hsr_polyfeat_predict")
+                                           activation, _ptr(out), out.stride(0), _stream(torch, out)), "hsr_polyfeat_predict")
         return out
 
     def predict(self, X):

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HSR_ABI_VERSION 1
+#define HSR_ABI_VERSION 2
 
 #define HSR_OK 0
 #define HSR_ERR_INVALID 1      /* bad argument (shape, alignment, NULL)            */
@@ -49,13 +49,28 @@ extern "C" {
 
 typedef void* hsr_stream_t;
 
+/* Per-call tuning of the K1 launches (NULL = defaults).  There is no process-wide tuning state: two plans in one
+ * process cannot interfere, and a call's partial-slot layout is a function of (npix, *opts) only. */
+typedef struct hsr_srf_options {
+  int32_t tile_pixels;        /* LDS tile of the float32 K1: 0 = default (64): 64 -> 512-thread workgroups, 2 per CU;
+                                 32 -> 256-thread workgroups, 4 per CU.  uint16 cubes and batches always use 64. */
+  int32_t reserved_cus;       /* CUs left without a persistent K1 workgroup (default 0, at most 128): lets the small
+                                 kernels of the previous tile's fit (slot reduction, RCCL exchange, solve) run on another
+                                 stream while K1 streams the next tile. */
+  int32_t u16_single_buffer;  /* uint16 cubes: 0 = double-buffered kernel where it fits (default), 1 = single buffer */
+  int32_t reserved;           /* must be 0 */
+} hsr_srf_options;
+
 /* ---- library ------------------------------------------------------------------------------ */
 int hsr_abi_version(void);
 const char* hsr_last_error(void);
 /* Number of moments per band for a degree: 3*deg + 2. */
 int hsr_moment_count(int32_t deg);
-/* Partial-sum slots a launch over `npix` pixels uses (depends on npix only -> reproducible). */
-int hsr_partial_slots(int64_t npix);
+/* Partial-sum slots a K1 launch over a tile of `npix` pixels uses: min(pixel groups, resident workgroups), a
+ * function of npix and *opts (tile_pixels, reserved_cus) only - never of the device state - so the summation tree,
+ * and with it every bit of the fitted coefficients, is reproducible.  Group g of the tile accumulates into slot
+ * g % slots, in increasing g.  (hsr_poly_moments / _f64 use the default geometry: min(ceil(npix/64), 512).) */
+int hsr_partial_slots(int64_t npix, const hsr_srf_options* opts);
 /* Bytes of the partials workspace for (nb, deg): nb * (3deg+2) * HSR_MAX_PARTIALS doubles. */
 size_t hsr_partials_bytes(int32_t nb, int32_t deg);
 
@@ -68,11 +83,14 @@ size_t hsr_partials_bytes(int32_t nb, int32_t deg);
  *   wn_dev     (nb, B) float32 dense normalised trapezoid weights (host builds them in float64
  *              from np.interp exactly as synth.py:33-35,42-43 and rounds once)
  *   k0, klen   host arrays [nb]: support [k0, k0+klen) of each row of wn (zeros outside)
- *   out_dev    float32 out, element (b, p) at out_dev[b * out_bs + p * out_ps]
+ *   out_dev    float32 out, element (b, p) at out_dev[b * out_bs + p * out_ps].  A pixel-major output whose rows
+ *              are a multiple of 4 floats (<= 16) and 16-byte aligned is owned by the callee as whole rows: the
+ *              pad columns nb..row-1 are written too (with zeros).
  */
 int hsr_srf_integrate(const float* cube_dev, int64_t npix, int32_t B,
                       const float* wn_dev, const int32_t* k0, const int32_t* klen, int32_t nb,
-                      float* out_dev, int64_t out_bs, int64_t out_ps, hsr_stream_t stream);
+                      float* out_dev, int64_t out_bs, int64_t out_ps, const hsr_srf_options* opts,
+                      hsr_stream_t stream);
 
 /* ---- K1+K2 fused: SRF integration and Vandermonde moments in one pass over the cube --------
  * K1 as above and, in the same pass, the per-band power sums that np.polyfit's normal equations
@@ -81,14 +99,15 @@ int hsr_srf_integrate(const float* cube_dev, int64_t npix, int32_t B,
  * pixel p counts for band b iff mask[p] (if given) && finite(x) && finite(y) && x > min_x && y > min_y,
  * with x = out[b][p] (float32) and y = real_dev[b * real_bs + p * real_ps]; sums are float64.
  *   partials_dev  workspace of hsr_partials_bytes(nb, deg); slot layout [nb][3deg+2][slots]
- *   returns the slot count used in *slots_out (a function of npix and the tile setting only).
+ *   returns the slot count used in *slots_out (= hsr_partial_slots(npix, opts)).
  */
 int hsr_srf_integrate_moments(const float* cube_dev, int64_t npix, int32_t B,
                               const float* wn_dev, const int32_t* k0, const int32_t* klen, int32_t nb,
                               float* out_dev, int64_t out_bs, int64_t out_ps,
                               const float* real_dev, int64_t real_bs, int64_t real_ps, const uint8_t* mask_dev,
                               float min_x, float min_y, int32_t deg,
-                              double* partials_dev, int32_t* slots_out, hsr_stream_t stream);
+                              double* partials_dev, int32_t* slots_out, const hsr_srf_options* opts,
+                              hsr_stream_t stream);
 
 /* ---- K2: moments of already materialised planes -----------------------------------------------
  * Same sums as above for x/y planes that exist already (after a percentile stretch, or for the
@@ -178,20 +197,84 @@ int hsr_percentile_scan(int32_t pass, int32_t nb, double pmin, double pmax, void
  * Planes and partial moments are bit-identical to hsr_tile_decode_u16 followed by the float32 entry points;
  * a pixel with a nodata sample is NaN in every band (0 * NaN), exactly as the two-step path.  Other
  * arguments as hsr_srf_integrate / hsr_srf_integrate_moments. */
-int hsr_set_srf_u16_ring(int32_t on);  /* tuning switch: 1 (default) double-buffered uint16 K1, 0 single buffer */
 int hsr_tile_encode_u16(const float* x_dev, int64_t n, float scale, int32_t has_src_nodata, float src_nodata,
                         int32_t nodata_u16, uint16_t* out_dev, hsr_stream_t stream);
 int hsr_tile_decode_u16(const uint16_t* u_dev, int64_t n, float scale, int32_t nodata, float* out_dev,
                         hsr_stream_t stream);
 int hsr_srf_integrate_u16(const uint16_t* cube_dev, int64_t npix, int32_t B, float scale, int32_t nodata,
                           const float* wn_dev, const int32_t* k0, const int32_t* klen, int32_t nb, float* out_dev,
-                          int64_t out_bs, int64_t out_ps, hsr_stream_t stream);
+                          int64_t out_bs, int64_t out_ps, const hsr_srf_options* opts, hsr_stream_t stream);
 int hsr_srf_integrate_moments_u16(const uint16_t* cube_dev, int64_t npix, int32_t B, float scale, int32_t nodata,
                                   const float* wn_dev, const int32_t* k0, const int32_t* klen, int32_t nb,
                                   float* out_dev, int64_t out_bs, int64_t out_ps, const float* real_dev,
                                   int64_t real_bs, int64_t real_ps, const uint8_t* mask_dev, float min_x,
                                   float min_y, int32_t deg, double* partials_dev, int32_t* slots_out,
-                                  hsr_stream_t stream);
+                                  const hsr_srf_options* opts, hsr_stream_t stream);
+
+/* ---- batched small tiles (the reference's actual problem size) -----------------------------------------------
+ * The authors run this pipeline on 100 x 100 EMIT <-> 600 x 600 S2 tile pairs, one independent fit per tile
+ * (tiles_helpers/utils.py:223-305 find_valid_paired_tiles(emit_tile_size=100, scale=6);
+ * legacy_notebooks/Spectral_matching.ipynb raw lines 293-294 "EMIT: (285, 100, 100)").  A 100 x 100 x 285 tile is
+ * 11.4 MB = 2 us of HBM time: launched one by one the step is launch-bound.  These entry points run T tiles of
+ * arbitrary npix_t in ONE launch per stage with per-tile partial slots, per-tile solve and per-tile coefficients
+ * ("independent coefficients per tile" = coeff_sync "local").  Results are bit-identical to T single-tile calls:
+ * a tile's slots, the group -> slot map and every summation order depend on that tile's npix (and *opts) only.
+ *
+ *   1. fill hsr_batch_tile[T] on the host (pointers, npix);  hsr_batch_plan() -> per-tile slot ranges and the work
+ *      units (one per (tile, slot)); call it with units_out = NULL first to size the buffers (info->nunits);
+ *   2. copy tiles and units to the device (plain bytes; they stay valid as long as the pointers do);
+ *   3. per batch: hsr_srf_integrate_moments_batched -> hsr_moments_reduce_solve_batched -> hsr_poly_apply_batched.
+ * Images of a batch are pixel-major rows (band_stride 1): pseudo / matched rows of `out_row` floats, real-S2 rows
+ * of `real_row` floats. */
+typedef struct hsr_batch_tile {       /* 64 bytes */
+  const void* cube_dev;               /* (npix, B) float32 - or uint16 tile samples - pixel-major                */
+  const float* real_dev;              /* real-S2 target rows of the tile (NULL if deg == 0)                      */
+  const uint8_t* mask_dev;            /* npix bytes, 1 = use; or NULL                                            */
+  float* pseudo_dev;                  /* K1 output rows                                                          */
+  float* matched_dev;                 /* K3 output rows (may equal pseudo_dev: in place)                         */
+  int64_t npix;                       /* > 0                                                                     */
+  int64_t slot0;                      /* [plan] first partial slot of the tile in the batch workspace            */
+  int32_t slots;                      /* [plan] = hsr_partial_slots(npix, opts)                                  */
+  int32_t ngroups;                    /* [plan] 64-pixel groups of the tile                                      */
+} hsr_batch_tile;
+typedef struct hsr_batch_unit {       /* 64 bytes, written by hsr_batch_plan, read by the K1 kernels only          */
+  const void* cube_dev;
+  const float* real_dev;
+  const uint8_t* mask_dev;
+  float* pseudo_dev;
+  double* part_dev;                   /* &partials of the tile [slot]; element (band b, moment m) at [(b*M+m)*slots] */
+  int64_t npix;
+  int32_t slots, slot, ngroups, reserved;
+} hsr_batch_unit;
+typedef struct hsr_batch_info {
+  int64_t nunits;                     /* work units = total partial slots of the batch                           */
+  int64_t total_pixels;
+  int64_t max_npix;
+  int32_t ntiles;
+  int32_t aligned16;                  /* every cube base is 16-byte aligned (LDS-DMA path for whole groups)      */
+} hsr_batch_info;
+/* Bytes of the partials workspace of a batch: nunits * nb * (3deg+2) doubles. */
+size_t hsr_batch_partials_bytes(int64_t nunits, int32_t nb, int32_t deg);
+/* Host-side, no GPU call.  Fills slot0 / slots / ngroups of every tile and *info; if units_out != NULL (capacity
+ * units_capacity >= info->nunits) also the unit table, whose part_dev pointers point into partials_dev. */
+int hsr_batch_plan(hsr_batch_tile* tiles, int32_t ntiles, int32_t nb, int32_t deg, double* partials_dev,
+                   const hsr_srf_options* opts, hsr_batch_unit* units_out, int64_t units_capacity,
+                   hsr_batch_info* info);
+/* K1 (+K2 if deg >= 1) over the whole batch in one launch.  cube_dtype 0: float32, 2: uint16 tiles (scale, nodata
+ * as hsr_srf_integrate_u16). */
+int hsr_srf_integrate_moments_batched(const hsr_batch_unit* units_dev, const hsr_batch_info* info, int32_t cube_dtype,
+                                      float scale, int32_t nodata, int32_t B, const float* wn_dev, const int32_t* k0,
+                                      const int32_t* klen, int32_t nb, int32_t out_row, int32_t real_row, float min_x,
+                                      float min_y, int32_t deg, const hsr_srf_options* opts, hsr_stream_t stream);
+/* Per tile: fixed-order slot reduction + np.polyfit solve (same trees as hsr_moments_reduce_solve).
+ * moments_dev (T, nb, 3deg+2), coeffs_dev (T, nb, deg+1) doubles. */
+int hsr_moments_reduce_solve_batched(const hsr_batch_tile* tiles_dev, int32_t ntiles, const double* partials_dev,
+                                     int32_t nb, int32_t deg, int64_t min_count, double* moments_dev,
+                                     double* coeffs_dev, hsr_stream_t stream);
+/* K3 over the whole batch: matched = apply(pseudo) with the tile's own coefficients (hsr_poly_apply semantics;
+ * use_mask: polynomial only where the tile's mask is set). */
+int hsr_poly_apply_batched(const hsr_batch_tile* tiles_dev, int32_t ntiles, int64_t max_npix, const double* coeffs_dev,
+                           int32_t nb, int32_t deg, int32_t row, int32_t use_mask, int32_t clip, hsr_stream_t stream);
 
 /* ---- entropic OT targets ------------------------------------------------------------------
  * Replaces, for uniform marginals, the POT calls of s2_emit/poly_regression.py:49-56 and color.py:97-104:
@@ -276,20 +359,12 @@ int hsr_block_mean(const void* in_dev, int32_t in_dtype, int64_t in_bs, int64_t 
 int hsr_bilinear_upsample(const float* in_dev, int64_t in_bs, int64_t in_ps, int32_t nb, int32_t Hc, int32_t Wc,
                           int32_t factor, float* out_dev, int64_t out_bs, int64_t out_ps, hsr_stream_t stream);
 
-/* ---- tuning --------------------------------------------------------------------------------------
- * LDS tile of K1: 64 pixels (512-thread workgroups, 2 per CU) or 32 pixels (256-thread workgroups,
- * 4 per CU).  Process-wide; results are identical up to the summation tree of the moments. */
-int hsr_set_srf_tile(int32_t pixels);
-int hsr_get_srf_tile(void);
-/* Leave `cus` compute units without a persistent K1 workgroup (default 0): lets the small kernels of the
- * previous tile's fit (slot reduction, RCCL exchange, solve) run on another stream while K1 streams the next
- * tile.  Changes the slot count, hence only the summation tree of the moments. */
-int hsr_set_srf_reserved_cus(int32_t cus);
-
 /* ---- diagnostics -------------------------------------------------------------------------------
- * Pure streaming read of `bytes` bytes (16 B per lane, coalesced) folded into sink_dev[64]: the
- * measured HBM read rate of the box, reported by bench.py beside the vendor peak. */
-int hsr_probe_read(const void* buf_dev, int64_t bytes, float* sink_dev, hsr_stream_t stream);
+ * Pure streaming read of `bytes` bytes (a multiple of 16, 16-byte aligned base): the measured HBM read ceiling of
+ * the box, reported by bench.py beside the vendor peak.  mode 0: K1's own load shape - non-temporal LDS-DMA
+ * (global_load_lds_dwordx4 nt), 72 KiB slabs, 512 persistent workgroups, nothing computed (a ceiling for K1);
+ * mode 1: plain 16-byte global_load per lane folded into sink_dev[64] (what an ordinary streaming kernel reads). */
+int hsr_probe_read(const void* buf_dev, int64_t bytes, int32_t mode, float* sink_dev, hsr_stream_t stream);
 
 #ifdef __cplusplus
 }

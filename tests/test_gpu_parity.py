@@ -112,11 +112,9 @@ def test_k1_vs_oracle_shapes(torch_gpu, H, W, B, offset):
     assert pm.shape == (H * W, eng.padded_row(table.nb))
     assert torch.equal(pm[:, :table.nb].t().contiguous().view(torch.int32),
                        torch.from_numpy(planes.reshape(table.nb, -1)).cuda().view(torch.int32))
-    for tile in (32, 64):      # both tile geometries
-        nat.load().hsr_set_srf_tile(tile)
-        p2 = eng.srf_integrate(cube, table).cpu().numpy().reshape(table.nb, H, W)
+    for tile in (32, 64):      # both tile geometries: a per-call option, no process-wide state to restore
+        p2 = eng.srf_integrate(cube, table, opts=eng.srf_options(tile_pixels=tile)).cpu().numpy().reshape(table.nb, H, W)
         assert np.array_equal(p2.view(np.int32), planes.view(np.int32))
-    nat.load().hsr_set_srf_tile(64)
 
 
 def test_k1_torch_input_zero_copy_and_many_bands(torch_gpu):
@@ -708,14 +706,13 @@ def test_pipelined_submit_flush_matches_step(torch_gpu):
         names = [k for k, v in ps.items() if v is not None]
         real = torch.from_numpy(onp.synthetic_real_planes(np.stack([ps[k] for k in names]).astype(np.float32), seed=seed)).cuda()
         tiles.append((R, real))
-    try:
-        nat.check(nat.load().hsr_set_srf_reserved_cus(1))
-        ref_plan = SpectralFusion(w, srf, good, deg=3)
+    for reserve in (0, 1, 8):     # the reserved CUs belong to the plan: step() and submit() of one plan always agree
+        ref_plan = SpectralFusion(w, srf, good, deg=3, reserved_cus=reserve)
         refs = []
         for R, real in tiles:
             o = ref_plan.step(R, real, reuse_buffers=False)
             refs.append((o.coeffs.clone(), o.matched.clone()))
-        plan = SpectralFusion(w, srf, good, deg=3)
+        plan = SpectralFusion(w, srf, good, deg=3, reserved_cus=reserve)
         outs = []
         for R, real in tiles:
             o = plan.submit(R, real)
@@ -728,8 +725,6 @@ def test_pipelined_submit_flush_matches_step(torch_gpu):
         assert len(outs) == len(refs) == 4
         for (c, m), (rc, rm) in zip(outs, refs):
             assert torch.equal(c, rc) and torch.equal(m.view(torch.int32), rm.view(torch.int32))
-    finally:
-        nat.check(nat.load().hsr_set_srf_reserved_cus(0))
 
 
 # ---------------------------------------------------------------------------------------------
@@ -848,12 +843,9 @@ def test_k1_spectral_size_sweep(torch_gpu, B):
     cube = torch.from_numpy(R).cuda()
     base = None
     for tile in (64, 32):
-        nat.check(nat.load().hsr_set_srf_tile(tile))
-        try:
-            pl = eng.srf_integrate(cube, table, layout=nat.PLANAR)
-            pm = eng.srf_integrate(cube, table, layout=nat.PIXMAJOR)
-        finally:
-            nat.check(nat.load().hsr_set_srf_tile(64))
+        o = eng.srf_options(tile_pixels=tile)
+        pl = eng.srf_integrate(cube, table, layout=nat.PLANAR, opts=o)
+        pm = eng.srf_integrate(cube, table, layout=nat.PIXMAJOR, opts=o)
         got = pl.cpu().numpy().reshape(len(names), H, W)
         for i, k in enumerate(names):
             assert _rel_err(got[i], ref[k]) < 3e-6, (B, tile, k)
@@ -1333,14 +1325,11 @@ def test_u16_single_buffer_kernel_matches_ring(torch_gpu):
     ud = torch.from_numpy(u).cuda()
     real = torch.rand((table.nb, u.shape[0]), device="cuda")
     res = []
-    try:
-        for ring in (1, 0):
-            nat.check(nat.load().hsr_set_srf_u16_ring(ring))
-            ws = eng.MomentWorkspace("cuda", table.nb, 3)
-            p, m = eng.srf_integrate_moments(ud, table, real, 3, ws, None, 0.0, 0.0, layout="pixmajor", real_layout="planar")
-            res.append((p[:, :table.nb].cpu().numpy(), m.cpu().numpy().copy()))
-    finally:
-        nat.check(nat.load().hsr_set_srf_u16_ring(1))
+    for single in (False, True):
+        ws = eng.MomentWorkspace("cuda", table.nb, 3)
+        p, m = eng.srf_integrate_moments(ud, table, real, 3, ws, None, 0.0, 0.0, layout="pixmajor", real_layout="planar",
+                                         opts=eng.srf_options(u16_single_buffer=single))
+        res.append((p[:, :table.nb].cpu().numpy(), m.cpu().numpy().copy()))
     np.testing.assert_array_equal(res[0][0], res[1][0])
     np.testing.assert_array_equal(res[0][1], res[1][1])
     B = 400
@@ -1350,3 +1339,247 @@ def test_u16_single_buffer_kernel_matches_ring(torch_gpu):
     a = eng.srf_integrate(torch.from_numpy(u4).cuda(), t4, layout="planar")
     b = eng.srf_integrate(eng.tile_decode_u16(torch.from_numpy(u4).cuda()), t4, layout="planar")
     np.testing.assert_array_equal(a.cpu().numpy(), b.cpu().numpy())
+
+
+# ---------------------------------------------------------------------------------------------
+# batched small tiles: the reference's own workload (100 x 100 EMIT tiles, one fit per tile,
+# tiles_helpers/utils.py:223-305; Spectral_matching.ipynb "EMIT: (285, 100, 100)")
+# ---------------------------------------------------------------------------------------------
+def _small_tiles(torch, T, H, W, seed0=100):
+    """T synthetic (cube, real band-last) tile pairs on the GPU, plus what the oracle needs for the first ones."""
+    from s2_emit import _engine as eng
+    from s2_emit.synthetic import device_problem
+    probs = [device_problem(H, W, 285, deg=3, seed=seed0 + i) for i in range(T)]
+    return probs
+
+
+@pytest.mark.parametrize("kind", ["f32", "u16"])
+def test_step_batch_64_tiles_100x100_bit_identical_to_step(torch_gpu, kind):
+    """T = 64 tiles of 100 x 100 x 285 in three launches: coefficients, moments and both images are bit-identical to
+    64 step() calls, and tiles 0 and 37 agree with the oracle (pseudo 2e-6, matched 1e-4)."""
+    torch = torch_gpu
+    from s2_emit import SpectralFusion, _engine as eng
+    T, H, W = 64, 100, 100
+    probs = _small_tiles(torch, T, H, W)
+    p0 = probs[0]
+    plan = SpectralFusion(p0.emit_w, p0.srf, p0.good_mask, deg=3, min_valid=0.0, min_count=50)
+    cubes = [p.cube for p in probs]
+    if kind == "u16":
+        cubes = [eng.tile_encode_u16(c) for c in cubes]
+        for c in cubes[:3]:
+            c.view(-1)[12345] = 65535                     # a nodata sample: that pixel is NaN in every band
+    reals = [p.real for p in probs]
+    masks = [None] * T
+    masks[5] = (torch.rand(H * W, device="cuda") > 0.3).to(torch.uint8)
+    out = plan.step_batch(cubes, reals, masks)
+    torch.cuda.synchronize()
+    assert len(out) == T and out.coeffs.shape == (T, 12, 4) and out.pseudo.shape == (T * H * W, 12)
+    nb = len(plan.names)
+    for i in range(T):
+        o = plan.step(cubes[i], reals[i], masks[i], reuse_buffers=False)
+        ti = out.tile(i)
+        assert torch.equal(o.coeffs.view(torch.int64), ti.coeffs.view(torch.int64)), i
+        assert torch.equal(o.moments.view(torch.int64), ti.moments.view(torch.int64)), i
+        assert torch.equal(o.pseudo.view(torch.int32), ti.pseudo.view(torch.int32)), i
+        assert torch.equal(o.matched.view(torch.int32), ti.matched.view(torch.int32)), i
+    # the same call again reuses the batch plan and gives the same bits (no state left behind by the flushes)
+    c1, m1 = out.coeffs.clone(), out.matched.clone()
+    out2 = plan.step_batch(cubes, reals, masks)
+    torch.cuda.synchronize()
+    assert torch.equal(out2.coeffs.view(torch.int64), c1.view(torch.int64)) and torch.equal(out2.matched.view(torch.int32), m1.view(torch.int32))
+    for i in (0, 37):
+        R = (eng.tile_decode_u16(cubes[i]) if kind == "u16" else cubes[i]).cpu().numpy()
+        real = probs[i].real_planes.cpu().numpy()
+        pseudo_o, coeffs_o, matched_o, names = onp.fuse_lsq_reference(R, p0.emit_w, p0.srf, p0.good_mask, real, deg=3)
+        ti = out.tile(i)
+        assert names == plan.names
+        assert _rel_err(ti.planes("pseudo").cpu().numpy().reshape(nb, H, W), pseudo_o) < 2e-6
+        got_m = ti.planes("matched").cpu().numpy().reshape(nb, H, W)
+        if kind == "u16" and i == 0:
+            assert np.isnan(got_m).sum() == nb              # the nodata pixel
+        ok = np.isfinite(matched_o)
+        assert np.max(np.abs(got_m[ok] - matched_o[ok])) < 1e-4
+        np.testing.assert_allclose(ti.coeffs.cpu().numpy(), coeffs_o, rtol=2e-6, atol=1e-7)
+
+
+def test_step_batch_ragged_tile_sizes_and_masks(torch_gpu):
+    """Arbitrary npix per tile in one batch: 1 pixel, just under / at / over one group, a 100 x 100 tile, and a tile
+    with more groups than resident workgroups (its units run several groups each) - every tile bit-identical to
+    its own step(), with and without masks, for every fit degree, float32 and uint16."""
+    torch = torch_gpu
+    from s2_emit import SpectralFusion, _engine as eng
+    w, good = onp.synthetic_wavelengths()
+    srf = onp.synthetic_srf()
+    shapes = [(1, 1), (1, 63), (8, 8), (5, 13), (100, 100), (130, 300), (3, 50)]      # 130 x 300 = 610 groups > 512
+    g = torch.Generator(device="cuda")
+    g.manual_seed(5)
+    cubes, reals, masks = [], [], []
+    for i, (H, W) in enumerate(shapes):
+        c = torch.rand((H, W, 285), generator=g, device="cuda") * 0.6
+        if i == 4:
+            c[3, 7, 100] = float("nan")
+            c[50, 50, 150] = float("inf")             # zero-weight band
+        cubes.append(c)
+        reals.append(torch.rand((H, W, 12), generator=g, device="cuda"))
+        masks.append((torch.rand(H * W, generator=g, device="cuda") > 0.2).to(torch.uint8) if i % 2 else None)
+    for deg in (1, 2, 3, 4):
+        for kind in ("f32", "u16"):
+            cs = cubes if kind == "f32" else [eng.tile_encode_u16(torch.nan_to_num(c, nan=0.1, posinf=0.2)) for c in cubes]
+            plan = SpectralFusion(w, srf, good, deg=deg, min_valid=0.0, min_count=5, apply_mask=True)
+            out = plan.step_batch(cs, reals, masks)
+            torch.cuda.synchronize()
+            for i in range(len(shapes)):
+                o = plan.step(cs[i], reals[i], masks[i], reuse_buffers=False)
+                ti = out.tile(i)
+                assert torch.equal(o.coeffs.view(torch.int64), ti.coeffs.view(torch.int64)), (deg, kind, i)
+                assert torch.equal(o.moments.view(torch.int64), ti.moments.view(torch.int64)), (deg, kind, i)
+                assert torch.equal(o.pseudo.view(torch.int32), ti.pseudo.view(torch.int32)), (deg, kind, i)
+                assert torch.equal(o.matched.view(torch.int32), ti.matched.view(torch.int32)), (deg, kind, i)
+    # one stacked tensor in, same thing
+    st_c = torch.stack([cubes[4], cubes[4].flip(0)])
+    st_r = torch.stack([reals[4], reals[4].flip(0)])
+    plan = SpectralFusion(w, srf, good, deg=2, min_valid=0.0)
+    out = plan.step_batch(st_c, st_r)
+    o = plan.step(st_c[1], st_r[1], reuse_buffers=False)
+    assert torch.equal(o.matched.view(torch.int32), out.tile(1).matched.view(torch.int32))
+
+
+def test_padded_rows_are_owned_and_zeroed(torch_gpu):
+    """Pixel-major outputs with padded rows (nb = 3 -> 4, nb = 13 -> 16): the pad columns come back as zeros, never as
+    whatever the LDS staging area held - in K1, through K3 ('channels >= nb pass through'), float32 and uint16."""
+    torch = torch_gpu
+    from s2_emit import _engine as eng, _native as nat
+    w, good = onp.synthetic_wavelengths()
+    srf13 = onp.synthetic_srf()
+    for names_sel, gm in ((("B4", "B3", "B2"), good), (None, None)):
+        srf = srf13 if names_sel is None else {k: srf13[k] for k in names_sel}
+        table = eng.build_srf_table(w, srf, gm)
+        nb, row = table.nb, eng.padded_row(table.nb)
+        assert row > nb
+        cube = torch.rand((64 * 9 + 5, 285), device="cuda") * 0.6
+        for c in (cube, eng.tile_encode_u16(cube)):
+            out = torch.full((cube.shape[0], row), float("nan"), device="cuda")        # sentinel
+            eng.srf_integrate(c, table, out=out, layout=nat.PIXMAJOR)
+            assert torch.isfinite(out[:, :nb]).all() and (out[:, nb:] == 0).all()
+            co = torch.tensor([[2.0, 0.1]] * nb, dtype=torch.float64, device="cuda")
+            m = eng.poly_apply(out, co, None, None, True, nat.PIXMAJOR, nb=nb)
+            assert (m[:, nb:] == 0).all()
+
+
+def test_plan_device_argument_is_honoured(torch_gpu):
+    """Launches go to the device (and that device's current stream) that owns the tensors, not to whatever device is
+    current.  One GPU here: the explicit-device path must work, on a non-default stream too, and a helper that cannot
+    switch devices must refuse a foreign tensor instead of launching on the wrong GPU."""
+    torch = torch_gpu
+    from s2_emit import SpectralFusion, _engine as eng
+    p = _small_tiles(torch, 1, 40, 30)[0]
+    plan = SpectralFusion(p.emit_w, p.srf, p.good_mask, deg=2, device="cuda:0")
+    ref = plan.step(p.cube, p.real, reuse_buffers=False)
+    side = torch.cuda.Stream(device="cuda:0")
+    with torch.cuda.stream(side):
+        o = plan.step(p.cube, p.real, reuse_buffers=False)
+    side.synchronize()
+    assert torch.equal(o.matched.view(torch.int32), ref.matched.view(torch.int32))
+
+    class Foreign:                      # stands in for a tensor on another GPU
+        is_cuda = True
+        device = torch.device("cuda", torch.cuda.current_device() + 1)
+    with pytest.raises(ValueError, match="current device"):
+        eng._stream(torch, Foreign())
+    assert eng._stream(torch, p.cube).value == torch.cuda.current_stream().cuda_stream
+
+
+def test_mosaic_8_tiles_1024_on_one_gpu(torch_gpu):
+    """BASELINE configs[3]/[4] on the one GPU there is: eight resident 1024 x 1024 x 285 tiles (9.6 GB), ONE global fit
+    (fuse_mosaic), properties at full size + the coefficients of one band against np.polyfit of the union."""
+    torch = torch_gpu
+    from s2_emit import SpectralFusion
+    from s2_emit.synthetic import device_problem
+    T, H, W = 8, 1024, 1024
+    probs = [device_problem(H, W, 285, deg=3, seed=40 + i) for i in range(T)]
+    p0 = probs[0]
+    plan = SpectralFusion(p0.emit_w, p0.srf, p0.good_mask, deg=3, min_valid=0.0, min_count=50)
+    coeffs, moments, outs = plan.fuse_mosaic([(p.cube, p.real) for p in probs])
+    torch.cuda.synchronize()
+    nb = len(plan.names)
+    assert coeffs.shape == (nb, 4) and len(outs) == T
+    assert float(moments[:, 0].min()) > 0.99 * T * H * W            # counts: nearly every pixel valid (x > 0, y > 0)
+    # one band against NumPy on the union of all eight tiles
+    b = 3
+    x = np.concatenate([o.band(b, "pseudo").cpu().numpy() for o in outs]).astype(np.float64)
+    y = np.concatenate([p.real[..., b].reshape(-1).cpu().numpy() for p in probs]).astype(np.float64)
+    ok = (x > 0) & (y > 0)
+    assert int(ok.sum()) == int(round(float(moments[b, 0])))
+    ref = np.polyfit(x[ok], y[ok], 3)
+    np.testing.assert_allclose(coeffs[b].cpu().numpy(), ref, rtol=2e-7, atol=1e-9)
+    # every tile's matched image is the polynomial of its pseudo image (one tile bit-exact against NumPy's polyval)
+    co = coeffs.cpu().numpy()
+    for ti in (0, 7):
+        xs = outs[ti].band(b, "pseudo").cpu().numpy()
+        want = np.clip(np.polyval(co[b], xs.astype(np.float64)).astype(np.float32), 0, 1)
+        assert np.array_equal(outs[ti].band(b, "matched").cpu().numpy(), want)
+    # the mosaic fit equals the sum of the per-tile moments (tile order), and per-tile local fits differ from it
+    local = plan.step(probs[0].cube, probs[0].real, reuse_buffers=False)
+    assert not torch.equal(local.coeffs, coeffs)
+    del outs, probs
+    torch.cuda.empty_cache()
+
+
+def test_bench_line_carries_full_size_parity(torch_gpu):
+    """bench.py as the driver runs it (fewer steps): the JSON line holds roofline (>= 20 event-bracketed launches, total
+    fraction), the CPU baseline (1 thread + all cores) and max_rel_err of the FULL 1024 x 1024 tile against the
+    oracle run on the same cube - C3 is oracle-checked at full size, not only through properties."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "5", "--warmup", "2", "--cpu-rows", "64"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["steps"] == 5 and line["dtype"] == "f32" and line["vs_baseline"] is None
+    roof = line["roofline"]
+    assert roof["kernel_launches_timed"] >= 20 and 0.2 < roof["frac"] < 1.0 and roof["total_fraction"] > roof["step_frac_of_peak"]
+    assert roof["measured_read_peak"] > roof["measured_plain_read"] * 0.9
+    cb = line["cpu_baseline"]
+    assert cb["cores"] == 1 and cb["all_cores"]["cores"] >= 1 and cb["all_cores"]["value"] > cb["value"] * 0.5
+    err = line["max_rel_err"]
+    assert err["pixels_checked"] == 1024 * 1024 and err["pseudo"] < 2e-6 and err["matched"] < 1e-4, err
+
+
+def test_integration_md_stub_runs(torch_gpu):
+    """The ctypes stub printed in INTEGRATION.md, exactly as a maintainer of the reference would write it (nothing
+    from this package but the shared library), gives the package's own planes."""
+    torch = torch_gpu
+    import ctypes as C, os
+    import s2_emit
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    _lib = C.CDLL(os.path.join(root, "hyperspectral_super-resolution_amd", "lib", "libhsr_mi355x.so"))
+    _lib.hsr_srf_integrate.restype = C.c_int
+    _lib.hsr_srf_integrate.argtypes = [C.c_void_p, C.c_int64, C.c_int32, C.c_void_p,
+                                       C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_int32,
+                                       C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_void_p]
+    _lib.hsr_last_error.restype = C.c_char_p
+
+    def srf_integrate(cube, Wn, k0, klen):
+        npix, B, nb = cube.shape[0] * cube.shape[1], cube.shape[2], Wn.shape[0]
+        out = torch.empty((nb, npix), dtype=torch.float32, device=cube.device)
+        rc = _lib.hsr_srf_integrate(cube.data_ptr(), npix, B, Wn.data_ptr(),
+                                    k0.ctypes.data_as(C.POINTER(C.c_int32)),
+                                    klen.ctypes.data_as(C.POINTER(C.c_int32)), nb,
+                                    out.data_ptr(), npix, 1, None,
+                                    torch.cuda.current_stream().cuda_stream)
+        if rc:
+            raise RuntimeError(_lib.hsr_last_error().decode())
+        return out
+
+    srf = onp.synthetic_srf()
+    w, good = onp.synthetic_wavelengths()
+    R = onp.synthetic_cube(40, 30, seed=3)
+    Wn64, names = onp.srf_weight_matrix(w, srf, good)
+    Wn = np.ascontiguousarray(Wn64, dtype=np.float32)
+    nz = [np.flatnonzero(r) for r in Wn]
+    k0 = np.array([z[0] for z in nz], np.int32)
+    klen = np.array([z[-1] - z[0] + 1 for z in nz], np.int32)
+    planes = srf_integrate(torch.from_numpy(R).cuda(), torch.from_numpy(Wn).cuda(), k0, klen).cpu().numpy()
+    ref = s2_emit.pseudo_s2_srf_integral(R, w, srf, good)
+    for i, k in enumerate(names):
+        assert np.array_equal(planes[i].reshape(40, 30), ref[k].astype(np.float32)), k

@@ -32,34 +32,45 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/hsr.h but not exported"
         assert n in nat.SIGNATURES, f"{n} has no ctypes signature in _native.py"
     assert set(nat.SIGNATURES) == set(names)
-    assert lib.hsr_abi_version() == 1
+    assert lib.hsr_abi_version() == 2
 
 
 def test_sizing_helpers_and_error_strings():
     lib = nat.load()
     assert [lib.hsr_moment_count(d) for d in (1, 2, 3, 4)] == [5, 8, 11, 14]
     assert lib.hsr_moment_count(0) == -1 and lib.hsr_moment_count(5) == -1
-    assert lib.hsr_partial_slots(1) == 1 and lib.hsr_partial_slots(64) == 1 and lib.hsr_partial_slots(65) == 2
-    assert lib.hsr_partial_slots(1 << 20) == 512 and lib.hsr_partial_slots(1 << 30) == 512
+    assert lib.hsr_partial_slots(1, None) == 1 and lib.hsr_partial_slots(64, None) == 1 and lib.hsr_partial_slots(65, None) == 2
+    assert lib.hsr_partial_slots(1 << 20, None) == 512 and lib.hsr_partial_slots(1 << 30, None) == 512
+    # the slot layout is a function of (npix, options) only: no process-wide tuning state exists any more
+    o = nat.SrfOptions(32, 0, 0, 0)
+    assert lib.hsr_partial_slots(65, ctypes.byref(o)) == 3 and lib.hsr_partial_slots(1 << 20, ctypes.byref(o)) == 1024
+    o = nat.SrfOptions(0, 8, 0, 0)
+    assert lib.hsr_partial_slots(1 << 20, ctypes.byref(o)) == 496 and lib.hsr_partial_slots(1 << 20, None) == 512
+    assert lib.hsr_partial_slots(100, ctypes.byref(nat.SrfOptions(48, 0, 0, 0))) == -1 and b"tile_pixels" in lib.hsr_last_error()
+    assert lib.hsr_partial_slots(100, ctypes.byref(nat.SrfOptions(0, 200, 0, 0))) == -1
+    assert not hasattr(lib, "hsr_set_srf_tile") and not hasattr(lib, "hsr_set_srf_reserved_cus")
     assert lib.hsr_partials_bytes(12, 3) == 12 * 11 * 4096 * 8
     assert lib.hsr_percentile_work_bytes(3) > 3 * (2048 + 4 * 2048 + 4 * 1024) * 4
     # argument validation happens before any device work -> testable without a GPU
     k = (ctypes.c_int32 * 1)(0)
-    rc = lib.hsr_srf_integrate(None, 10, 285, None, k, k, 1, None, 10, 1, None)
+    rc = lib.hsr_srf_integrate(None, 10, 285, None, k, k, 1, None, 10, 1, None, None)
     assert rc == 1 and b"NULL" in lib.hsr_last_error()
-    rc = lib.hsr_srf_integrate(ctypes.c_void_p(16), 10, 9999, ctypes.c_void_p(16), k, k, 1, ctypes.c_void_p(16), 10, 1, None)
+    rc = lib.hsr_srf_integrate(ctypes.c_void_p(16), 10, 9999, ctypes.c_void_p(16), k, k, 1, ctypes.c_void_p(16), 10, 1, None, None)
     assert rc == 2 and b"B=9999" in lib.hsr_last_error()
     rc = lib.hsr_poly_solve(None, 3, 2, 50, None, None)
     assert rc == 1
     # strides must describe band-major planes or pixel-major rows
-    rc = lib.hsr_srf_integrate(ctypes.c_void_p(16), 10, 285, ctypes.c_void_p(16), k, k, 1, ctypes.c_void_p(16), 3, 7, None)
+    rc = lib.hsr_srf_integrate(ctypes.c_void_p(16), 10, 285, ctypes.c_void_p(16), k, k, 1, ctypes.c_void_p(16), 3, 7, None, None)
     assert rc == 1 and b"neither band-major nor pixel-major" in lib.hsr_last_error()
+    bad = nat.SrfOptions(0, 0, 0, 7)
+    rc = lib.hsr_srf_integrate(ctypes.c_void_p(16), 10, 285, ctypes.c_void_p(16), k, k, 1, ctypes.c_void_p(16), 10, 1, ctypes.byref(bad), None)
+    assert rc == 1 and b"reserved must be 0" in lib.hsr_last_error()
     # the rows added later in the round validate the same way
     P = ctypes.c_void_p(256)
     assert lib.hsr_tile_decode_u16(P, 10, 1e-4, 70000, P, None) == 1 and b"not a uint16 value" in lib.hsr_last_error()
     assert lib.hsr_tile_decode_u16(None, 0, 1e-4, 65535, None, None) == 0            # empty input: nothing to do
     assert lib.hsr_tile_encode_u16(P, 10, 1e4, 0, 0.0, 0, P, None) == 1 and b"nodata_u16" in lib.hsr_last_error()
-    assert lib.hsr_srf_integrate_u16(P, 10, 285, 1e-4, 1 << 20, P, k, k, 1, P, 10, 1, None) == 1
+    assert lib.hsr_srf_integrate_u16(P, 10, 285, 1e-4, 1 << 20, P, k, k, 1, P, 10, 1, None, None) == 1
     assert lib.hsr_percentile_hist(4, P, 10, 1, None, 10, 1, P, None) == 1
     off, cnt = ctypes.c_int64(0), ctypes.c_int64(0)
     assert lib.hsr_percentile_hist_region(1, 3, ctypes.byref(off), ctypes.byref(cnt)) == 0 and cnt.value == 3 * (2048 + 4)
@@ -70,8 +81,60 @@ def test_sizing_helpers_and_error_strings():
     assert lib.hsr_ot_iterate(10, 10, 0, 5, 1e-6, ctypes.c_void_p(8), None, None) == 1 and b"256-byte aligned" in lib.hsr_last_error()
     assert lib.hsr_gram_f64(P, 30, 32, P, 48, 48, 10, P, P, 48, None) == 1
     assert lib.hsr_gram_work_bytes(288, 576, 29127) >= 34 * 18 * 36 * 256 * 8
-    assert lib.hsr_set_srf_tile(48) == 1 and lib.hsr_get_srf_tile() == 64
-    assert lib.hsr_set_srf_tile(32) == 0 and lib.hsr_get_srf_tile() == 32 and lib.hsr_set_srf_tile(64) == 0
+    assert lib.hsr_probe_read(P, 1 << 20, 2, P, None) == 1 and b"mode" in lib.hsr_last_error()
+
+
+def test_batch_plan_host_side():
+    """hsr_batch_plan is pure host code: per-tile slot ranges == hsr_partial_slots of each tile, one unit per
+    (tile, slot), longest units first, part_dev pointers inside the workspace."""
+    lib = nat.load()
+    npix = [10000, 64, 65, 1 << 20, 10000, 1]
+    T = len(npix)
+    tiles = (nat.BatchTile * T)()
+    for i, n in enumerate(npix):
+        tiles[i].cube_dev = 0x10000000 + i * 0x1000000
+        tiles[i].real_dev = 0x20000000 + i * 0x1000000
+        tiles[i].pseudo_dev = 0x30000000 + i * 0x1000000
+        tiles[i].matched_dev = 0x40000000 + i * 0x1000000
+        tiles[i].npix = n
+    info = nat.BatchInfo()
+    nb, deg, M = 12, 3, 11
+    assert lib.hsr_batch_plan(tiles, T, nb, deg, None, None, None, 0, ctypes.byref(info)) == 0
+    slots = [lib.hsr_partial_slots(n, None) for n in npix]
+    assert [tiles[i].slots for i in range(T)] == slots == [157, 1, 2, 512, 157, 1]
+    assert [tiles[i].ngroups for i in range(T)] == [157, 1, 2, 16384, 157, 1]
+    assert [tiles[i].slot0 for i in range(T)] == list(np.cumsum([0] + slots[:-1]))
+    assert info.nunits == sum(slots) and info.total_pixels == sum(npix) and info.max_npix == 1 << 20
+    assert info.ntiles == T and info.aligned16 == 1
+    assert lib.hsr_batch_partials_bytes(info.nunits, nb, deg) == info.nunits * nb * M * 8
+    n = int(info.nunits)
+    buf = (ctypes.c_uint8 * (64 * n))()
+    base = 0x50000000
+    assert lib.hsr_batch_plan(tiles, T, nb, deg, ctypes.c_void_p(base), None, buf, n - 1, ctypes.byref(info)) == 1   # too small
+    assert lib.hsr_batch_plan(tiles, T, nb, deg, ctypes.c_void_p(base), None, buf, n, ctypes.byref(info)) == 0
+    rec = np.frombuffer(buf, dtype=np.dtype([("cube", "<u8"), ("real", "<u8"), ("mask", "<u8"), ("pseudo", "<u8"), ("part", "<u8"),
+                                              ("npix", "<i8"), ("slots", "<i4"), ("slot", "<i4"), ("ngroups", "<i4"), ("pad", "<i4")]))
+    assert len(rec) == n
+    seen = set()
+    lens = []
+    for r in rec:
+        t = [i for i in range(T) if tiles[i].cube_dev == int(r["cube"])][0]
+        assert (int(r["npix"]), int(r["slots"]), int(r["ngroups"])) == (npix[t], slots[t], tiles[t].ngroups)
+        assert 0 <= r["slot"] < slots[t] and (t, int(r["slot"])) not in seen
+        seen.add((t, int(r["slot"])))
+        assert int(r["part"]) == base + 8 * (int(tiles[t].slot0) * nb * M + int(r["slot"]))
+        lens.append((tiles[t].ngroups - int(r["slot"]) + slots[t] - 1) // slots[t])
+    assert len(seen) == n and lens == sorted(lens, reverse=True) and lens[0] == 32 and lens[-1] == 1
+    # options: reserved CUs shrink the slot cap of the big tile only
+    o = nat.SrfOptions(0, 8, 0, 0)
+    assert lib.hsr_batch_plan(tiles, T, nb, deg, None, ctypes.byref(o), None, 0, ctypes.byref(info)) == 0
+    assert tiles[3].slots == 496 and tiles[0].slots == 157
+    # validation
+    tiles[1].npix = 0
+    assert lib.hsr_batch_plan(tiles, T, nb, deg, None, None, None, 0, ctypes.byref(info)) == 1 and b"npix" in lib.hsr_last_error()
+    tiles[1].npix = 64
+    tiles[2].pseudo_dev = 0x30000004
+    assert lib.hsr_batch_plan(tiles, T, nb, deg, None, None, None, 0, ctypes.byref(info)) == 1 and b"16-byte" in lib.hsr_last_error()
 
 
 def test_polyfeat_table_matches_sklearn_order():

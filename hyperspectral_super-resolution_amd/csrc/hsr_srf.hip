@@ -371,7 +371,12 @@ __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
           const int bb = bidx[j];
           yv[j] = load_f32_async(cu.real_dev + bb * a.real_bs + pc * a.real_ps);
         }
-        if (cu.mask_dev != nullptr) mraw = load_u8_async(cu.mask_dev + pc);
+        // Batch launches: the mask comes and goes from unit to unit.  An inline-asm load under a condition that
+        // changes inside the loop is merged with the default value by a register copy the compiler may place BEFORE the
+        // data has landed (seen: a masked tile's moments changed from launch to launch).  So the byte is loaded
+        // unconditionally - from any valid address when there is no mask - and selected after the wait.
+        if (BATCH) mraw = load_u8_async(cu.mask_dev != nullptr ? cu.mask_dev + pc : reinterpret_cast<const uint8_t*>(cu.real_dev));
+        else if (cu.mask_dev != nullptr) mraw = load_u8_async(cu.mask_dev + pc);
       }
     };
     auto wait_targets = [&]() {
@@ -379,6 +384,7 @@ __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         static_assert(kBandSlots == 2, "pin list below");
         asm volatile("" : "+v"(yv[0]), "+v"(yv[1]), "+v"(mraw));
+        if (BATCH && cu.mask_dev == nullptr) mraw = 1u;
       }
     };
     // everything that fills the wait for the DMA: targets, the next unit record, the previous group's output slab,
@@ -745,7 +751,8 @@ __global__ __launch_bounds__(512, 4) void srf_u16_kernel(const SrfArgs a) {
         const int64_t pc = pvalid ? pix0 + pl : cu.npix - 1;
 #pragma unroll
         for (int j = 0; j < kBandSlots; ++j) yv[j] = load_f32_async(cu.real_dev + bidx[j] * a.real_bs + pc * a.real_ps);
-        if (cu.mask_dev != nullptr) mraw = load_u8_async(cu.mask_dev + pc);
+        if (BATCH) mraw = load_u8_async(cu.mask_dev != nullptr ? cu.mask_dev + pc : reinterpret_cast<const uint8_t*>(cu.real_dev));
+        else if (cu.mask_dev != nullptr) mraw = load_u8_async(cu.mask_dev + pc);     // see srf_kernel
       }
     };
     auto wait_targets = [&]() {
@@ -753,6 +760,7 @@ __global__ __launch_bounds__(512, 4) void srf_u16_kernel(const SrfArgs a) {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         static_assert(kBandSlots == 2, "pin list below");
         asm volatile("" : "+v"(yv[0]), "+v"(yv[1]), "+v"(mraw));
+        if (BATCH && cu.mask_dev == nullptr) mraw = 1u;
       }
     };
     auto behind_the_dma = [&]() {
@@ -926,8 +934,9 @@ __global__ __launch_bounds__(512, 4) void srf_u16_ring_kernel(const SrfArgs a) {
       const int64_t pc = pl < left ? pix0 + pl : u.npix - 1;
 #pragma unroll
       for (int j = 0; j < kBandSlots; ++j) yn[j] = load_f32_async(u.real_dev + bidx[j] * a.real_bs + pc * a.real_ps);
-      mn = 1u;
-      if (u.mask_dev != nullptr) mn = load_u8_async(u.mask_dev + pc);
+      // unconditional load + select after the wait in batch launches (srf_kernel explains)
+      if (BATCH) mn = load_u8_async(u.mask_dev != nullptr ? u.mask_dev + pc : reinterpret_cast<const uint8_t*>(u.real_dev));
+      else if (u.mask_dev != nullptr) mn = load_u8_async(u.mask_dev + pc);
     }
   };
 
@@ -976,7 +985,7 @@ __global__ __launch_bounds__(512, 4) void srf_u16_ring_kernel(const SrfArgs a) {
     asm volatile("" : "+v"(yn[0]), "+v"(yn[1]), "+v"(mn));
     yv[0] = yn[0];
     yv[1] = yn[1];
-    mraw = mn;
+    mraw = (BATCH && cu.mask_dev == nullptr) ? 1u : mn;
     if (npx < P) {  // ragged last group: plain copy, tail of the last chunk zeroed
       const uint16_t* src = reinterpret_cast<const uint16_t*>(cu.cube_dev) + pix0 * B;
       const int n = npx * B;
@@ -989,11 +998,16 @@ __global__ __launch_bounds__(512, 4) void srf_u16_ring_kernel(const SrfArgs a) {
     const int g2 = g + cu.slots;
     const bool same_unit = g2 < cu.ngroups;
     const bool next_unit = BATCH && !same_unit && nidx < a.nunits;
-    if (same_unit) {
-      prefetch(cu, g2, cur ^ 1);
-    } else if (next_unit) {
-      const SrfUnit nu = unit_from_lds(ustage + 16 * cur);
-      prefetch(nu, nu.slot, cur ^ 1);
+    {
+      // ONE call site for the prefetch: its inline-asm loads write loop-carried registers (yn, mn), and two sites under
+      // different conditions would be merged by register copies the compiler may place before the data has landed
+      SrfUnit nx = cu;
+      int ng = g2;
+      if (next_unit) {
+        nx = unit_from_lds(ustage + 16 * cur);
+        ng = nx.slot;
+      }
+      if (same_unit || next_unit) prefetch(nx, ng, cur ^ 1);
     }
     fetch_record(next_unit ? nidx + gridDim.x : nidx, cur ^ 1);
     if (OUTV) flush_stage<T>(ostage, prev_out, prev_pix0, prev_npx, ops, t);

@@ -1399,7 +1399,9 @@ def test_step_batch_64_tiles_100x100_bit_identical_to_step(torch_gpu, kind):
             assert np.isnan(got_m).sum() == nb              # the nodata pixel
         ok = np.isfinite(matched_o)
         assert np.max(np.abs(got_m[ok] - matched_o[ok])) < 1e-4
-        np.testing.assert_allclose(ti.coeffs.cpu().numpy(), coeffs_o, rtol=2e-6, atol=1e-7)
+        # coefficients: the oracle fits ITS float32 planes, the kernel its own (1e-7 apart); with cond(V) ~ 1e4 for a
+        # cubic on [0, 0.6] that moves the coefficients by ~1e-5 while the polynomial (matched, above) moves by 1e-7
+        np.testing.assert_allclose(ti.coeffs.cpu().numpy(), coeffs_o, rtol=1e-4, atol=1e-5)
 
 
 def test_step_batch_ragged_tile_sizes_and_masks(torch_gpu):
@@ -1486,7 +1488,7 @@ def test_plan_device_argument_is_honoured(torch_gpu):
         device = torch.device("cuda", torch.cuda.current_device() + 1)
     with pytest.raises(ValueError, match="current device"):
         eng._stream(torch, Foreign())
-    assert eng._stream(torch, p.cube).value == torch.cuda.current_stream().cuda_stream
+    assert (eng._stream(torch, p.cube).value or 0) == torch.cuda.current_stream().cuda_stream
 
 
 def test_mosaic_8_tiles_1024_on_one_gpu(torch_gpu):

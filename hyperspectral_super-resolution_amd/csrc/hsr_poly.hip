@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256) void moments_kernel(const MomArgs a) {
   if (threadIdx.x < M) {
     const int m = threadIdx.x;
     const double s = ((red[0][m] + red[1][m]) + red[2][m]) + red[3][m];
-    a.partials[((size_t)b * M + m) * a.slots + blockIdx.x] = s;
+    a.partials[((size_t)blockIdx.x * gridDim.y + b) * M + m] = s;     // slot-major: [slot][band][moment]
   }
 }
 
@@ -117,21 +117,24 @@ __global__ __launch_bounds__(256) void moments_f64_kernel(const double* __restri
   __syncthreads();
   if (threadIdx.x < M) {
     const int m = threadIdx.x;
-    partials[((size_t)b * M + m) * slots + blockIdx.x] = ((red[0][m] + red[1][m]) + red[2][m]) + red[3][m];
+    partials[((size_t)blockIdx.x * gridDim.y + b) * M + m] = ((red[0][m] + red[1][m]) + red[2][m]) + red[3][m];
   }
 }
 
 // one wave per (band, moment) row; lane-strided partial sums then the fixed butterfly
 // Lane-strided sum of one slot row in a fixed order (slot = lane, lane+64, ...), the loads issued in
 // independent batches of 8 so that the row costs one memory round trip instead of slots/64.
-__device__ __forceinline__ double row_sum(const double* __restrict__ row, int slots, int lane) {
+// The partials are slot-major, [slot][band][moment] (a K1 work unit writes its 2*M*... sums as whole cache lines; the
+// first layout, [band][moment][slot], made every unit of a batch scatter 8-byte stores over nb*M lines shared with
+// units running on other XCDs): row = address of (slot 0, band, moment), stride = nb * M doubles between slots.
+__device__ __forceinline__ double row_sum(const double* __restrict__ row, int slots, int stride, int lane) {
   double s = 0.0;
   for (int i0 = lane; i0 < slots; i0 += 64 * 8) {
     double v[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const int i = i0 + 64 * u;
-      v[u] = i < slots ? row[i] : 0.0;
+      v[u] = i < slots ? row[(size_t)i * stride] : 0.0;
     }
 #pragma unroll
     for (int u = 0; u < 8; ++u) s += v[u];   // adding +0.0 for absent slots does not change the sum
@@ -147,7 +150,7 @@ __global__ __launch_bounds__(256) void reduce_kernel(const double* __restrict__ 
                                                      double* __restrict__ moments) {
   const int lane = threadIdx.x & 63;
   for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < nrows; row += gridDim.x * 4) {
-    const double s = row_sum(partials + (size_t)row * slots, slots, lane);
+    const double s = row_sum(partials + row, slots, nrows, lane);
     if (lane == 0) moments[row] = s;
   }
 }
@@ -308,7 +311,7 @@ __global__ __launch_bounds__(1024) void reduce_solve_kernel(const double* __rest
   const int b = blockIdx.x;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int m = wave; m < M; m += 16) {   // one wave per moment row (M <= 14 < 16 waves)
-    const double s = row_sum(partials + ((size_t)b * M + m) * slots, slots, lane);
+    const double s = row_sum(partials + (size_t)b * M + m, slots, (int)gridDim.x * M, lane);
     if (lane == 0) {
       mom[m] = s;
       moments[(size_t)b * M + m] = s;
@@ -318,29 +321,32 @@ __global__ __launch_bounds__(1024) void reduce_solve_kernel(const double* __rest
   if (threadIdx.x == 0) solve_band(mom, deg, min_count, coeffs + (size_t)b * (deg + 1));
 }
 
-// Batch form (hsr_moments_reduce_solve_batched): workgroup (band, tile) - the tile's slot block starts at
-// slot0 * nb * M in the batch workspace and has its own slot count.  Same row_sum tree, same solve -> same bits as the
-// single-tile launch on that tile.
+// Batch form (hsr_moments_reduce_solve_batched): ONE workgroup per tile (16 waves: the nb * M slot rows round-robin
+// over the waves, then one thread per band solves).  The tile's slot block starts at slot0 * nb * M in the batch
+// workspace and has its own slot count.  Same row_sum tree, same solve -> same bits as the single-tile launch on that
+// tile.  (First version: a (band, tile) grid of 1024-thread workgroups with thread 0 solving - 49 us for 256 tiles,
+// six rounds of workgroups; this one is a single round.)
 __global__ __launch_bounds__(1024) void reduce_solve_batched_kernel(const hsr_batch_tile* __restrict__ tiles,
                                                                     const double* __restrict__ partials, int nb, int deg,
                                                                     long long min_count, double* __restrict__ moments,
                                                                     double* __restrict__ coeffs) {
-  __shared__ double mom[3 * HSR_MAX_DEG + 2];
+  __shared__ double mom[HSR_MAX_BANDS * (3 * HSR_MAX_DEG + 2)];
   const int M = moment_count(deg);
-  const int b = blockIdx.x, tile = blockIdx.y;
+  const int tile = blockIdx.x;
   const int64_t slot0 = tiles[tile].slot0;
   const int slots = tiles[tile].slots;
   const double* part = partials + (size_t)slot0 * nb * M;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int m = wave; m < M; m += 16) {
-    const double s = row_sum(part + ((size_t)b * M + m) * slots, slots, lane);
+  for (int r = wave; r < nb * M; r += 16) {      // row r = band * M + moment
+    const double s = row_sum(part + r, slots, nb * M, lane);
     if (lane == 0) {
-      mom[m] = s;
-      moments[((size_t)tile * nb + b) * M + m] = s;
+      mom[r] = s;
+      moments[(size_t)tile * nb * M + r] = s;
     }
   }
   __syncthreads();
-  if (threadIdx.x == 0) solve_band(mom, deg, min_count, coeffs + ((size_t)tile * nb + b) * (deg + 1));
+  if (threadIdx.x < nb)
+    solve_band(mom + threadIdx.x * M, deg, min_count, coeffs + ((size_t)tile * nb + threadIdx.x) * (deg + 1));
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -816,7 +822,7 @@ extern "C" int hsr_moments_reduce_solve_batched(const hsr_batch_tile* tiles_dev,
   HSR_REQUIRE(ntiles >= 1 && ntiles <= 65535, HSR_ERR_UNSUPPORTED, "hsr_moments_reduce_solve_batched: ntiles=%d outside [1,65535]", ntiles);
   HSR_REQUIRE(nb >= 1 && nb <= HSR_MAX_BANDS && deg >= 1 && deg <= HSR_MAX_DEG, HSR_ERR_UNSUPPORTED,
               "hsr_moments_reduce_solve_batched: nb=%d deg=%d", nb, deg);
-  hipLaunchKernelGGL(reduce_solve_batched_kernel, dim3(nb, ntiles), dim3(1024), 0, (hipStream_t)stream, tiles_dev, partials_dev,
+  hipLaunchKernelGGL(reduce_solve_batched_kernel, dim3(ntiles), dim3(1024), 0, (hipStream_t)stream, tiles_dev, partials_dev,
                      nb, deg, (long long)min_count, moments_dev, coeffs_dev);
   HSR_LAUNCH_CHECK("reduce_solve_batched_kernel");
   return HSR_OK;

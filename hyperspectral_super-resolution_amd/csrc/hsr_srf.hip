@@ -50,7 +50,7 @@ typedef hsr_batch_unit SrfUnit;
 static_assert(sizeof(SrfUnit) == 64 && sizeof(hsr_batch_tile) == 64, "batch records are 64 bytes");
 
 struct SrfArgs {
-  SrfUnit one;            // single-tile launch: the tile (slot = blockIdx.x, part_dev = base of slot 0)
+  SrfUnit one;            // single-tile launch: the tile (slot = blockIdx.x, part_dev = base of slot 0); partials [slot][band][moment]
   const SrfUnit* units;   // batch launch: the unit table (device)
   int32_t nunits;
   int32_t B;
@@ -196,71 +196,113 @@ __device__ __forceinline__ void flush_stage(const float* ostage, float* out, int
   for (int i = t; i < n4; i += T) st_stream(dst + i, src[i]);
 }
 
-// ---- fixed-order sum of one double per pixel over the pixels of a group, without LDS ----------------------
-// v_add_f64 cannot take a DPP operand, so one tree level is two v_mov_b32_dpp (the halves of the double) and one
-// add.  (The first version used __shfl_xor = two ds_bpermute_b32 per level: fine once per launch, but a batch of
-// small tiles reduces once per 64-pixel group and 264 LDS-crossbar instructions per wave and group were as
-// expensive as the dot products.)
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ double dpp_f64(double v) {
-  const int lo = __double2loint(v), hi = __double2hiint(v);
-  const int l2 = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);   // rows outside ROW_MASK read 0
-  const int h2 = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
-  return __hiloint2double(h2, l2);
-}
-constexpr int kDppXor1 = 0xB1, kDppXor2 = 0x4E;                 // quad_perm [1,0,3,2], [2,3,0,1]
-constexpr int kDppHalfMirror = 0x141, kDppRowMirror = 0x140;   // lane i <-> 7-i within 8, i <-> 15-i within 16
-constexpr int kDppBcast15 = 0x142, kDppBcast31 = 0x143;        // lane 15 of a row -> next row; lane 31 -> rows 2, 3
+// ---- fixed-order sums of the per-lane power sums over the pixels of a group, without LDS ---------------------------
+// Every kernel adds the 64 (P = 32: 32) per-pixel values of a group in the same binary tree over the PIXEL index p:
+// pairs (p, p ^ 32), then ^ 16, ^ 8, ^ 4, ^ 2, ^ 1 - so float32 K1, uint16 K1 and the batch kernels give the same bits.
+//   float32 kernels: lane = pixel, lane distances 32, 16, 8, 4, 2, 1 (P = 32: from 16 down, per half-wave).
+//   uint16 kernels:  lanes 0..31 hold the even pixels, 32..63 the odd ones (see srf_u16_kernel): p ^ 32 is lane ^ 16,
+//                    ..., p ^ 2 is lane ^ 1 and p ^ 1 is lane ^ 32: lane distances 16, 8, 4, 2, 1, 32.
+// A wave holds N = 2 * M such values (two bands x M moments).  Reduced one by one that is N x 6 x (2 v_mov_dpp +
+// v_add_f64) = 400-500 VALU instructions per wave; a batch of small tiles reduces once per 64-pixel group, all 8
+// waves at once, and that was 37 % of the batch kernel (0.74 ms against 0.47 ms without any flush; neither fewer
+// stores nor more ILP helped: it is VALU issue).  So the tree is evaluated MERGED: after the level with lane distance D
+// only half of the lanes of a register carry a needed result (lanes l and l ^ D hold the same sum), so two registers
+// a, b are combined into one - lanes with (l & D) == 0 keep a's sums, the others b's:
+//     x = { a[l] where (l & D) == 0, b[l ^ D] elsewhere },  y = { a[l ^ D] where (l & D) == 0, b[l] elsewhere },  r = x + y
+// which is one v_add_f64 for two trees (same operands as the plain tree, addition is commutative: same bits), and
+// the register count halves level by level: 22 -> 11 -> 6 -> 3 -> 2.  x and y cost two instructions per 32-bit
+// half: v_permlane32_swap / v_permlane16_swap for D = 32 / 16 (CDNA4), a DPP row rotation whose bank mask does the
+// select for D = 8 / 4.  The last levels (D = 2, 1, and 32 for the uint16 lane order) run plain on the 2-3 registers left.
+// ~90 instructions instead of ~450.  Which lane ends up with which sum is a compile-time function of the lane bits
+// (flush_moments); the sums leave in one store instruction per remaining register.
+__device__ __forceinline__ double f64_of(int hi, int lo) { return __hiloint2double(hi, lo); }
 
-// The tree, in pixels p of the group: ((p ^ 1) pairs) -> 4 -> 8 -> 16 -> 32 (-> 64).  Every kernel reduces in this
-// tree, so float32 K1, uint16 K1 and the batch kernels give the same bits:
-//   LANE_IS_PIXEL (float32 kernels): lane = pixel.  Levels: xor 1, xor 2, half mirror, row mirror, row 1 += row 0 and
-//     row 3 += row 2 (row_bcast:15), then (P = 64) rows 2, 3 += lane 31 (row_bcast:31).  Result in lane P - 1 (+ 32k).
-//   uint16 kernels: lanes 0..31 hold the even pixels, lanes 32..63 the odd ones (see srf_u16_kernel).  Level 1 is
-//     then lane ^ 32 (v_permlane32_swap), levels 2..5 the four in-row steps, level 6 row_bcast:15.  Result in lane 63.
-template <int P, bool LANE_IS_PIXEL>
-__device__ __forceinline__ double group_sum(double v) {
-  if (LANE_IS_PIXEL) {
-    v += dpp_f64<kDppXor1, 0xf>(v);
-    v += dpp_f64<kDppXor2, 0xf>(v);
-    v += dpp_f64<kDppHalfMirror, 0xf>(v);
-    v += dpp_f64<kDppRowMirror, 0xf>(v);
-    v += dpp_f64<kDppBcast15, 0xa>(v);
-    if (P == 64) v += dpp_f64<kDppBcast31, 0xc>(v);
-  } else {
-    const int lo = __double2loint(v), hi = __double2hiint(v);
-    const auto sl = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);   // [0]: lower half in both halves, [1]: upper
-    const auto sh = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
-    v = __hiloint2double(sh[0], sl[0]) + __hiloint2double(sh[1], sl[1]);      // even pixel + odd pixel
-    v += dpp_f64<kDppXor1, 0xf>(v);
-    v += dpp_f64<kDppXor2, 0xf>(v);
-    v += dpp_f64<kDppHalfMirror, 0xf>(v);
-    v += dpp_f64<kDppRowMirror, 0xf>(v);
-    v += dpp_f64<kDppBcast15, 0xa>(v);
+template <int D>
+__device__ __forceinline__ double merge_pair(double a, double b) {
+  const int alo = __double2loint(a), ahi = __double2hiint(a), blo = __double2loint(b), bhi = __double2hiint(b);
+  if (D == 32) {        // new a = [a lanes 0..31 | b lanes 0..31], new b = [a lanes 32..63 | b lanes 32..63]
+    const auto l = __builtin_amdgcn_permlane32_swap(alo, blo, false, false);
+    const auto h = __builtin_amdgcn_permlane32_swap(ahi, bhi, false, false);
+    return f64_of(h[0], l[0]) + f64_of(h[1], l[1]);
+  } else if (D == 16) {  // new a = rows [a0 b0 a2 b2], new b = rows [a1 b1 a3 b3]
+    const auto l = __builtin_amdgcn_permlane16_swap(alo, blo, false, false);
+    const auto h = __builtin_amdgcn_permlane16_swap(ahi, bhi, false, false);
+    return f64_of(h[0], l[0]) + f64_of(h[1], l[1]);
+  } else if (D == 8) {   // row_ror:8; bank mask 0xC = lanes 8..15 of a row, 0x3 = lanes 0..7
+    const int xlo = __builtin_amdgcn_update_dpp(alo, blo, 0x128, 0xf, 0xC, false), xhi = __builtin_amdgcn_update_dpp(ahi, bhi, 0x128, 0xf, 0xC, false);
+    const int ylo = __builtin_amdgcn_update_dpp(blo, alo, 0x128, 0xf, 0x3, false), yhi = __builtin_amdgcn_update_dpp(bhi, ahi, 0x128, 0xf, 0x3, false);
+    return f64_of(xhi, xlo) + f64_of(yhi, ylo);
+  } else {               // D == 4: row_ror:4 (lane <- lane - 4) into banks 1, 3; row_ror:12 (lane <- lane + 4) into banks 0, 2
+    static_assert(D == 32 || D == 16 || D == 8 || D == 4, "merge levels");
+    const int xlo = __builtin_amdgcn_update_dpp(alo, blo, 0x124, 0xf, 0xA, false), xhi = __builtin_amdgcn_update_dpp(ahi, bhi, 0x124, 0xf, 0xA, false);
+    const int ylo = __builtin_amdgcn_update_dpp(blo, alo, 0x12C, 0xf, 0x5, false), yhi = __builtin_amdgcn_update_dpp(bhi, ahi, 0x12C, 0xf, 0x5, false);
+    return f64_of(xhi, xlo) + f64_of(yhi, ylo);
   }
-  return v;
+}
+
+// v[l] + v[l ^ D] in every lane (the levels that run on the few registers left)
+template <int D>
+__device__ __forceinline__ double plain_level(double v) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  if (D == 32) {
+    const auto l = __builtin_amdgcn_permlane32_swap(lo, lo, false, false);
+    const auto h = __builtin_amdgcn_permlane32_swap(hi, hi, false, false);
+    return f64_of(h[0], l[0]) + f64_of(h[1], l[1]);
+  }
+  static_assert(D == 32 || D == 2 || D == 1, "plain levels");
+  constexpr int ctrl = D == 2 ? 0x4E : 0xB1;   // quad_perm [2,3,0,1] / [1,0,3,2]
+  return v + f64_of(__builtin_amdgcn_update_dpp(0, hi, ctrl, 0xf, 0xf, false), __builtin_amdgcn_update_dpp(0, lo, ctrl, 0xf, 0xf, false));
+}
+
+template <int D, int NIN, int NMAX>
+__device__ __forceinline__ void merge_level(double (&v)[NMAX]) {
+  constexpr int NOUT = (NIN + 1) / 2;
+#pragma unroll
+  for (int i = 0; i < NOUT; ++i) v[i] = merge_pair<D>(v[2 * i], v[2 * i + 1 < NIN ? 2 * i + 1 : NIN - 1]);   // an odd one out merges with itself
 }
 
 // Reduce the per-lane power sums of a finished work unit, write them to its partial slot and clear them.
 template <int M, int P, bool LANE_IS_PIXEL>
 __device__ __forceinline__ void flush_moments(double (&acc_m)[2][M], const bool (&bval)[2], const int (&bidx)[2],
-                                              double* part, int slots, int lane) {
+                                              double* part, int lane) {
+  constexpr int N = 2 * M;
+  constexpr bool kTop32 = P == 64 && LANE_IS_PIXEL;       // float32, 64-pixel groups: lane distance 32 comes first
+  constexpr int N1 = kTop32 ? (N + 1) / 2 : N, N2 = (N1 + 1) / 2, N3 = (N2 + 1) / 2, N4 = (N3 + 1) / 2;
+  double v[N];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    // opaque copy of the band index: otherwise LICM hoists the 2*M row offsets (bidx*M + m) out of the batch
-    // kernels' group loop and parks them in scratch
-    int bi = bidx[j];
-    asm volatile("" : "+v"(bi));
-    double* row = part + (size_t)bi * M * slots;
+  for (int j = 0; j < 2; ++j)
 #pragma unroll
     for (int m = 0; m < M; ++m) {
-      const double sv = group_sum<P, LANE_IS_PIXEL>(acc_m[j][m]);
-      if (bval[j] && (lane % P) == P - 1) row[(size_t)m * slots] = sv;
+      v[j * M + m] = acc_m[j][m];
       acc_m[j][m] = 0.0;
-      // one moment at a time: left alone, the scheduler interleaves all 2*M trees for ILP and the batch kernels,
-      // which run this inside the group loop, spill ~150 VGPRs to scratch
-      __builtin_amdgcn_sched_barrier(0);
     }
+  if (kTop32) merge_level<32, N, N>(v);
+  merge_level<16, N1, N>(v);
+  merge_level<8, N2, N>(v);
+  merge_level<4, N3, N>(v);
+#pragma unroll
+  for (int q = 0; q < N4; ++q) {
+    v[q] = plain_level<1>(plain_level<2>(v[q]));
+    if (!LANE_IS_PIXEL) v[q] = plain_level<32>(v[q]);     // uint16 lane order: even / odd pixel halves last
+  }
+  // which sum sits in this lane of register q: undo the merges, last level first
+  const int b2 = (lane >> 2) & 1, b3 = (lane >> 3) & 1, b4 = (lane >> 4) & 1, b5 = (lane >> 5) & 1;
+  const bool canonical = (lane & 3) == 0 && (LANE_IS_PIXEL || b5 == 0);      // one writer among the lanes holding a copy
+#pragma unroll
+  for (int q = 0; q < N4; ++q) {
+    int i = 2 * q + b2;
+    bool valid = canonical && i < N3;
+    i = 2 * i + b3;
+    valid = valid && i < N2;
+    i = 2 * i + b4;
+    valid = valid && i < N1;
+    if (kTop32) {
+      i = 2 * i + b5;
+      valid = valid && i < N;
+    }
+    const bool second = i >= M;                            // i = j * M + m
+    if (valid && (second ? bval[1] : bval[0]))
+      part[(size_t)(second ? bidx[1] : bidx[0]) * M + (i - (second ? M : 0))] = v[q];   // slot-major partials: [slot][band][moment]
   }
 }
 
@@ -340,13 +382,12 @@ __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
   } else {
     cu = a.one;
     cu.slot = blockIdx.x;
-    cu.part_dev = a.one.part_dev + blockIdx.x;
+    cu.part_dev = a.one.part_dev + (size_t)blockIdx.x * a.nb * M;
   }
   int64_t nidx = (int64_t)blockIdx.x + gridDim.x;
   int g = cu.slot;
   bool pend = false;             // a finished unit's sums still sit in acc_m (batch launches)
   double* pend_part = nullptr;
-  int pend_slots = 0;
 
   for (bool more = true; more;) {
     const int64_t pix0 = (int64_t)g * P;
@@ -394,10 +435,12 @@ __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
       if (BATCH && wave == 0 && lane < 16)
         __builtin_amdgcn_global_load_lds((gptr_t)unit_record_addr(a.units, nidx, a.nunits, lane), (lptr_t)ustage, 4, 0, 0);
       if (OUTV) flush_stage<8 * P>(ostage, prev_out, prev_pix0, prev_npx, ops, t);   // no-op before the first group
+#ifndef HSR_EXP_NOFLUSH   /* diagnostic builds (tools/dbg): timing of the loop without the per-unit flush */
       if (BATCH && DEG > 0 && pend) {
-        flush_moments<M, P, true>(acc_m, bval, bidx, pend_part, pend_slots, lane);
+        flush_moments<M, P, true>(acc_m, bval, bidx, pend_part, lane);
         pend = false;
       }
+#endif
     };
 
     HSR_STAMP(st0);
@@ -484,7 +527,11 @@ __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
         // issued together, then a 16-deep fma chain: no serial remainder loop.
         // (batch kernels read 8 taps at a time: the unit bookkeeping needs the registers, and 16 + 16 operands in
         // flight pushed a dozen loop invariants of the hot path into scratch; same taps, same order, same bits)
+#ifdef HSR_EXP_CH16
+        constexpr int CH = kTapChunk;
+#else
         constexpr int CH = BATCH ? kTapChunk / 2 : kTapChunk;
+#endif
         const float4* w4 = reinterpret_cast<const float4*>(wl + bwo[j]);
         for (int i0 = 0; i0 < bkl[j]; i0 += CH) {
           float4 ww[CH / 4];
@@ -550,7 +597,6 @@ __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
     if (g >= cu.ngroups) {
       pend = true;
       pend_part = cu.part_dev;
-      pend_slots = cu.slots;
       if (BATCH && nidx < a.nunits) {
         cu = unit_from_lds(ustage);     // landed before the barrier that published this group
         g = cu.slot;
@@ -575,7 +621,7 @@ __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
   if (a.stamps && lane == 0)
     for (int k = 0; k < 8; ++k) a.stamps[((size_t)blockIdx.x * NW + wave) * 8 + k] = stamp_acc[k];
 #endif
-  if (DEG > 0 && pend) flush_moments<M, P, true>(acc_m, bval, bidx, pend_part, pend_slots, lane);
+  if (DEG > 0 && pend) flush_moments<M, P, true>(acc_m, bval, bidx, pend_part, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -727,13 +773,12 @@ __global__ __launch_bounds__(512, 4) void srf_u16_kernel(const SrfArgs a) {
   } else {
     cu = a.one;
     cu.slot = blockIdx.x;
-    cu.part_dev = a.one.part_dev + blockIdx.x;
+    cu.part_dev = a.one.part_dev + (size_t)blockIdx.x * a.nb * M;
   }
   int64_t nidx = (int64_t)blockIdx.x + gridDim.x;
   int g = cu.slot;
   bool pend = false;
   double* pend_part = nullptr;
-  int pend_slots = 0;
 
   for (bool more = true; more;) {
     const int64_t pix0 = (int64_t)g * P;
@@ -769,7 +814,7 @@ __global__ __launch_bounds__(512, 4) void srf_u16_kernel(const SrfArgs a) {
         __builtin_amdgcn_global_load_lds((gptr_t)unit_record_addr(a.units, nidx, a.nunits, lane), (lptr_t)ustage, 4, 0, 0);
       if (OUTV) flush_stage<T>(ostage, prev_out, prev_pix0, prev_npx, ops, t);
       if (BATCH && DEG > 0 && pend) {
-        flush_moments<M, P, false>(acc_m, bval, bidx, pend_part, pend_slots, lane);
+        flush_moments<M, P, false>(acc_m, bval, bidx, pend_part, lane);
         pend = false;
       }
     };
@@ -830,7 +875,6 @@ __global__ __launch_bounds__(512, 4) void srf_u16_kernel(const SrfArgs a) {
     if (g >= cu.ngroups) {
       pend = true;
       pend_part = cu.part_dev;
-      pend_slots = cu.slots;
       if (BATCH && nidx < a.nunits) {
         cu = unit_from_lds(ustage);
         g = cu.slot;
@@ -842,7 +886,7 @@ __global__ __launch_bounds__(512, 4) void srf_u16_kernel(const SrfArgs a) {
     lds_barrier();
   }
   if (OUTV) flush_stage<T>(ostage, prev_out, prev_pix0, prev_npx, ops, t);
-  if (DEG > 0 && pend) flush_moments<M, P, false>(acc_m, bval, bidx, pend_part, pend_slots, lane);
+  if (DEG > 0 && pend) flush_moments<M, P, false>(acc_m, bval, bidx, pend_part, lane);
 }
 
 // LDS-DMA issued from inline asm: the compiler's waitcnt pass then does not know a DMA is pending and does
@@ -931,12 +975,15 @@ __global__ __launch_bounds__(512, 4) void srf_u16_ring_kernel(const SrfArgs a) {
       }
     }
     if (DEG > 0) {
+      // The targets are ORDINARY loads here: yn / mn live across the loop back-edge, and an inline-asm load into a
+      // loop-carried register can be copied by the compiler (phi of the prologue's and the loop's prefetch) before the
+      // data has landed - seen as moments that changed from launch to launch in the batch kernel.  Ordinary loads
+      // cost nothing in this kernel: its LDS-DMA is inline asm, so the compiler has no DMA to drain for (the
+      // float32 kernel, whose DMA is the builtin, must keep asm loads, but consumes them in the same iteration).
       const int64_t pc = pl < left ? pix0 + pl : u.npix - 1;
 #pragma unroll
-      for (int j = 0; j < kBandSlots; ++j) yn[j] = load_f32_async(u.real_dev + bidx[j] * a.real_bs + pc * a.real_ps);
-      // unconditional load + select after the wait in batch launches (srf_kernel explains)
-      if (BATCH) mn = load_u8_async(u.mask_dev != nullptr ? u.mask_dev + pc : reinterpret_cast<const uint8_t*>(u.real_dev));
-      else if (u.mask_dev != nullptr) mn = load_u8_async(u.mask_dev + pc);
+      for (int j = 0; j < kBandSlots; ++j) yn[j] = u.real_dev[bidx[j] * a.real_bs + pc * a.real_ps];
+      mn = u.mask_dev != nullptr ? (uint32_t)u.mask_dev[pc] : 1u;
     }
   };
 
@@ -946,7 +993,7 @@ __global__ __launch_bounds__(512, 4) void srf_u16_ring_kernel(const SrfArgs a) {
   } else {
     cu = a.one;
     cu.slot = blockIdx.x;
-    cu.part_dev = a.one.part_dev + blockIdx.x;
+    cu.part_dev = a.one.part_dev + (size_t)blockIdx.x * a.nb * M;
   }
   int g = cu.slot;
   prefetch(cu, g, 0);
@@ -965,7 +1012,6 @@ __global__ __launch_bounds__(512, 4) void srf_u16_ring_kernel(const SrfArgs a) {
   int prev_npx = 0;
   bool pend = false;
   double* pend_part = nullptr;
-  int pend_slots = 0;
 
   for (bool more = true; more; cur ^= 1) {
     const int64_t pix0 = (int64_t)g * P;
@@ -980,12 +1026,10 @@ __global__ __launch_bounds__(512, 4) void srf_u16_ring_kernel(const SrfArgs a) {
     // everything this wave issued one iteration ago has landed: group k, its targets, the flush of group k-2
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     float yv[kBandSlots];
-    uint32_t mraw;
-    static_assert(kBandSlots == 2, "pin list below");
-    asm volatile("" : "+v"(yn[0]), "+v"(yn[1]), "+v"(mn));
+    static_assert(kBandSlots == 2, "two target registers");
     yv[0] = yn[0];
     yv[1] = yn[1];
-    mraw = (BATCH && cu.mask_dev == nullptr) ? 1u : mn;
+    const uint32_t mraw = mn;
     if (npx < P) {  // ragged last group: plain copy, tail of the last chunk zeroed
       const uint16_t* src = reinterpret_cast<const uint16_t*>(cu.cube_dev) + pix0 * B;
       const int n = npx * B;
@@ -1012,7 +1056,7 @@ __global__ __launch_bounds__(512, 4) void srf_u16_ring_kernel(const SrfArgs a) {
     fetch_record(next_unit ? nidx + gridDim.x : nidx, cur ^ 1);
     if (OUTV) flush_stage<T>(ostage, prev_out, prev_pix0, prev_npx, ops, t);
     if (BATCH && DEG > 0 && pend) {
-      flush_moments<M, P, false>(acc_m, bval, bidx, pend_part, pend_slots, lane);
+      flush_moments<M, P, false>(acc_m, bval, bidx, pend_part, lane);
       pend = false;
     }
 
@@ -1050,7 +1094,6 @@ __global__ __launch_bounds__(512, 4) void srf_u16_ring_kernel(const SrfArgs a) {
     } else {
       pend = true;
       pend_part = cu.part_dev;
-      pend_slots = cu.slots;
       if (next_unit) {
         cu = unit_from_lds(ustage + 16 * cur);   // decoded again rather than held in 15 SGPRs across the dot products
         g = cu.slot;
@@ -1064,7 +1107,7 @@ __global__ __launch_bounds__(512, 4) void srf_u16_ring_kernel(const SrfArgs a) {
     __syncthreads();
     flush_stage<T>(ostage, prev_out, prev_pix0, prev_npx, ops, t);
   }
-  if (DEG > 0 && pend) flush_moments<M, P, false>(acc_m, bval, bidx, pend_part, pend_slots, lane);
+  if (DEG > 0 && pend) flush_moments<M, P, false>(acc_m, bval, bidx, pend_part, lane);
 }
 
 template <typename K>
@@ -1460,7 +1503,7 @@ extern "C" int hsr_batch_plan(hsr_batch_tile* tiles, int32_t ntiles, int32_t nb,
         u.real_dev = tl.real_dev;
         u.mask_dev = tl.mask_dev;
         u.pseudo_dev = tl.pseudo_dev;
-        u.part_dev = partials_dev ? partials_dev + (size_t)tl.slot0 * nb * M + s : nullptr;
+        u.part_dev = partials_dev ? partials_dev + ((size_t)tl.slot0 + s) * nb * M : nullptr;
         u.npix = tl.npix;
         u.slots = tl.slots;
         u.slot = s;

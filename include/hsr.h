@@ -98,7 +98,7 @@ int hsr_srf_integrate(const float* cube_dev, int64_t npix, int32_t B,
  * calibrate_pseudo_to_real_linear, Pairs_EMIT_S2_demo-2.ipynb cell 72 raw lines 4484-4510):
  * pixel p counts for band b iff mask[p] (if given) && finite(x) && finite(y) && x > min_x && y > min_y,
  * with x = out[b][p] (float32) and y = real_dev[b * real_bs + p * real_ps]; sums are float64.
- *   partials_dev  workspace of hsr_partials_bytes(nb, deg); slot layout [nb][3deg+2][slots]
+ *   partials_dev  workspace of hsr_partials_bytes(nb, deg); layout [slot][nb][3deg+2] (a slot is whole cache lines)
  *   returns the slot count used in *slots_out (= hsr_partial_slots(npix, opts)).
  */
 int hsr_srf_integrate_moments(const float* cube_dev, int64_t npix, int32_t B,
@@ -242,7 +242,7 @@ typedef struct hsr_batch_unit {       /* 64 bytes, written by hsr_batch_plan, re
   const float* real_dev;
   const uint8_t* mask_dev;
   float* pseudo_dev;
-  double* part_dev;                   /* &partials of the tile [slot]; element (band b, moment m) at [(b*M+m)*slots] */
+  double* part_dev;                   /* partials of (tile, slot): nb * M doubles, (band b, moment m) at [b*M+m]   */
   int64_t npix;
   int32_t slots, slot, ngroups, reserved;
 } hsr_batch_unit;

@@ -122,7 +122,7 @@ def test_batch_plan_host_side():
         assert (int(r["npix"]), int(r["slots"]), int(r["ngroups"])) == (npix[t], slots[t], tiles[t].ngroups)
         assert 0 <= r["slot"] < slots[t] and (t, int(r["slot"])) not in seen
         seen.add((t, int(r["slot"])))
-        assert int(r["part"]) == base + 8 * (int(tiles[t].slot0) * nb * M + int(r["slot"]))
+        assert int(r["part"]) == base + 8 * (int(tiles[t].slot0) + int(r["slot"])) * nb * M      # slot-major partials
         lens.append((tiles[t].ngroups - int(r["slot"]) + slots[t] - 1) // slots[t])
     assert len(seen) == n and lens == sorted(lens, reverse=True) and lens[0] == 32 and lens[-1] == 1
     # options: reserved CUs shrink the slot cap of the big tile only

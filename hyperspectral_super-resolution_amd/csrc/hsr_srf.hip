@@ -89,7 +89,11 @@ __device__ __forceinline__ unsigned long long phase_stamp() {
 constexpr int kGroups = 8;                          // band groups per workgroup (band = group + 8 * slot)
 constexpr int kBandSlots = HSR_MAX_BANDS / kGroups;  // 2 bands per thread
 constexpr int kTapChunk = 16;                       // taps per unrolled dot-product chunk
-constexpr int kScanBatch = 5;                       // ds_read_b128 in flight per thread in the sweep
+constexpr int kScanBatch = 5;                       // ds_read_b128 in flight per thread in the uint16 sweep
+#ifndef HSR_F32_SCAN_BATCH
+#define HSR_F32_SCAN_BATCH 5
+#endif
+constexpr int kScanBatchF32 = HSR_F32_SCAN_BATCH;   // ... in the float32 sweep
 
 // Tile geometry: P pixels per LDS tile, 8*P threads per workgroup.
 //   P = 64: 512 threads (8 waves), lane = pixel, wave = band group;      2 workgroups per CU
@@ -467,23 +471,23 @@ __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
     wait_targets();
     HSR_STAMP(st2);
     if (fast_group) {
-      // non-finite sweep: kScanBatch independent ds_read_b128 in flight per thread (a serial
+      // non-finite sweep: kScanBatchF32 independent ds_read_b128 in flight per thread (a serial
       // read->wait->test loop cost 3.7k cycles per group; batched it is LDS-bandwidth bound).
       // Indices past the group are clamped to its last chunk (a harmless re-read, no predication).
       const float4* t4 = reinterpret_cast<const float4*>(smem);
-      for (int c0 = t; c0 < nchunk; c0 += T * kScanBatch) {
-        float4 v[kScanBatch];
+      for (int c0 = t; c0 < nchunk; c0 += T * kScanBatchF32) {
+        float4 v[kScanBatchF32];
 #pragma unroll
-        for (int u = 0; u < kScanBatch; ++u) {
+        for (int u = 0; u < kScanBatchF32; ++u) {
           const int c = c0 + u * T;
           v[u] = t4[c < nchunk ? c : nchunk - 1];
         }
         bool bad = false;
 #pragma unroll
-        for (int u = 0; u < kScanBatch; ++u) bad |= any_nonfinite4(v[u]);
+        for (int u = 0; u < kScanBatchF32; ++u) bad |= any_nonfinite4(v[u]);
         if (bad) {  // rare
 #pragma unroll
-          for (int u = 0; u < kScanBatch; ++u) {
+          for (int u = 0; u < kScanBatchF32; ++u) {
             const int c = c0 + u * T;
             const int e = (c < nchunk ? c : nchunk - 1) * 4;
             if (!finite_f32(v[u].x)) flags[(e + 0) / B] = 1u;

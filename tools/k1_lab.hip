@@ -504,17 +504,17 @@ int main(int argc, char** argv) {
   SETLDS((k_ring<512, 2>), ring_bytes()); SETLDS((k_ring<1024, 4>), ring_bytes());
   add("ring P64x2 T512 1/CU g256", [&] { hipLaunchKernelGGL((k_ring<512, 2>), dim3(256), dim3(512), ring_bytes(), 0, d_cube, npix, d_wn, bands, nb, d_planes, stride); }, true);
   add("ring P64x2 T1024 1/CU g256", [&] { hipLaunchKernelGGL((k_ring<1024, 4>), dim3(256), dim3(1024), ring_bytes(), 0, d_cube, npix, d_wn, bands, nb, d_planes, stride); }, true);
-  add("LIB K1 PIXMAJOR out", [&] { if (hsr_srf_integrate(d_cube, npix, B, d_wn, raw.k0, raw.klen, nb, d_planes, 1, 12, 0)) { printf("%s\n", hsr_last_error()); exit(1);} }, false);
-  add("LIB K1+K2 deg3 PIXMAJOR in/out", [&] { if (hsr_srf_integrate_moments(d_cube, npix, B, d_wn, raw.k0, raw.klen, nb, d_planes, 1, 12, d_real, 1, 12, nullptr, 0.f, 0.f, 3, d_part, &slots, 0)) { printf("%s\n", hsr_last_error()); exit(1);} }, false);
-  add("LIB K1+K2 deg3 PIXMAJOR out, PLANAR real", [&] { if (hsr_srf_integrate_moments(d_cube, npix, B, d_wn, raw.k0, raw.klen, nb, d_planes, 1, 12, d_real, npix, 1, nullptr, 0.f, 0.f, 3, d_part, &slots, 0)) { printf("%s\n", hsr_last_error()); exit(1);} }, false);
-  add("LIB K1 tile32 PIXMAJOR out", [&] { hsr_set_srf_tile(32); if (hsr_srf_integrate(d_cube, npix, B, d_wn, raw.k0, raw.klen, nb, d_planes, 1, 12, 0)) { printf("%s\n", hsr_last_error()); exit(1);} hsr_set_srf_tile(64); }, false);
-  add("LIB K1+K2 deg3 tile32 PIXMAJOR", [&] { hsr_set_srf_tile(32); if (hsr_srf_integrate_moments(d_cube, npix, B, d_wn, raw.k0, raw.klen, nb, d_planes, 1, 12, d_real, 1, 12, nullptr, 0.f, 0.f, 3, d_part, &slots, 0)) { printf("%s\n", hsr_last_error()); exit(1);} hsr_set_srf_tile(64); }, false);
-  add("LIB K1 tile32", [&] { hsr_set_srf_tile(32); if (hsr_srf_integrate(d_cube, npix, B, d_wn, raw.k0, raw.klen, nb, d_planes, stride, 1, 0)) { printf("%s\n", hsr_last_error()); exit(1);} hsr_set_srf_tile(64); }, true);
-  add("LIB K1+K2 deg3 tile32", [&] { hsr_set_srf_tile(32); if (hsr_srf_integrate_moments(d_cube, npix, B, d_wn, raw.k0, raw.klen, nb, d_planes, stride, 1, d_real, npix, 1, nullptr, 0.f, 0.f, 3, d_part, &slots, 0)) { printf("%s\n", hsr_last_error()); exit(1);} hsr_set_srf_tile(64); }, true);
-  add("LIB hsr_srf_integrate (K1)", [&] { if (hsr_srf_integrate(d_cube, npix, B, d_wn, raw.k0, raw.klen, nb, d_planes, stride, 1, 0)) { printf("%s\n", hsr_last_error()); exit(1);} }, true);
+  add("LIB K1 PIXMAJOR out", [&] { if (hsr_srf_integrate(d_cube, npix, B, d_wn, raw.k0, raw.klen, nb, d_planes, 1, 12, nullptr, 0)) { printf("%s\n", hsr_last_error()); exit(1);} }, false);
+  add("LIB K1+K2 deg3 PIXMAJOR in/out", [&] { if (hsr_srf_integrate_moments(d_cube, npix, B, d_wn, raw.k0, raw.klen, nb, d_planes, 1, 12, d_real, 1, 12, nullptr, 0.f, 0.f, 3, d_part, &slots, nullptr, 0)) { printf("%s\n", hsr_last_error()); exit(1);} }, false);
+  add("LIB K1+K2 deg3 PIXMAJOR out, PLANAR real", [&] { if (hsr_srf_integrate_moments(d_cube, npix, B, d_wn, raw.k0, raw.klen, nb, d_planes, 1, 12, d_real, npix, 1, nullptr, 0.f, 0.f, 3, d_part, &slots, nullptr, 0)) { printf("%s\n", hsr_last_error()); exit(1);} }, false);
+  add("LIB K1 tile32 PIXMAJOR out", [&] { hsr_srf_options o32 = {32, 0, 0, 0}; if (hsr_srf_integrate(d_cube, npix, B, d_wn, raw.k0, raw.klen, nb, d_planes, 1, 12, &o32, 0)) { printf("%s\n", hsr_last_error()); exit(1);} }, false);
+  add("LIB K1+K2 deg3 tile32 PIXMAJOR", [&] { hsr_srf_options o32 = {32, 0, 0, 0}; if (hsr_srf_integrate_moments(d_cube, npix, B, d_wn, raw.k0, raw.klen, nb, d_planes, 1, 12, d_real, 1, 12, nullptr, 0.f, 0.f, 3, d_part, &slots, &o32, 0)) { printf("%s\n", hsr_last_error()); exit(1);} }, false);
+  add("LIB K1 tile32", [&] { hsr_srf_options o32 = {32, 0, 0, 0}; if (hsr_srf_integrate(d_cube, npix, B, d_wn, raw.k0, raw.klen, nb, d_planes, stride, 1, &o32, 0)) { printf("%s\n", hsr_last_error()); exit(1);} }, true);
+  add("LIB K1+K2 deg3 tile32", [&] { hsr_srf_options o32 = {32, 0, 0, 0}; if (hsr_srf_integrate_moments(d_cube, npix, B, d_wn, raw.k0, raw.klen, nb, d_planes, stride, 1, d_real, npix, 1, nullptr, 0.f, 0.f, 3, d_part, &slots, &o32, 0)) { printf("%s\n", hsr_last_error()); exit(1);} }, true);
+  add("LIB hsr_srf_integrate (K1)", [&] { if (hsr_srf_integrate(d_cube, npix, B, d_wn, raw.k0, raw.klen, nb, d_planes, stride, 1, nullptr, 0)) { printf("%s\n", hsr_last_error()); exit(1);} }, true);
   for (int deg = 1; deg <= 4; ++deg) {
     static char names[5][64]; snprintf(names[deg], 64, "LIB hsr_srf_integrate_moments deg%d", deg);
-    add(names[deg], [&, deg] { if (hsr_srf_integrate_moments(d_cube, npix, B, d_wn, raw.k0, raw.klen, nb, d_planes, stride, 1, d_real, npix, 1, nullptr, 0.f, 0.f, deg, d_part, &slots, 0)) { printf("%s\n", hsr_last_error()); exit(1);} }, true);
+    add(names[deg], [&, deg] { if (hsr_srf_integrate_moments(d_cube, npix, B, d_wn, raw.k0, raw.klen, nb, d_planes, stride, 1, d_real, npix, 1, nullptr, 0.f, 0.f, deg, d_part, &slots, nullptr, 0)) { printf("%s\n", hsr_last_error()); exit(1);} }, true);
   }
   const int64_t n16 = npix * B / 4;
   add("read probe unroll4 g2048", [&] { hipLaunchKernelGGL((k_read<4>), dim3(2048), dim3(256), 0, 0, (const float4*)d_cube, n16, d_sink); }, false);

@@ -15,7 +15,7 @@ int main(int argc, char** argv) {
   const int H = argc > 1 ? atoi(argv[1]) : 1024, W = argc > 2 ? atoi(argv[2]) : 1024, B = 285, nb = 12;
   const int64_t npix = (int64_t)H * W;
   const int tilepx = argc > 3 ? atoi(argv[3]) : 64;
-  if (hsr_set_srf_tile(tilepx)) { printf("%s\n", hsr_last_error()); return 1; }
+  hsr_srf_options opts = {tilepx, 0, 0, 0};
   printf("tile pixels %d\n", tilepx);
   std::vector<float> wn((size_t)nb * B, 0.f);
   int k0[16], klen[16];
@@ -42,8 +42,8 @@ int main(int argc, char** argv) {
     CK(hipMemset(d_st, 0, stn * 8));
     int slots = 0;
     for (int rep = 0; rep < 3; ++rep) {
-      int rc = deg == 0 ? hsr_srf_integrate(d_cube, npix, B, d_wn, k0, klen, nb, d_planes, 1, 12, 0)
-                        : hsr_srf_integrate_moments(d_cube, npix, B, d_wn, k0, klen, nb, d_planes, 1, 12, d_real, 1, 12, nullptr, 0.f, 0.f, deg, d_part, &slots, 0);
+      int rc = deg == 0 ? hsr_srf_integrate(d_cube, npix, B, d_wn, k0, klen, nb, d_planes, 1, 12, &opts, 0)
+                        : hsr_srf_integrate_moments(d_cube, npix, B, d_wn, k0, klen, nb, d_planes, 1, 12, d_real, 1, 12, nullptr, 0.f, 0.f, deg, d_part, &slots, &opts, 0);
       if (rc) { printf("error: %s\n", hsr_last_error()); return 1; }
     }
     CK(hipDeviceSynchronize());

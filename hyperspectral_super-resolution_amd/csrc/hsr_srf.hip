@@ -95,16 +95,14 @@ constexpr int kScanBatch = 5;                       // ds_read_b128 in flight pe
 #endif
 constexpr int kScanBatchF32 = HSR_F32_SCAN_BATCH;   // ... in the float32 sweep
 
-// Tile geometry: P pixels per LDS tile, 8*P threads per workgroup.
-//   P = 64: 512 threads (8 waves), lane = pixel, wave = band group;      2 workgroups per CU
-//   P = 32: 256 threads (4 waves), lane&31 = pixel, each wave half = one band group; 4 per CU
-// (Measured and dropped: P = 8, one-wave workgroups with wave-local barriers, ~14 per CU: 0.2535 ms; P = 128,
-//  one 1024-thread workgroup per CU: 0.234 ms; P = 64: 0.2133 ms on the same box.)
-// Both keep 16 waves (4 per SIMD, <= 128 VGPRs) and ~146 KB of LDS tiles per CU; the smaller tile
-// gives the CU's memory pipe four queued customers instead of two (see DESIGN.md, K1 tuning).
+// Group geometry: P = 64 pixels per LDS group, 512 threads (8 waves), lane = pixel, wave = band group; 2 workgroups
+// per CU: 16 waves (4 per SIMD, <= 128 VGPRs) and ~146 KB of LDS groups per CU.
+// (Measured and dropped: P = 8, one-wave workgroups with wave-local barriers, ~14 per CU: 0.2535 ms; P = 128, one
+//  1024-thread workgroup per CU: 0.234 ms; P = 32, 256 threads x 4 per CU: 3-8 % slower, and its per-half-wave band
+//  groups kept the band parameters in VGPRs; P = 64: 0.2133 ms on the same box.)
 // The geometry comes with every call (hsr_srf_options); the library keeps no tuning state.
 struct SrfTuning {
-  int tile_pixels;    // 64 or 32
+  int tile_pixels;    // 64
   int reserved_cus;   // CUs left without a persistent K1 workgroup (side-stream kernels of the previous tile's fit)
   bool u16_ring;      // uint16 cubes: double-buffered kernel where it fits
 };
@@ -114,8 +112,9 @@ static int srf_tuning(const hsr_srf_options* o, SrfTuning* t, const char* who) {
   t->reserved_cus = 0;
   t->u16_ring = true;
   if (o == nullptr) return HSR_OK;
-  HSR_REQUIRE(o->tile_pixels == 0 || o->tile_pixels == 64 || o->tile_pixels == 32, HSR_ERR_INVALID,
-              "%s: options.tile_pixels must be 0 (default), 64 or 32, got %d", who, o->tile_pixels);
+  HSR_REQUIRE(o->tile_pixels == 0 || o->tile_pixels == 64, HSR_ERR_INVALID,
+              "%s: options.tile_pixels must be 0 (default) or 64, got %d (the 32-pixel geometry of round 1 measured 3-8 %% "
+              "slower and was removed)", who, o->tile_pixels);
   HSR_REQUIRE(o->reserved_cus >= 0 && o->reserved_cus <= 128, HSR_ERR_INVALID, "%s: options.reserved_cus=%d outside [0,128]",
               who, o->reserved_cus);
   HSR_REQUIRE(o->reserved == 0, HSR_ERR_INVALID, "%s: options.reserved must be 0", who);
@@ -201,9 +200,9 @@ __device__ __forceinline__ void flush_stage(const float* ostage, float* out, int
 }
 
 // ---- fixed-order sums of the per-lane power sums over the pixels of a group, without LDS ---------------------------
-// Every kernel adds the 64 (P = 32: 32) per-pixel values of a group in the same binary tree over the PIXEL index p:
+// Every kernel adds the 64 per-pixel values of a group in the same binary tree over the PIXEL index p:
 // pairs (p, p ^ 32), then ^ 16, ^ 8, ^ 4, ^ 2, ^ 1 - so float32 K1, uint16 K1 and the batch kernels give the same bits.
-//   float32 kernels: lane = pixel, lane distances 32, 16, 8, 4, 2, 1 (P = 32: from 16 down, per half-wave).
+//   float32 kernels: lane = pixel, lane distances 32, 16, 8, 4, 2, 1.
 //   uint16 kernels:  lanes 0..31 hold the even pixels, 32..63 the odd ones (see srf_u16_kernel): p ^ 32 is lane ^ 16,
 //                    ..., p ^ 2 is lane ^ 1 and p ^ 1 is lane ^ 32: lane distances 16, 8, 4, 2, 1, 32.
 // A wave holds N = 2 * M such values (two bands x M moments).  Reduced one by one that is N x 6 x (2 v_mov_dpp +
@@ -340,7 +339,7 @@ __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
   const int lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int pl = t % P;     // pixel of this thread inside the group
-  const int grp = t / P;    // band group 0..7 (wave-uniform for P = 64, per half-wave for P = 32)
+  const int grp = wave;     // band group 0..7: wave-uniform, so the band parameters below live in SGPRs (-20 VGPRs)
   const int nchunk = P * B / 4;  // 16-byte chunks of a full group (P is a multiple of 4)
 
   // the (at most two) bands of this thread, fixed for the whole launch
@@ -439,12 +438,10 @@ __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
       if (BATCH && wave == 0 && lane < 16)
         __builtin_amdgcn_global_load_lds((gptr_t)unit_record_addr(a.units, nidx, a.nunits, lane), (lptr_t)ustage, 4, 0, 0);
       if (OUTV) flush_stage<8 * P>(ostage, prev_out, prev_pix0, prev_npx, ops, t);   // no-op before the first group
-#ifndef HSR_EXP_NOFLUSH   /* diagnostic builds (tools/dbg): timing of the loop without the per-unit flush */
       if (BATCH && DEG > 0 && pend) {
         flush_moments<M, P, true>(acc_m, bval, bidx, pend_part, lane);
         pend = false;
       }
-#endif
     };
 
     HSR_STAMP(st0);
@@ -529,13 +526,9 @@ __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
         // so the sum is bit-identical to the exact-support sum.  One chunk = 4 broadcast
         // ds_read_b128 (weights) + 16 ds_read_b32 (samples, stride ldsB words: conflict-free)
         // issued together, then a 16-deep fma chain: no serial remainder loop.
-        // (batch kernels read 8 taps at a time: the unit bookkeeping needs the registers, and 16 + 16 operands in
-        // flight pushed a dozen loop invariants of the hot path into scratch; same taps, same order, same bits)
-#ifdef HSR_EXP_CH16
-        constexpr int CH = kTapChunk;
-#else
-        constexpr int CH = BATCH ? kTapChunk / 2 : kTapChunk;
-#endif
+        // (8 taps are read at a time although the supports are padded to 16: 16 + 16 operands in flight cost registers
+        // and measured no faster - A/B on one box, 0.2165 vs 0.2162 ms; same taps, same order, same bits)
+        constexpr int CH = kTapChunk / 2;
         const float4* w4 = reinterpret_cast<const float4*>(wl + bwo[j]);
         for (int i0 = 0; i0 < bkl[j]; i0 += CH) {
           float4 ww[CH / 4];
@@ -1324,7 +1317,7 @@ static int srf_common(SrfArgs& a, const int32_t* k0, const int32_t* klen, int32_
   const bool aligned = (((uintptr_t)a.one.cube_dev) & 15) == 0;
   if (a.u16) return dispatch_u16(a, deg, aligned, tn.u16_ring, a.one.slots, stream);
   const bool fast = (a.B & 1) && aligned;
-  return P == 64 ? dispatch_deg<64>(a, deg, fast, a.one.slots, stream) : dispatch_deg<32>(a, deg, fast, a.one.slots, stream);
+  return dispatch_deg<64>(a, deg, fast, a.one.slots, stream);
 }
 
 }  // namespace hsr

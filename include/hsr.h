@@ -52,8 +52,8 @@ typedef void* hsr_stream_t;
 /* Per-call tuning of the K1 launches (NULL = defaults).  There is no process-wide tuning state: two plans in one
  * process cannot interfere, and a call's partial-slot layout is a function of (npix, *opts) only. */
 typedef struct hsr_srf_options {
-  int32_t tile_pixels;        /* LDS tile of the float32 K1: 0 = default (64): 64 -> 512-thread workgroups, 2 per CU;
-                                 32 -> 256-thread workgroups, 4 per CU.  uint16 cubes and batches always use 64. */
+  int32_t tile_pixels;        /* pixels per LDS group of K1: 0 = default, or 64 (512-thread workgroups, 2 per CU) - the
+                                 only geometry left; the field stays for ABI stability */
   int32_t reserved_cus;       /* CUs left without a persistent K1 workgroup (default 0, at most 128): lets the small
                                  kernels of the previous tile's fit (slot reduction, RCCL exchange, solve) run on another
                                  stream while K1 streams the next tile. */

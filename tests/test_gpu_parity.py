@@ -112,9 +112,9 @@ def test_k1_vs_oracle_shapes(torch_gpu, H, W, B, offset):
     assert pm.shape == (H * W, eng.padded_row(table.nb))
     assert torch.equal(pm[:, :table.nb].t().contiguous().view(torch.int32),
                        torch.from_numpy(planes.reshape(table.nb, -1)).cuda().view(torch.int32))
-    for tile in (32, 64):      # both tile geometries: a per-call option, no process-wide state to restore
-        p2 = eng.srf_integrate(cube, table, opts=eng.srf_options(tile_pixels=tile)).cpu().numpy().reshape(table.nb, H, W)
-        assert np.array_equal(p2.view(np.int32), planes.view(np.int32))
+    # launch options travel with the call (no process-wide state to restore): reserved CUs change the grid, not the planes
+    p2 = eng.srf_integrate(cube, table, opts=eng.srf_options(tile_pixels=64, reserved_cus=8)).cpu().numpy().reshape(table.nb, H, W)
+    assert np.array_equal(p2.view(np.int32), planes.view(np.int32))
 
 
 def test_k1_torch_input_zero_copy_and_many_bands(torch_gpu):
@@ -847,7 +847,7 @@ def test_k1_spectral_size_sweep(torch_gpu, B):
         return
     cube = torch.from_numpy(R).cuda()
     base = None
-    for tile in (64, 32):
+    for tile in (64, 0):
         o = eng.srf_options(tile_pixels=tile)
         pl = eng.srf_integrate(cube, table, layout=nat.PLANAR, opts=o)
         pm = eng.srf_integrate(cube, table, layout=nat.PIXMAJOR, opts=o)

@@ -42,8 +42,9 @@ def test_sizing_helpers_and_error_strings():
     assert lib.hsr_partial_slots(1, None) == 1 and lib.hsr_partial_slots(64, None) == 1 and lib.hsr_partial_slots(65, None) == 2
     assert lib.hsr_partial_slots(1 << 20, None) == 512 and lib.hsr_partial_slots(1 << 30, None) == 512
     # the slot layout is a function of (npix, options) only: no process-wide tuning state exists any more
-    o = nat.SrfOptions(32, 0, 0, 0)
-    assert lib.hsr_partial_slots(65, ctypes.byref(o)) == 3 and lib.hsr_partial_slots(1 << 20, ctypes.byref(o)) == 1024
+    o = nat.SrfOptions(64, 0, 0, 0)
+    assert lib.hsr_partial_slots(65, ctypes.byref(o)) == 2 and lib.hsr_partial_slots(1 << 20, ctypes.byref(o)) == 512
+    assert lib.hsr_partial_slots(65, ctypes.byref(nat.SrfOptions(32, 0, 0, 0))) == -1        # 32-pixel geometry removed
     o = nat.SrfOptions(0, 8, 0, 0)
     assert lib.hsr_partial_slots(1 << 20, ctypes.byref(o)) == 496 and lib.hsr_partial_slots(1 << 20, None) == 512
     assert lib.hsr_partial_slots(100, ctypes.byref(nat.SrfOptions(48, 0, 0, 0))) == -1 and b"tile_pixels" in lib.hsr_last_error()

@@ -507,10 +507,6 @@ int main(int argc, char** argv) {
   add("LIB K1 PIXMAJOR out", [&] { if (hsr_srf_integrate(d_cube, npix, B, d_wn, raw.k0, raw.klen, nb, d_planes, 1, 12, nullptr, 0)) { printf("%s\n", hsr_last_error()); exit(1);} }, false);
   add("LIB K1+K2 deg3 PIXMAJOR in/out", [&] { if (hsr_srf_integrate_moments(d_cube, npix, B, d_wn, raw.k0, raw.klen, nb, d_planes, 1, 12, d_real, 1, 12, nullptr, 0.f, 0.f, 3, d_part, &slots, nullptr, 0)) { printf("%s\n", hsr_last_error()); exit(1);} }, false);
   add("LIB K1+K2 deg3 PIXMAJOR out, PLANAR real", [&] { if (hsr_srf_integrate_moments(d_cube, npix, B, d_wn, raw.k0, raw.klen, nb, d_planes, 1, 12, d_real, npix, 1, nullptr, 0.f, 0.f, 3, d_part, &slots, nullptr, 0)) { printf("%s\n", hsr_last_error()); exit(1);} }, false);
-  add("LIB K1 tile32 PIXMAJOR out", [&] { hsr_srf_options o32 = {32, 0, 0, 0}; if (hsr_srf_integrate(d_cube, npix, B, d_wn, raw.k0, raw.klen, nb, d_planes, 1, 12, &o32, 0)) { printf("%s\n", hsr_last_error()); exit(1);} }, false);
-  add("LIB K1+K2 deg3 tile32 PIXMAJOR", [&] { hsr_srf_options o32 = {32, 0, 0, 0}; if (hsr_srf_integrate_moments(d_cube, npix, B, d_wn, raw.k0, raw.klen, nb, d_planes, 1, 12, d_real, 1, 12, nullptr, 0.f, 0.f, 3, d_part, &slots, &o32, 0)) { printf("%s\n", hsr_last_error()); exit(1);} }, false);
-  add("LIB K1 tile32", [&] { hsr_srf_options o32 = {32, 0, 0, 0}; if (hsr_srf_integrate(d_cube, npix, B, d_wn, raw.k0, raw.klen, nb, d_planes, stride, 1, &o32, 0)) { printf("%s\n", hsr_last_error()); exit(1);} }, true);
-  add("LIB K1+K2 deg3 tile32", [&] { hsr_srf_options o32 = {32, 0, 0, 0}; if (hsr_srf_integrate_moments(d_cube, npix, B, d_wn, raw.k0, raw.klen, nb, d_planes, stride, 1, d_real, npix, 1, nullptr, 0.f, 0.f, 3, d_part, &slots, &o32, 0)) { printf("%s\n", hsr_last_error()); exit(1);} }, true);
   add("LIB hsr_srf_integrate (K1)", [&] { if (hsr_srf_integrate(d_cube, npix, B, d_wn, raw.k0, raw.klen, nb, d_planes, stride, 1, nullptr, 0)) { printf("%s\n", hsr_last_error()); exit(1);} }, true);
   for (int deg = 1; deg <= 4; ++deg) {
     static char names[5][64]; snprintf(names[deg], 64, "LIB hsr_srf_integrate_moments deg%d", deg);

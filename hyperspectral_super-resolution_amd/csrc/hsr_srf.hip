@@ -65,6 +65,7 @@ struct SrfArgs {
   float min_x, min_y;
   // uint16 tiles (srf_u16_kernel): cube points at uint16 samples, x = float(u) * scale, u == nodata -> NaN
   int32_t u16;
+  int32_t u16_fast;  // opt-in fast arithmetic of the uint16 kernels (hsr_srf_options.flags & HSR_SRF_U16_FAST)
   float scale;
   uint32_t nodata;   // > 0xffff: no nodata value
 #ifdef HSR_PHASE_STAMPS
@@ -105,22 +106,25 @@ struct SrfTuning {
   int tile_pixels;    // 64
   int reserved_cus;   // CUs left without a persistent K1 workgroup (side-stream kernels of the previous tile's fit)
   bool u16_ring;      // uint16 cubes: double-buffered kernel where it fits
+  bool u16_fast;      // uint16 cubes: fast arithmetic (decode scale folded into the weights, packed fma)
 };
 
 static int srf_tuning(const hsr_srf_options* o, SrfTuning* t, const char* who) {
   t->tile_pixels = 64;
   t->reserved_cus = 0;
   t->u16_ring = true;
+  t->u16_fast = false;
   if (o == nullptr) return HSR_OK;
   HSR_REQUIRE(o->tile_pixels == 0 || o->tile_pixels == 64, HSR_ERR_INVALID,
               "%s: options.tile_pixels must be 0 (default) or 64, got %d (the 32-pixel geometry of round 1 measured 3-8 %% "
               "slower and was removed)", who, o->tile_pixels);
   HSR_REQUIRE(o->reserved_cus >= 0 && o->reserved_cus <= 128, HSR_ERR_INVALID, "%s: options.reserved_cus=%d outside [0,128]",
               who, o->reserved_cus);
-  HSR_REQUIRE(o->reserved == 0, HSR_ERR_INVALID, "%s: options.reserved must be 0", who);
+  HSR_REQUIRE((o->flags & ~HSR_SRF_U16_FAST) == 0, HSR_ERR_INVALID, "%s: options.flags has unknown bits (0x%x)", who, o->flags);
   if (o->tile_pixels) t->tile_pixels = o->tile_pixels;
   t->reserved_cus = o->reserved_cus;
   t->u16_ring = o->u16_single_buffer == 0;
+  t->u16_fast = (o->flags & HSR_SRF_U16_FAST) != 0;
   return HSR_OK;
 }
 
@@ -711,6 +715,39 @@ __device__ __forceinline__ float u16_band_dot(const uint16_t* tile, int e0, cons
   return acc;
 }
 
+// Opt-in fast arithmetic for uint16 cubes (hsr_srf_options.flags & HSR_SRF_U16_FAST).  The exact path above spends
+// ~3.5 VALU instructions per tap (realign, extract, convert, decode multiply, fma) and is VALU-bound at half the HBM
+// bytes of the float32 kernel.  Here the decode scale is folded into the weights once (w' = w * scale, rounded to
+// float32 when the taps are staged) and even / odd taps accumulate in the two halves of one v_pk_fma_f32: ~2 per tap.
+// Not bit-identical to decode -> float32 K1 any more (one rounding moved, two partial sums): |rel| <= 1e-6 against
+// the exact kernel (7e-7 observed), <= 2e-6 against the float64 oracle (tests/test_gpu_parity.py).  Measured: K1 on a
+// 1024 x 1024 tile 0.136 vs 0.144 ms - the exact kernel is no longer VALU-bound since the ring, so halving the
+// arithmetic buys 6 %, not 2x.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float u16_band_dot_fast(const uint16_t* tile, int e0, const float4* w4, int klen) {
+  f32x2 acc = {0.0f, 0.0f};
+  const uint32_t sh = (uint32_t)(e0 & 1) * 2u;
+  const uint32_t* d32 = reinterpret_cast<const uint32_t*>(tile) + (e0 >> 1);
+  for (int i0 = 0; i0 < klen; i0 += kTapChunk) {
+    float4 ww[kTapChunk / 4];
+    uint32_t d[kTapChunk / 2 + 1];
+#pragma unroll
+    for (int u = 0; u < kTapChunk / 4; ++u) ww[u] = w4[(i0 >> 2) + u];
+#pragma unroll
+    for (int u = 0; u <= kTapChunk / 2; ++u) d[u] = d32[(i0 >> 1) + u];
+#pragma unroll
+    for (int u = 0; u < kTapChunk / 4; ++u) {
+      const uint32_t ea = __builtin_amdgcn_alignbyte(d[2 * u + 1], d[2 * u], sh);
+      const uint32_t eb = __builtin_amdgcn_alignbyte(d[2 * u + 2], d[2 * u + 1], sh);
+      const f32x2 x0 = {(float)(ea & 0xffffu), (float)(ea >> 16)}, x1 = {(float)(eb & 0xffffu), (float)(eb >> 16)};
+      const f32x2 w0 = {ww[u].x, ww[u].y}, w1 = {ww[u].z, ww[u].w};
+      acc = __builtin_elementwise_fma(w0, x0, acc);
+      acc = __builtin_elementwise_fma(w1, x1, acc);
+    }
+  }
+  return acc.x + acc.y;
+}
+
 template <int DEG, bool FAST, bool OUTV, bool BATCH>
 __global__ __launch_bounds__(512, 4) void srf_u16_kernel(const SrfArgs a) {
   constexpr int P = 64, T = 512;
@@ -905,7 +942,7 @@ __device__ __forceinline__ void glds4_asm(const void* gaddr, uint32_t lds_base) 
 // the next top barrier.  Same arithmetic, same summation trees -> same bits as srf_u16_kernel.
 // Batch launches: the group after the last one of a unit is the first group of the workgroup's next unit, so three
 // unit records are alive: cu (being reduced), nu (being prefetched), nn (its record is on its way).
-template <int DEG, bool OUTV, bool BATCH>
+template <int DEG, bool OUTV, bool BATCH, bool FASTU>
 __global__ __launch_bounds__(512, 4) void srf_u16_ring_kernel(const SrfArgs a) {
   constexpr int P = 64, T = 512;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -942,7 +979,10 @@ __global__ __launch_bounds__(512, 4) void srf_u16_ring_kernel(const SrfArgs a) {
     float* wlw = const_cast<float*>(wl);
     for (int b = 0; b < a.nb; ++b) {
       const int kl = a.bands.klen[b];
-      for (int i = t; i < kl; i += T) wlw[a.bands.woff[b] + i] = a.wn[(size_t)b * B + a.bands.k0[b] + i];
+      for (int i = t; i < kl; i += T) {
+        const float wv = a.wn[(size_t)b * B + a.bands.k0[b] + i];
+        wlw[a.bands.woff[b] + i] = FASTU ? wv * scale : wv;     // fast arithmetic: decode scale folded into the taps
+      }
     }
   }
   if (OUTV) zero_stage_pad<T>(ostage, P, a.nb, ops, t);
@@ -1066,7 +1106,8 @@ __global__ __launch_bounds__(512, 4) void srf_u16_ring_kernel(const SrfArgs a) {
     for (int j = 0; j < kBandSlots; ++j) {
       float acc = 0.0f;
       if (wlds) {
-        acc = u16_band_dot(tile, pl * B + bk0[j], reinterpret_cast<const float4*>(wl + bwo[j]), bkl[j], scale);
+        acc = FASTU ? u16_band_dot_fast(tile, pl * B + bk0[j], reinterpret_cast<const float4*>(wl + bwo[j]), bkl[j])
+                    : u16_band_dot(tile, pl * B + bk0[j], reinterpret_cast<const float4*>(wl + bwo[j]), bkl[j], scale);
       } else {
         const uint16_t* vs = tile + pl * B + bk0[j];
         const float* ws = a.wn + (size_t)bidx[j] * B + bk0[j];
@@ -1116,10 +1157,10 @@ static void ensure_dynamic_lds(K kern, size_t lds, size_t* configured) {
   }
 }
 
-template <int DEG, bool OUTV, bool BATCH>
+template <int DEG, bool OUTV, bool BATCH, bool FASTU>
 static int launch_srf_u16_ring(const SrfArgs& a, int grid, hipStream_t stream) {
   const size_t lds = (size_t)2 * 64 * a.B * 2 + 128 * sizeof(uint32_t) + (size_t)a.wtaps * 4 + (OUTV ? (size_t)64 * a.out_ps * 4 : 0);
-  auto kern = srf_u16_ring_kernel<DEG, OUTV, BATCH>;
+  auto kern = srf_u16_ring_kernel<DEG, OUTV, BATCH, FASTU>;
   static thread_local size_t configured = 0;
   ensure_dynamic_lds(kern, lds, &configured);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, a);
@@ -1151,8 +1192,10 @@ static bool u16_ring_fits(const SrfArgs& a, bool outv) {
 template <int DEG>
 static int dispatch_u16_deg(const SrfArgs& a, bool fast, bool ring, int grid, hipStream_t s) {
   const bool outv = out_rows_vectorised(a, a.one.pseudo_dev);
-  if (fast && ring && u16_ring_fits(a, outv))
-    return outv ? launch_srf_u16_ring<DEG, true, false>(a, grid, s) : launch_srf_u16_ring<DEG, false, false>(a, grid, s);
+  if (fast && ring && u16_ring_fits(a, outv)) {
+    if (outv && a.u16_fast && a.wtaps > 0) return launch_srf_u16_ring<DEG, true, false, true>(a, grid, s);
+    return outv ? launch_srf_u16_ring<DEG, true, false, false>(a, grid, s) : launch_srf_u16_ring<DEG, false, false, false>(a, grid, s);
+  }
   if (outv) return fast ? launch_srf_u16<DEG, true, true, false>(a, grid, s) : launch_srf_u16<DEG, false, true, false>(a, grid, s);
   return fast ? launch_srf_u16<DEG, true, false, false>(a, grid, s) : launch_srf_u16<DEG, false, false, false>(a, grid, s);
 }
@@ -1210,7 +1253,8 @@ static int dispatch_deg(const SrfArgs& a, int deg, bool fast, int grid, hipStrea
 template <int DEG>
 static int dispatch_batch_deg(const SrfArgs& a, bool fast, bool ring, int grid, hipStream_t s) {
   if (a.u16) {
-    if (fast && ring && u16_ring_fits(a, true)) return launch_srf_u16_ring<DEG, true, true>(a, grid, s);
+    if (fast && ring && u16_ring_fits(a, true))
+      return a.u16_fast ? launch_srf_u16_ring<DEG, true, true, true>(a, grid, s) : launch_srf_u16_ring<DEG, true, true, false>(a, grid, s);
     return fast ? launch_srf_u16<DEG, true, true, true>(a, grid, s) : launch_srf_u16<DEG, false, true, true>(a, grid, s);
   }
   return fast ? launch_srf<DEG, true, true, 64, true, true>(a, grid, s) : launch_srf<DEG, false, true, 64, true, true>(a, grid, s);
@@ -1307,6 +1351,7 @@ static int srf_common(SrfArgs& a, const int32_t* k0, const int32_t* klen, int32_
   HSR_REQUIRE(((uintptr_t)a.one.cube_dev & (a.u16 ? 1 : 3)) == 0, HSR_ERR_INVALID, "hsr_srf_integrate: cube not %d-byte aligned",
               a.u16 ? 2 : 4);
   if (a.one.npix == 0) return HSR_OK;
+  a.u16_fast = a.u16 && tn.u16_fast;
   int P = a.u16 ? 64 : tn.tile_pixels;
   if (a.wtaps == 0) P = 64;  // the generic fallback kernel exists for 64-pixel groups only
   a.one.ngroups = (int32_t)((a.one.npix + P - 1) / P);
@@ -1533,6 +1578,7 @@ extern "C" int hsr_srf_integrate_moments_batched(const hsr_batch_unit* units_dev
   a.units = units_dev;
   a.nunits = (int32_t)info->nunits;
   a.u16 = cube_dtype == 2;
+  a.u16_fast = a.u16 && tn.u16_fast;
   a.scale = scale;
   a.nodata = nodata < 0 ? 0x10000u : (uint32_t)nodata;
   a.B = B;

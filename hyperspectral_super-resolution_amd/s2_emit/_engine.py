@@ -60,9 +60,11 @@ def _stream(torch, t=None):
     return C.c_void_p(torch.cuda.current_stream(cur).cuda_stream)
 
 
-def srf_options(tile_pixels: int = 0, reserved_cus: int = 0, u16_single_buffer: bool = False):
-    """hsr_srf_options for one call / one plan (None everywhere means the defaults)."""
-    return nat.SrfOptions(int(tile_pixels), int(reserved_cus), 1 if u16_single_buffer else 0, 0)
+def srf_options(tile_pixels: int = 0, reserved_cus: int = 0, u16_single_buffer: bool = False, u16_fast: bool = False):
+    """hsr_srf_options for one call / one plan (None everywhere means the defaults).  u16_fast: opt-in fast arithmetic
+    of the uint16 kernels (decode scale folded into the weights; ~1e-7 relative off the bit-exact path)."""
+    return nat.SrfOptions(int(tile_pixels), int(reserved_cus), 1 if u16_single_buffer else 0,
+                          nat.HSR_SRF_U16_FAST if u16_fast else 0)
 
 
 def _opt(opts):

@@ -19,6 +19,7 @@ HSR_MAX_DEG = 4
 HSR_MAX_APPLY_DEG = 8
 HSR_MAX_SPECTRAL = 560
 HSR_TILE_PIXELS = 64
+HSR_SRF_U16_FAST = 1
 HSR_MAX_PARTIALS = 4096
 PLANAR = "planar"        # band-major planes: tensor (nb, npix), unit pixel stride
 PIXMAJOR = "pixmajor"    # pixel-major / band-last: tensor (npix, row) with row >= nb, unit band stride
@@ -38,7 +39,7 @@ _pi32 = C.POINTER(C.c_int32)
 
 class SrfOptions(C.Structure):
     """hsr_srf_options (include/hsr.h): per-call tuning of the K1 launches; the library keeps no tuning state."""
-    _fields_ = [("tile_pixels", _i32), ("reserved_cus", _i32), ("u16_single_buffer", _i32), ("reserved", _i32)]
+    _fields_ = [("tile_pixels", _i32), ("reserved_cus", _i32), ("u16_single_buffer", _i32), ("flags", _i32)]
 
 
 class BatchTile(C.Structure):

@@ -100,7 +100,8 @@ class SpectralFusion:
                  min_count: int = 50, clip: bool = True, apply_mask: bool = False, device=None,
                  group=None, coeff_sync: str = "allreduce", layout: str = nat.PIXMAJOR,
                  force_exchange: bool = False, tile_scale=None, tile_nodata: Optional[int] = eng.TILE_NODATA,
-                 reserved_cus: Optional[int] = None, tile_pixels: int = 0, u16_single_buffer: bool = False):
+                 reserved_cus: Optional[int] = None, tile_pixels: int = 0, u16_single_buffer: bool = False,
+                 u16_fast: bool = False):
         torch = nat.require_gpu()
         # decode of uint16 cubes (the reference's tile format, tiles_helpers/utils.py:362-374): x = u * tile_scale
         # (default float32(1e-4)), u == tile_nodata -> NaN (None: no nodata value).  Ignored for float32 cubes.
@@ -129,7 +130,7 @@ class SpectralFusion:
         # use the same geometry, hence the same partial-slot layout and bit-identical coefficients.
         if reserved_cus is None:
             reserved_cus = 8 if self._exchanges() else 0
-        self.opts = eng.srf_options(tile_pixels, reserved_cus, u16_single_buffer)
+        self.opts = eng.srf_options(tile_pixels, reserved_cus, u16_single_buffer, u16_fast)
         self._batches: Dict[tuple, object] = {}
         self._pipe = None                            # state of submit()/flush(), created on first use
         self.ws = eng.MomentWorkspace(self.device, self.table.nb, deg)

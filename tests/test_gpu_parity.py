@@ -1590,3 +1590,36 @@ def test_integration_md_stub_runs(torch_gpu):
     ref = s2_emit.pseudo_s2_srf_integral(R, w, srf, good)
     for i, k in enumerate(names):
         assert np.array_equal(planes[i].reshape(40, 30), ref[k].astype(np.float32)), k
+
+
+def test_u16_fast_arithmetic_option(torch_gpu):
+    """hsr_srf_options.flags & HSR_SRF_U16_FAST: decode scale folded into the weights + packed fma.  Not bit-identical to
+    the exact uint16 path any more; stated tolerance: <= 1e-6 relative against it (7e-7 observed), <= 2e-6 against the float64 oracle,
+    NaN pattern (nodata pixels) identical; coefficients of a fused step within 1e-5 of the exact path's."""
+    torch = torch_gpu
+    from s2_emit import SpectralFusion, _engine as eng
+    from s2_emit.synthetic import device_problem
+    p = device_problem(100, 130, 285, deg=3, seed=9)
+    u = eng.tile_encode_u16(p.cube)
+    u.view(-1)[7 * 285 + 3] = 65535
+    table = eng.build_srf_table(p.emit_w, p.srf, p.good_mask)
+    exact = eng.srf_integrate(u, table, layout="pixmajor")
+    fast = eng.srf_integrate(u, table, layout="pixmajor", opts=eng.srf_options(u16_fast=True))
+    e, f = exact[:, :table.nb].cpu().numpy(), fast[:, :table.nb].cpu().numpy()
+    assert np.array_equal(np.isnan(e), np.isnan(f)) and np.isnan(f[7]).all()
+    ok = np.isfinite(e)
+    assert not np.array_equal(e[ok], f[ok])                      # it IS a different arithmetic
+    assert np.max(np.abs(f[ok] - e[ok]) / np.abs(e[ok])) < 1e-6
+    R = eng.tile_decode_u16(u).cpu().numpy().reshape(100, 130, 285)
+    ref = onp.pseudo_s2_srf_integral(R, p.emit_w, p.srf, p.good_mask)
+    for i, k in enumerate(table.supported):
+        assert _rel_err(f[:, i].reshape(100, 130), ref[k]) < 2e-6, k
+    a = SpectralFusion(p.emit_w, p.srf, p.good_mask, deg=3).step(u, p.real, reuse_buffers=False)
+    b = SpectralFusion(p.emit_w, p.srf, p.good_mask, deg=3, u16_fast=True).step(u, p.real, reuse_buffers=False)
+    np.testing.assert_allclose(b.coeffs.cpu().numpy(), a.coeffs.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    ma, mb = a.matched.cpu().numpy(), b.matched.cpu().numpy()
+    okm = np.isfinite(ma)
+    assert np.max(np.abs(ma[okm] - mb[okm])) < 1e-6
+    # batches take the flag too
+    tb = SpectralFusion(p.emit_w, p.srf, p.good_mask, deg=3, u16_fast=True).step_batch([u, u], [p.real, p.real])
+    assert torch.equal(tb.tile(1).matched.view(torch.int32), b.matched.view(torch.int32))

@@ -65,7 +65,7 @@ def test_sizing_helpers_and_error_strings():
     assert rc == 1 and b"neither band-major nor pixel-major" in lib.hsr_last_error()
     bad = nat.SrfOptions(0, 0, 0, 7)
     rc = lib.hsr_srf_integrate(ctypes.c_void_p(16), 10, 285, ctypes.c_void_p(16), k, k, 1, ctypes.c_void_p(16), 10, 1, ctypes.byref(bad), None)
-    assert rc == 1 and b"reserved must be 0" in lib.hsr_last_error()
+    assert rc == 1 and b"unknown bits" in lib.hsr_last_error()
     # the rows added later in the round validate the same way
     P = ctypes.c_void_p(256)
     assert lib.hsr_tile_decode_u16(P, 10, 1e-4, 70000, P, None) == 1 and b"not a uint16 value" in lib.hsr_last_error()

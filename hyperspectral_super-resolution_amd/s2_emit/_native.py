@@ -94,6 +94,7 @@ SIGNATURES = {
                                                     _i32, _i32, _i32, _f32, _f32, _i32, _popt, _vp]),
     "hsr_moments_reduce_solve_batched": (C.c_int, [_vp, _i32, _vp, _i32, _i32, _i64, _vp, _vp, _vp]),
     "hsr_poly_apply_batched": (C.c_int, [_vp, _i32, _i64, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "hsr_interleave_to_bip": (C.c_int, [_vp, _i32, _i32, _i64, _i64, _i64, _vp, _i32, _vp]),
     "hsr_ot_work_bytes": (_i64, [_i64, _i64]),
     "hsr_ot_begin": (C.c_int, [_vp, _i64, _vp, _i64, _f64, _vp, _vp]),
     "hsr_ot_iterate": (C.c_int, [_i64, _i64, _i32, _i32, _f64, _vp, _vp, _vp]),

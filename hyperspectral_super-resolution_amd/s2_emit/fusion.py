@@ -287,6 +287,9 @@ class SpectralFusion:
     def stream(self, tiles, depth: int = 2, to_host: bool = True):
         """Run the hot path over an iterable of host tiles ``(cube, real)`` or ``(cube, real, mask)``
         (NumPy arrays or CPU tensors; cube float32 or uint16 (H,W,B)/(npix,B), real as in step()).
+        ``cube`` may also be an ``emit_io.EnviCubeFile``: the BIL / BSQ / BIP file then goes file -> pinned staging
+        -> GPU in file order and is transposed to pixel-major on the GPU (reference loader s2_emit/emit_io.py:7-16
+        does the transpose on the host).
         Yields ``(index, coeffs, matched, out)``: with ``to_host`` coeffs is a (nb, deg+1) float64 and matched a
         float32 NumPy array in the plan's layout (pinned memory reused every ``depth`` tiles - copy what you
         keep); otherwise the device tensors of ``out`` (valid until the next iteration)."""
@@ -296,7 +299,8 @@ class SpectralFusion:
         dev = self.device
         copy_stream = torch.cuda.Stream(device=dev)
         main = torch.cuda.current_stream(dev)
-        slots = [dict(cube=None, real=None, mask=None, ready=torch.cuda.Event(), free=torch.cuda.Event(), used=False,
+        from .emit_io import EnviCubeFile
+        slots = [dict(cube=None, real=None, mask=None, ready=torch.cuda.Event(), free=torch.cuda.Event(), h2d=torch.cuda.Event(), used=False,
                       coeffs_h=None, matched_h=None, done=torch.cuda.Event()) for _ in range(depth)]
 
         def as_tensor(x):
@@ -305,14 +309,41 @@ class SpectralFusion:
 
         def upload(i, tile):
             sl = slots[i % depth]
-            cube, real = as_tensor(tile[0]), as_tensor(tile[1])
+            src_cube = tile[0]
+            real = as_tensor(tile[1])
             mask = as_tensor(tile[2]) if len(tile) > 2 and tile[2] is not None else None
             if mask is not None and mask.dtype == torch.bool:
                 mask = mask.view(torch.uint8)
+            envi = isinstance(src_cube, EnviCubeFile)
+            if envi:
+                # BIL / BSQ / BIP file: file -> pinned staging in FILE order (the host's only pass over the samples),
+                # H2D of the raw bytes, transpose on the GPU (hsr_interleave_to_bip), all on the copy stream
+                st = sl.get("stage")
+                if st is None or st.shape[0] != src_cube.raw.shape[0] or st.dtype != src_cube._torch_dtype(torch):
+                    if sl["used"]:
+                        sl["free"].synchronize()        # the H2D copy out of the old staging buffer has finished
+                    st = sl["stage"] = src_cube.new_staging(torch)
+                elif sl["used"]:
+                    sl["h2d"].synchronize()             # previous copy out of this staging buffer has finished
+                src_cube.stage(st)
+            else:
+                cube = as_tensor(src_cube)
             with torch.cuda.stream(copy_stream):
                 if sl["used"]:
                     copy_stream.wait_event(sl["free"])       # the step that last read this buffer set
-                for key, src in (("cube", cube), ("real", real), ("mask", mask)):
+                if envi:
+                    raw = sl.get("raw")
+                    if raw is None or raw.shape != st.shape or raw.dtype != st.dtype:
+                        raw = sl["raw"] = torch.empty(st.shape, dtype=st.dtype, device=dev)
+                    raw.copy_(st, non_blocking=True)
+                    sl["h2d"].record(copy_stream)
+                    odt = src_cube.cube_dtype(torch)
+                    cube_dev = sl["cube"]
+                    if src_cube.interleave == "bip" or cube_dev is None or tuple(cube_dev.shape) != src_cube.shape or cube_dev.dtype != odt:
+                        cube_dev = None
+                    sl["cube"] = src_cube.to_bip(raw, out=cube_dev)
+                pairs = (("real", real), ("mask", mask)) if envi else (("cube", cube), ("real", real), ("mask", mask))
+                for key, src in pairs:
                     if src is None:
                         sl[key] = None
                         continue

@@ -280,6 +280,14 @@ int hsr_moments_reduce_solve_batched(const hsr_batch_tile* tiles_dev, int32_t nt
 int hsr_poly_apply_batched(const hsr_batch_tile* tiles_dev, int32_t ntiles, int64_t max_npix, const double* coeffs_dev,
                            int32_t nb, int32_t deg, int32_t row, int32_t use_mask, int32_t clip, hsr_stream_t stream);
 
+/* ---- ENVI interleaves -> pixel-major -------------------------------------------------------
+ * load_emit_envi_rfl (s2_emit/emit_io.py:7-16) hands the path an (H, W, B) array whatever the file's interleave; files
+ * written by gdalwarp are BIL or BSQ.  The raw file bytes go to the GPU as they are and are transposed there:
+ * interleave 1 = BIL (lines, bands, samples), 2 = BSQ (bands, lines, samples) -> out (lines, samples, bands).
+ * dtypes: 0 float32, 2 uint16, 3 int16 (in only); out_dtype 0 or 2 (uint16 only from uint16).  HBM-bound, 2 x bytes. */
+int hsr_interleave_to_bip(const void* in_dev, int32_t in_dtype, int32_t interleave, int64_t lines, int64_t samples,
+                          int64_t bands, void* out_dev, int32_t out_dtype, hsr_stream_t stream);
+
 /* ---- entropic OT targets ------------------------------------------------------------------
  * Replaces, for uniform marginals, the POT calls of s2_emit/poly_regression.py:49-56 and color.py:97-104:
  *   M = ot.dist(X, Y, "sqeuclidean"); P = ot.sinkhorn(a, b, M, reg, numItermax=, stopThr=);

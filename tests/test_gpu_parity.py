@@ -1623,3 +1623,51 @@ def test_u16_fast_arithmetic_option(torch_gpu):
     # batches take the flag too
     tb = SpectralFusion(p.emit_w, p.srf, p.good_mask, deg=3, u16_fast=True).step_batch([u, u], [p.real, p.real])
     assert torch.equal(tb.tile(1).matched.view(torch.int32), b.matched.view(torch.int32))
+
+
+def test_stream_envi_files_bil_bsq_bit_exact_with_bip_feed(torch_gpu, tmp_path):
+    """SURVEY 8-f3 remainder: BIL / BSQ ENVI files go file -> pinned staging -> GPU in FILE order and are transposed there
+    (hsr_interleave_to_bip) inside SpectralFusion.stream(); coefficients and images are bit-identical to feeding the
+    same cube as a pixel-major array, for float32, uint16 (tile format, decoded in K1) and int16 files, ragged shapes
+    included (reference loader: s2_emit/emit_io.py:7-16, transposes on the host)."""
+    torch = torch_gpu
+    from s2_emit import SpectralFusion, _engine as eng
+    from s2_emit.emit_io import EnviCubeFile
+    w, good = onp.synthetic_wavelengths()
+    srf = onp.synthetic_srf()
+    rng = np.random.default_rng(3)
+    H, W, B = 37, 70, 285                                   # 70 samples, 285 bands: partial 64 x 64 transpose tiles
+    cube = (rng.random((H, W, B)) * 0.55).astype(np.float32)
+    real = rng.random((H, W, 12)).astype(np.float32)
+    codes = {np.dtype(np.float32): 4, np.dtype(np.uint16): 12, np.dtype(np.int16): 2}
+
+    def write(arr, inter, tag):
+        lay = {"bip": arr, "bil": arr.transpose(0, 2, 1), "bsq": arr.transpose(2, 0, 1)}[inter]
+        np.ascontiguousarray(lay).tofile(tmp_path / f"{tag}_{inter}.bin")
+        (tmp_path / f"{tag}_{inter}.hdr").write_text(
+            f"ENVI\nsamples = {W}\nlines = {H}\nbands = {B}\nheader offset = 0\ndata type = {codes[arr.dtype]}\n"
+            f"interleave = {inter}\nbyte order = 0\n")
+        return EnviCubeFile(str(tmp_path / f"{tag}_{inter}.hdr"), str(tmp_path / f"{tag}_{inter}.bin"))
+
+    plan = SpectralFusion(w, srf, good, deg=2, min_valid=0.0)
+    u16 = np.clip(np.rint(cube * 10000), 0, 65534).astype(np.uint16)
+    u16[3, 5, 100] = 65535
+    i16 = (u16.astype(np.int32) - 3000).astype(np.int16)
+    for tag, arr in (("f32", cube), ("u16", u16), ("i16", i16)):
+        feed = arr if tag != "i16" else arr.astype(np.float32)          # what the host loader would hand over
+        ref = [(c.copy(), m.copy()) for _, c, m, _ in plan.stream([(feed, real)] * 3, depth=2)]
+        for inter in ("bil", "bsq", "bip"):
+            f = write(arr, inter, tag)
+            assert f.shape == (H, W, B) and f.interleave == inter
+            d = f.to_device("cuda")
+            np.testing.assert_array_equal(d.cpu().numpy(), feed)                     # the transpose alone
+            got = [(c.copy(), m.copy()) for _, c, m, _ in plan.stream([(f, real)] * 3, depth=2)]
+            assert len(got) == 3
+            for (c, m), (rc, rm) in zip(got, ref):
+                assert np.array_equal(c.view(np.int64), rc.view(np.int64)), (tag, inter)
+                assert np.array_equal(m.view(np.int32), rm.view(np.int32)), (tag, inter)
+    # files and arrays mixed in one stream, depth 1 and 3
+    f = write(cube, "bsq", "mix")
+    for depth in (1, 3):
+        got = [c.copy() for _, c, _, _ in plan.stream([(f, real), (cube, real), (f, real)], depth=depth)]
+        assert np.array_equal(got[0], got[1]) and np.array_equal(got[1], got[2])

@@ -74,6 +74,9 @@ def parse_args():
                     help="f32: the headline workload (float32 cube, 4 B per pixel*band).  u16: the same cube in the "
                          "reference's on-disk tile format (uint16 x 10000, tiles_helpers/utils.py:362-374), decoded inside "
                          "K1 - a SURVEY 8-f2 measurement, 2 B per pixel*band, not the headline")
+    ap.add_argument("--u16-fast", action="store_true",
+                    help="with --cube u16: the opt-in fast arithmetic of the uint16 kernel (HSR_SRF_U16_FAST; 1e-6 relative "
+                         "off the bit-exact path)")
     ap.add_argument("--event-every", type=int, default=4,
                     help="bracket the K1+K2 kernel with HIP events on every n-th timed step (each pair of event "
                          "records costs ~12 us of launch gap, so not on every step)")
@@ -235,7 +238,8 @@ def main():
                           clip=True, device=device, group=None,
                           coeff_sync=args.coeff_sync if (world > 1 or args.force_exchange) else "local",
                           force_exchange=args.force_exchange,
-                          reserved_cus=args.reserve_cus if pipelined else 0)   # CUs kept free for the side stream
+                          reserved_cus=args.reserve_cus if pipelined else 0,   # CUs kept free for the side stream
+                          u16_fast=args.u16_fast)
     real = prob.real            # (H, W, row) band-last, like the cube and the reference's (H, W, C) images
     cube = prob.cube
     if args.cube == "u16":      # quantise once, outside the timed region (the writer's arithmetic, on the device)
@@ -306,7 +310,7 @@ def main():
         cube_bytes = npb * esz
         full_bytes = H * W * (esz * B + 16 * nb)        # + pseudo write, real read, apply read + write (no mask in this run)
         achieved = cube_bytes / (k1_ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": "srf_kernel<deg,fast> (K1+K2 fused)" if args.cube == "f32" else "srf_u16_ring_kernel<deg> (K1+K2 fused, uint16 tile decode)", "achieved": round(achieved, 1),
+        roof = {"bound": "hbm", "kernel": "srf_kernel<deg,fast> (K1+K2 fused)" if args.cube == "f32" else "srf_u16_ring_kernel<deg> (K1+K2 fused, uint16 tile decode%s)" % (", fast arithmetic" if args.u16_fast else ""), "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": None, "algorithmic_bytes": cube_bytes, "kernel_ms": round(k1_ms, 4),
                 "kernel_launches_timed": len(k1_all),

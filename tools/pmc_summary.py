@@ -37,10 +37,10 @@ def main():
     out.append("| kernel | calls | avg us | median us | min us | max us |\n|---|---|---|---|---|---|")
     for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
         out.append(f"| `{k}` | {len(v)} | {sum(v)/len(v)/1e3:.2f} | {statistics.median(v)/1e3:.2f} | {min(v)/1e3:.2f} | {max(v)/1e3:.2f} |")
-    srf = [k for k in dur if "srf_kernel<3" in k]
+    srf = [k for k in dur if "srf_kernel<3" in k] or [k for k in dur if "srf_u16_ring_kernel<3" in k]
     if srf:
         avg = sum(dur[srf[0]]) / len(dur[srf[0]])
-        cube = 1024 * 1024 * 285 * 4
+        cube = 1024 * 1024 * 285 * (2 if "u16" in srf[0] else 4)
         out.append(f"\nDominant kernel `{srf[0]}`: {avg/1e3:.1f} us average -> {cube/avg:.0f} GB/s of algorithmic cube bytes "
                    f"({cube} B per launch) = {cube/avg/8000*100:.1f} % of 8 TB/s.\n")
     traffic = {}
@@ -65,10 +65,20 @@ def main():
     os.makedirs(os.path.join(root, "profiles"), exist_ok=True)
     open(os.path.join(root, "profiles", f"{tag}_rocprof_summary.md"), "w").write("\n".join(out) + "\n")
     if traffic:
-        key = [k for k in traffic if "srf_kernel<3" in k]
-        json.dump({"srf_kernel_hbm_bytes_per_launch": traffic[key[0]] if key else None, "per_kernel": traffic,
-                   "source": f"profiles/{tag}_rocprof_summary.md"},
-                  open(os.path.join(root, "profiles", "traffic.json"), "w"), indent=1)
+        tf = os.path.join(root, "profiles", "traffic.json")
+        old = json.load(open(tf)) if os.path.isfile(tf) else {}
+        per = dict(old.get("per_kernel", {}))
+        per.update(traffic)
+        key = [k for k in traffic if "srf_kernel<3" in k and "true, false>" in k] or [k for k in traffic if "srf_kernel<3" in k]
+        ukey = [k for k in traffic if "srf_u16_ring_kernel<3" in k]
+        old["per_kernel"] = per
+        if key:
+            old["srf_kernel_hbm_bytes_per_launch"] = traffic[key[0]]
+            old["source"] = f"profiles/{tag}_rocprof_summary.md"
+        if ukey:
+            old["srf_u16_kernel_hbm_bytes_per_launch"] = traffic[ukey[0]]
+            old["source_u16"] = f"profiles/{tag}_rocprof_summary.md (separate --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py --cube u16)"
+        json.dump(old, open(tf, "w"), indent=1)
     print("\n".join(out))
 
 

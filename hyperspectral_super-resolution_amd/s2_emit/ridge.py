@@ -5,7 +5,8 @@ Mirrors the notebook-resident pipeline of the reference, legacy_notebooks/Spectr
 ``StandardScaler -> PolynomialFeatures(degree, include_bias=False) -> Ridge(alpha)`` (475-490) and
 ``predict_cube_logit`` (192-213).  The fit is the float64 normal-equation form of that pipeline
 (centre features and targets, solve (Phi^T Phi + alpha I) W = Phi^T Y): the Gram contraction runs on the
-float64 matrix cores (``hsr_gram_f64``), the small Cholesky solve through torch.linalg on the device, and
+float64 matrix cores (``hsr_gram_f64``), the 285 x 285 ridge system by the library's own one-workgroup blocked
+Cholesky (``hsr_chol_solve_f64``), and
 the prediction is one fused expand + float32-MFMA + sigmoid kernel (``hsr_polyfeat_predict``).
 """
 from __future__ import annotations

@@ -1,8 +1,8 @@
 """Load the reference's own functions for this path, by file path, in the BUILD CONTAINER ONLY.
 
 TEST INFRASTRUCTURE.  Used by ``tests/golden/gen_golden.py`` to freeze reference outputs into
-``tests/golden/*.npz`` and by ``tests/test_oracle_vs_reference.py`` (skipped when
-``/root/reference`` does not exist, i.e. on the GPU box).  Nothing from the reference tree is
+``tests/golden/*.npz`` (``tests/test_oracle_golden.py`` then checks the oracle against those fixtures bit for bit,
+here and on the GPU box, where ``/root/reference`` does not exist).  Nothing from the reference tree is
 copied into this repository: the functions are executed from where they lie.
 
 How:

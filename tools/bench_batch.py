@@ -77,6 +77,7 @@ def main():
         out[k] = {"ms_median": round(ms, 4), "ms_min": round(min(v), 4), "TBps_cube_bytes": round(byt / ms / 1e9, 3)}
         if k != "large":
             out[k]["us_per_tile"] = round(ms * 1e3 / T, 3)
+    out["placement_trials_ms"] = {"batch": getattr(next(iter(plan._batches.values())), "placement_log", None), "large": plan.placement_log.get(1024 * 1024)}
     out["batch_vs_large_rate"] = round(out["large"]["TBps_cube_bytes"] / out["batch"]["TBps_cube_bytes"], 3)
     print(json.dumps(out))
 

@@ -1,0 +1,145 @@
+#!/usr/bin/env python3
+"""Turn a tools/collect_profiles.sh run (gpurun_out/<dir>) into the committed summaries under profiles/.
+
+    python tools/make_profiles.py r02 gpurun_out/r02final
+"""
+import csv
+import glob
+import json
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def jload(p):
+    try:
+        return json.loads(open(p).read().strip().splitlines()[-1])
+    except Exception:
+        return None
+
+
+def kstats(d, flt="hsr::"):
+    f = glob.glob(os.path.join(d, "*kernel_stats.csv"))
+    rows = []
+    if f:
+        for r in csv.DictReader(open(f[0])):
+            if flt in r["Name"]:
+                rows.append((r["Name"].split("(")[0].replace("void ", ""), int(r["Calls"]), float(r["AverageNs"]) / 1e3,
+                             int(r["MinNs"]) / 1e3, int(r["MaxNs"]) / 1e3))
+    return rows
+
+
+def pmc_bytes(d, kern):
+    """FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024 per launch of kernels whose name contains `kern`."""
+    tot = {}
+    for c in ("FETCH_SIZE", "WRITE_SIZE"):
+        vals = []
+        for f in glob.glob(os.path.join(d, c, "*counter_collection.csv")):
+            for r in csv.DictReader(open(f)):
+                if kern in r["Kernel_Name"] and r["Counter_Name"] == c:
+                    vals.append(float(r["Counter_Value"]))
+        if vals:
+            tot[c] = sum(vals) / len(vals)
+    if len(tot) == 2:
+        return tot["FETCH_SIZE"] * 2048, tot["WRITE_SIZE"] * 1024
+    return None
+
+
+def main():
+    tag, src = sys.argv[1], sys.argv[2]
+    P = os.path.join(ROOT, "profiles")
+    os.makedirs(P, exist_ok=True)
+    # ---- headline
+    subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), tag, os.path.join(src, "trace"), os.path.join(src, "pmc")],
+                   stdout=subprocess.DEVNULL, check=True)
+    for name in ("bench_n1.json", "bench_under_rocprof.json", "bench_u16.json", "bench_u16_fast.json", "bench_mosaic8.json"):
+        if os.path.isfile(os.path.join(src, name)):
+            shutil.copy(os.path.join(src, name), os.path.join(P, f"{tag}_{name}.log"))
+    f = glob.glob(os.path.join(src, "trace", "*kernel_stats.csv"))
+    if f:
+        rows = list(csv.DictReader(open(f[0])))
+        with open(os.path.join(P, f"{tag}_kernel_stats.csv"), "w", newline="") as fh:
+            w = csv.DictWriter(fh, fieldnames=rows[0].keys())
+            w.writeheader()
+            for r in rows:
+                if "hsr::" in r["Name"]:
+                    r["Name"] = r["Name"].split("(")[0]
+                    w.writerow(r)
+    # ---- fresh processes
+    out = [f"# {tag}: the headline over fresh processes (one box, back to back)\n",
+           "`python bench.py --steps 100 --no-cpu-baseline` six times, then `--steps 20 --warmup 3` (the driver's shape) three times.\n",
+           "| run | steps | ms/step | K1+K2 ms (HIP events) | frac of 8 TB/s | placement trials (ms) |", "|---|---|---|---|---|---|"]
+    for pat, st in (("fresh_%d.json", 100), ("s20_%d.json", 20)):
+        for i in range(1, 7):
+            d = jload(os.path.join(src, pat % i))
+            if d:
+                out.append(f"| {i} | {st} | {d['ms_per_step']} | {d['roofline']['kernel_ms']} | {d['roofline']['frac']} | {d['config'].get('output_placement', {}).get('trials_ms')} |")
+    open(os.path.join(P, f"{tag}_fresh_processes.md"), "w").write("\n".join(out) + "\n")
+    # ---- batch
+    out = [f"# {tag}: batched small tiles (tools/bench_batch.py; 100 x 100 x 285 tiles, deg 3)\n"]
+    for name in ("batch_f32.json", "batch_u16.json", "batch_f32_t64.json"):
+        d = jload(os.path.join(src, name))
+        if d:
+            out.append(f"`{name}`: " + json.dumps(d) + "\n")
+    ks = kstats(os.path.join(src, "trace_batch"))
+    if ks:
+        out += ["Per kernel, `rocprofv3 --kernel-trace --stats -- python3 tools/bench_batch.py --tiles 256 --no-loop --rounds 2`:\n",
+                "| kernel | calls | avg us | min us | max us |", "|---|---|---|---|---|"]
+        out += [f"| `{n}` | {c} | {a:.2f} | {lo:.2f} | {hi:.2f} |" for n, c, a, lo, hi in ks]
+    b = pmc_bytes(os.path.join(src, "pmc_batch"), "srf_kernel<3, true, true, 64, true, true>")
+    if b:
+        algo = 256 * 10000 * (285 * 4 + 12 * 4 + 12 * 4)
+        out.append(f"\nHBM traffic of the batched K1+K2 launch (T = 256): read {b[0]/1e6:.1f} MB + write {b[1]/1e6:.1f} MB = {(b[0]+b[1])/1e6:.1f} MB "
+                   f"against {algo/1e6:.1f} MB algorithmic (cube + targets + planes) = {(b[0]+b[1])/algo:.3f}x.")
+    open(os.path.join(P, f"{tag}_batch_tiles.md"), "w").write("\n".join(out) + "\n")
+    # ---- u16
+    out = [f"# {tag}: uint16 tiles (bench.py --cube u16 [--u16-fast])\n", "| run | ms/step | K1+K2 ms | frac of 8 TB/s on cube bytes |", "|---|---|---|---|"]
+    for name in ("bench_u16.json", "bench_u16_fast.json"):
+        d = jload(os.path.join(src, name))
+        if d:
+            out.append(f"| {name} | {d['ms_per_step']} | {d['roofline']['kernel_ms']} | {d['roofline']['frac']} |")
+    ks = kstats(os.path.join(src, "trace_u16"))
+    if ks:
+        out += ["\n| kernel (rocprofv3) | calls | avg us | min us | max us |", "|---|---|---|---|---|"]
+        out += [f"| `{n}` | {c} | {a:.2f} | {lo:.2f} | {hi:.2f} |" for n, c, a, lo, hi in ks]
+    b = pmc_bytes(os.path.join(src, "pmc_u16"), "srf_u16_ring_kernel<3")
+    if b:
+        out.append(f"\nHBM traffic of the uint16 K1+K2 launch: read {b[0]/1e6:.1f} MB + write {b[1]/1e6:.1f} MB = {(b[0]+b[1])/1e6:.1f} MB "
+                   f"(algorithmic: 597.7 MB cube + 50.3 MB targets + 50.3 MB planes = 698.3 MB).")
+        tf = os.path.join(P, "traffic.json")
+        t = json.load(open(tf)) if os.path.isfile(tf) else {}
+        t["srf_u16_kernel_hbm_bytes_per_launch"] = int(b[0] + b[1])
+        t["source_u16"] = f"profiles/{tag}_u16_tiles.md (separate --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py --cube u16)"
+        json.dump(t, open(tf, "w"), indent=1)
+    open(os.path.join(P, f"{tag}_u16_tiles.md"), "w").write("\n".join(out) + "\n")
+    # ---- rehearsals
+    out = [f"# {tag}: multi-rank control flow rehearsed on one GPU\n"]
+    d = jload(os.path.join(src, "bench_gloo4.json"))
+    if d:
+        out.append("4 ranks, `--backend gloo --same-device` (256 x 256 tiles): " + json.dumps({k: d[k] for k in ("value", "n_gpus", "ms_per_step", "degraded") if k in d}) + "\n")
+    e = os.path.join(src, "two_ranks_one_gpu.err")
+    if os.path.isfile(e):
+        msg = [l for l in open(e) if "[bench]" in l]
+        out.append("2 ranks over RCCL on a 1-GPU box: " + (msg[0].strip() if msg else "(no message)") + "\n")
+    d = jload(os.path.join(src, "bench_force_exchange.json"))
+    if d:
+        out.append("one-rank RCCL all-reduce in the loop, pipelined submit(): " + json.dumps({"ms_per_step": d["ms_per_step"], "kernel_ms": d["roofline"]["kernel_ms"], "pipeline": d["config"]["pipeline"]}) + "\n")
+    d = jload(os.path.join(src, "bench_mosaic8.json"))
+    if d:
+        out.append("8 x 1024 x 1024 x 285 tiles resident on one GPU, one global fit per step (`--tiles-per-gpu 8`): " +
+                   json.dumps({"value": d["value"], "ms_per_step": d["ms_per_step"], "step_frac_of_peak": d["roofline"]["step_frac_of_peak"]}) + "\n")
+    open(os.path.join(P, f"{tag}_rehearsals.md"), "w").write("\n".join(out) + "\n")
+    for name, dst in (("feed.log", f"{tag}_feed.md"), ("k1_stamps.log", f"{tag}_k1_phase_stamps.log"), ("placement_probe.log", f"{tag}_placement_probe.log"),
+                      ("state_probe.log", f"{tag}_state_probe.log")):
+        s = os.path.join(src, name)
+        if os.path.isfile(s):
+            txt = "".join(l for l in open(s, errors="replace") if "amdgpu.ids" not in l and "Warning" not in l)
+            open(os.path.join(P, dst), "w").write(("```\n" + txt + "```\n") if dst.endswith(".md") else txt)
+    print("profiles written:", sorted(x for x in os.listdir(P) if x.startswith(tag)))
+
+
+if __name__ == "__main__":
+    main()

@@ -437,8 +437,8 @@ class TileBatch:
         cands, spacers, times, best = [self.pseudo], [], [], None
         for i in range(trials):
             if i > 0:
-                try:                                   # candidates 2 GB apart: the speed belongs to a REGION of memory
-                    spacers.append(torch.empty(1 << 31, dtype=torch.uint8, device=self.device))
+                try:                                   # candidates 4 GB apart: the speed belongs to a REGION of memory
+                    spacers.append(torch.empty(1 << 32, dtype=torch.uint8, device=self.device))
                     cands.append(torch.empty_like(cands[0]))
                 except RuntimeError:
                     break

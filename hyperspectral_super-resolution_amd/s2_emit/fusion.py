@@ -164,7 +164,8 @@ class SpectralFusion:
         """Time K1 on candidate output images and keep the fastest.  What decides the speed is the REGION of device
         memory the image lands in (a 3 GB arena: offsets below 2 GB fast, above slow, a step, not a period -
         profiles/r02_two_speeds.md), and back-to-back allocations of 48 MB land in the same region, so successive
-        candidates are separated by a 2 GB spacer allocation that is held until the trials end."""
+        candidates are separated by a 4 GB spacer allocation that is held until the trials end (in a 40 GB arena the
+        slow stretch was its last 8 GB, for two different cubes alike)."""
         torch = nat.require_gpu()
         nb = self.table.nb
         stream = torch.cuda.current_stream(self.device)
@@ -174,7 +175,7 @@ class SpectralFusion:
         for i in range(self.placement_trials):
             if i > 0:
                 try:
-                    spacers.append(torch.empty(1 << 31, dtype=torch.uint8, device=self.device))
+                    spacers.append(torch.empty(1 << 32, dtype=torch.uint8, device=self.device))
                     cands.append(eng.alloc_image(torch, nb, npix, self.layout, self.device))
                 except RuntimeError:          # out of memory: settle for what has been seen
                     break

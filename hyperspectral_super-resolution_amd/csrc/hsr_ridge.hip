@@ -558,6 +558,80 @@ __global__ __launch_bounds__(256, 2) void predict103_kernel(const PredArgs a) {
   }
 }
 
+// Many targets (T > 96, e.g. EMIT's 285 bands): the chunked path above re-stages the whole 329 KB of W through LDS for
+// every 128-pixel tile, with nine barriers per tile, and sat at 39 % of the f32-MFMA peak against 50 % for T <= 32 where
+// W is resident.  W does not fit one LDS, but a SLICE of 96 targets does (286 x 96 x 4 = 110 KB): blockIdx.y picks the
+// slice, the slice is staged once per workgroup and stays for the whole launch, and the workgroup (8 waves = 2 per
+// SIMD, each wave its own 32 pixels) walks the pixel tiles with no staging and no barrier in the loop.  The monomials
+// of a pixel are recomputed once per slice (2-4 v_mul per MFMA step of 3 x 64 cycles: free) and its 10 inputs re-read
+// (40 B per slice: nothing).  3 accumulator tiles per wave instead of 9.
+constexpr int kSliceTT = 3;
+__global__ __launch_bounds__(512, 2) void predict103_slice_kernel(const PredArgs a) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* wl = reinterpret_cast<float*>(smem);
+  constexpr int TT = kSliceTT, Tp = TT * 32;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int j = lane & 31, kh = lane >> 5;
+  const int t0 = blockIdx.y * Tp;                   // first target of this workgroup's slice
+  for (int i = t; i < 286 * Tp; i += 512) {
+    const int r = i / Tp, c = i % Tp;
+    wl[i] = t0 + c < a.T ? a.W[(size_t)r * a.ldw + t0 + c] : 0.0f;
+  }
+  __syncthreads();
+  for (int64_t tile = blockIdx.x; tile * 256 < a.npix; tile += gridDim.x) {
+    const int64_t p = tile * 256 + wave * 32 + j;
+    const int64_t pc = p < a.npix ? p : a.npix - 1;
+    float z[11];
+#pragma unroll
+    for (int c = 0; c < 10; ++c) z[c] = (a.x[pc * a.x_ps + c * a.x_cs] - a.mean[c]) * a.inv[c];
+    z[10] = 1.0f;
+    f32x16 acc[TT];
+#pragma unroll
+    for (int q = 0; q < TT; ++q)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
+    mfma_steps103<0, kSteps103, TT>(z, kh, wl, Tp, 0, j, acc);
+    if (p < a.npix) {
+      int64_t ostride = a.out_stride;
+      int tmax = a.T;
+      asm volatile("" : "+s"(ostride), "+s"(tmax));        // keep the addressing inside the loop (see predict103_kernel)
+      float* orow = a.out + (size_t)(t0 + 4 * kh) * ostride + p;
+#pragma unroll
+      for (int q = 0; q < TT; ++q) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int tu = q * 32 + (r & 3) + 8 * (r >> 2);
+          const int trg = t0 + tu + 4 * kh;
+          if (trg < tmax) {
+            float v = acc[q][r] + a.bias[trg];
+            if (a.act) {
+              v = v < -50.0f ? -50.0f : (v > 50.0f ? 50.0f : v);
+              v = 1.0f / (1.0f + __expf(-v));
+            }
+            orow[(size_t)tu * ostride] = v;
+          }
+        }
+      }
+    }
+  }
+}
+
+static void launch_predict103_slices(const PredArgs& a, hipStream_t s) {
+  const size_t lds = (size_t)286 * kSliceTT * 32 * 4;
+  static thread_local bool configured = false;
+  if (!configured) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(predict103_slice_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipGetLastError();
+    configured = true;
+  }
+  const int slices = (a.T + kSliceTT * 32 - 1) / (kSliceTT * 32);
+  int64_t tiles = (a.npix + 255) / 256;
+  int gx = 256 / slices;                       // one workgroup per CU in all (110 KB of LDS each)
+  if (gx < 1) gx = 1;
+  if (tiles < gx) gx = (int)tiles;
+  hipLaunchKernelGGL(predict103_slice_kernel, dim3(gx, slices), dim3(512), lds, s, a);
+}
+
 template <int TT, bool WHOLE>
 static void launch_predict103(const PredArgs& a, hipStream_t s) {
   const size_t lds = WHOLE ? (size_t)286 * TT * 32 * 4 : (size_t)2 * kChunkRows * TT * 32 * 4;
@@ -580,8 +654,7 @@ static bool try_predict103(const PredArgs& a, hipStream_t s) {
   if (tt == 1) launch_predict103<1, true>(a, s);          // T <= 32: W resident (36.6 KB)
   else if (tt == 2) launch_predict103<2, false>(a, s);
   else if (tt <= 3) launch_predict103<3, false>(a, s);
-  else if (tt <= 5) launch_predict103<5, false>(a, s);
-  else if (tt <= 9) launch_predict103<9, false>(a, s);     // T <= 288 (EMIT's 285 bands)
+  else if (tt <= 16) launch_predict103_slices(a, s);       // T <= 512 (EMIT's 285 bands: three slices of 96)
   else return false;
   return true;
 }

@@ -1673,3 +1673,26 @@ def test_stream_envi_files_bil_bsq_bit_exact_with_bip_feed(torch_gpu, tmp_path):
     for depth in (1, 3):
         got = [c.copy() for _, c, _, _ in plan.stream([(f, real), (cube, real), (f, real)], depth=depth)]
         assert np.array_equal(got[0], got[1]) and np.array_equal(got[1], got[2])
+
+
+def test_placement_trials_do_not_change_results(torch_gpu):
+    """SpectralFusion's placement trials for the images it owns (profiles/r02_two_speeds.md: K1 is ~9 % slower when its
+    output image lies in some stretches of device memory) only choose WHICH allocation is kept: results are bit-identical
+    with and without them, the log shows what was timed, and small tiles skip the trials."""
+    torch = torch_gpu
+    from s2_emit import SpectralFusion
+    from s2_emit.synthetic import device_problem
+    p = device_problem(384, 256, 285, deg=3, seed=12)          # 98 304 pixels: above the 65 536-pixel threshold
+    a = SpectralFusion(p.emit_w, p.srf, p.good_mask, deg=3, placement_trials=0)
+    b = SpectralFusion(p.emit_w, p.srf, p.good_mask, deg=3, placement_trials=3)
+    oa, ob = a.step(p.cube, p.real), b.step(p.cube, p.real)
+    torch.cuda.synchronize()
+    assert a.placement_log == {} and 2 <= len(b.placement_log[384 * 256]) <= 3
+    assert torch.equal(oa.coeffs.view(torch.int64), ob.coeffs.view(torch.int64))
+    assert torch.equal(oa.matched.view(torch.int32), ob.matched.view(torch.int32))
+    assert torch.equal(oa.pseudo.view(torch.int32), ob.pseudo.view(torch.int32))
+    ob2 = b.step(p.cube, p.real)                                  # second step: no more trials, same buffers
+    assert ob2.pseudo.data_ptr() == ob.pseudo.data_ptr() and len(b.placement_log) == 1
+    small = device_problem(64, 64, 285, deg=3, seed=13)
+    b.step(small.cube, small.real)
+    assert 64 * 64 not in b.placement_log

@@ -434,7 +434,12 @@ __global__ __launch_bounds__(256) void apply_planar_kernel(const ApplyArgs a) {
 template <int Q, int N, bool BATCH>
 __global__ __launch_bounds__(256) void apply_rows_kernel(const ApplyArgs a, const hsr_batch_tile* __restrict__ tiles,
                                                          int use_mask) {
-  constexpr int U = 4;                  // independent 16-byte loads in flight per thread
+#ifndef HSR_K3_U
+#define HSR_K3_U 16
+#endif
+  // independent 16-byte loads in flight per thread.  A/B on one box at 1024 x 1024 x 12 (tools/dbg/k3_time.py):
+  // U = 4: 25.0 us, 8: 22.1, 12: 22.7, 16: 19.0 (768 workgroups = 3 per CU in one round), 20: 21.7, 24: 24.0, 32: 23.2
+  constexpr int U = HSR_K3_U;
   const bool has_poly = a.coeffs != nullptr;
   const bool st = a.lohi != nullptr;
   const float* x = a.x;
@@ -770,7 +775,7 @@ extern "C" int hsr_poly_apply(const float* x_dev, int64_t x_bs, int64_t x_ps, co
     if (aligned && (x_ps & 3) == 0 && q >= 1 && q <= 4 && npix * q < ((int64_t)1 << 31)) {
       // one pass when it fits (4 x 16 B per thread): no grid-stride tail imbalance on a ~20 us kernel.  The
       // grid is a multiple of 3 workgroups so that the stride is a multiple of every Q (lane <-> channel group fixed).
-      int64_t gb = (npix * q + 256 * 4 - 1) / (256 * 4);
+      int64_t gb = (npix * q + 256 * HSR_K3_U - 1) / (256 * HSR_K3_U);
       if (gb > 8190) gb = 2046;
       gb = (gb + 2) / 3 * 3;
       const dim3 grid((unsigned)gb);
@@ -839,7 +844,7 @@ extern "C" int hsr_poly_apply_batched(const hsr_batch_tile* tiles_dev, int32_t n
   const int64_t q = row >> 2;
   HSR_REQUIRE(max_npix >= 1 && max_npix * q < ((int64_t)1 << 31), HSR_ERR_UNSUPPORTED, "hsr_poly_apply_batched: max_npix=%lld", (long long)max_npix);
   ApplyArgs a{nullptr, 1, row, nullptr, coeffs_dev, nullptr, nb, deg, clip, 0, nullptr, 1, row};
-  int64_t gb = (max_npix * q + 256 * 4 - 1) / (256 * 4);
+  int64_t gb = (max_npix * q + 256 * HSR_K3_U - 1) / (256 * HSR_K3_U);
   if (gb > 2046) gb = 2046;
   gb = (gb + 2) / 3 * 3;
   int rc = launch_apply_rows<true>(a, tiles_dev, use_mask, (int)q, deg, dim3((unsigned)gb, (unsigned)ntiles), (hipStream_t)stream);

@@ -454,8 +454,6 @@ class TileBatch:
             times.append(min(t))
             if best is None or times[-1] < times[best]:
                 best = i
-            if i >= 1 and times[best] < 0.93 * max(times):
-                break
         del spacers
         if cands[best] is not self.pseudo:
             self._build(cands[best])

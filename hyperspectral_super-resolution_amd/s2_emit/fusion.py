@@ -160,23 +160,20 @@ class SpectralFusion:
             self._buf[npix] = (pseudo, eng.alloc_image(torch, nb, npix, self.layout, self.device))
         return self._buf[npix]
 
-    def _place(self, npix: int, first, probe):
-        """Time K1 on candidate output images and keep the fastest.  What decides the speed is the REGION of device
-        memory the image lands in (a 3 GB arena: offsets below 2 GB fast, above slow, a step, not a period -
-        profiles/r02_two_speeds.md), and back-to-back allocations of 48 MB land in the same region, so successive
-        candidates are separated by a 4 GB spacer allocation that is held until the trials end (in a 40 GB arena the
-        slow stretch was its last 8 GB, for two different cubes alike)."""
+    def _trials(self, first, make, probe):
+        """Placement trials: ``first`` and up to placement_trials - 1 further candidates from ``make()``, each 4 GB apart
+        (a spacer allocation held until the end: the speed belongs to a REGION of device memory, and back-to-back
+        allocations land in the same region), ``probe(candidate)`` enqueues one K1 launch using the candidate; one
+        untimed and two timed launches each; returns (fastest candidate, times)."""
         torch = nat.require_gpu()
-        nb = self.table.nb
         stream = torch.cuda.current_stream(self.device)
         cands, spacers, times = [first], [], []
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        best = None
-        for i in range(self.placement_trials):
+        for i in range(max(1, self.placement_trials)):
             if i > 0:
                 try:
                     spacers.append(torch.empty(1 << 32, dtype=torch.uint8, device=self.device))
-                    cands.append(eng.alloc_image(torch, nb, npix, self.layout, self.device))
+                    cands.append(make())
                 except RuntimeError:          # out of memory: settle for what has been seen
                     break
             c = cands[-1]
@@ -189,15 +186,50 @@ class SpectralFusion:
                 e1.synchronize()
                 t.append(e0.elapsed_time(e1))
             times.append(min(t))
-            if best is None or times[-1] < times[best]:
-                best = i
-            # the two groups are 8-10 % apart but up to 4 % wide: stop only on a gap that cannot be in-group spread
-            if i >= 1 and times[best] < 0.93 * max(times):
-                break
-        self.placement_log[npix] = [round(t, 4) for t in times]
+        best = min(range(len(times)), key=times.__getitem__)
         keep = cands[best]
         del cands, spacers
+        return keep, [round(t, 4) for t in times]
+
+    def _place(self, npix: int, first, probe):
+        """Time K1 on candidate output images and keep the fastest (profiles/r02_two_speeds.md: in a 3 GB arena offsets
+        below 2 GB were fast and above slow - a step, not a period; in a 40 GB arena the slow stretch was its last 8 GB,
+        for two different cubes alike)."""
+        torch = nat.require_gpu()
+        keep, times = self._trials(first, lambda: eng.alloc_image(torch, self.table.nb, npix, self.layout, self.device), probe)
+        self.placement_log[npix] = times
         return keep
+
+    def place_inputs(self, cube, real, mask=None):
+        """Placement trials for a tile that stays resident and is processed many times (a benchmark loop, a resident
+        mosaic).  step() by itself only places the images the plan owns; but the stretches of device memory that slow K1's
+        write stream slow its read streams too, and the effects do not add (one slow operand costs the same 9 % as
+        three), so a search over one operand at a time sees nothing while another one sits in a slow stretch.  This
+        searches JOINTLY: candidate set i = (cube clone, real clone, output image) allocated back to back - one region -
+        with 4 GB between sets; set 0 is the caller's tensors with a fresh output image.  One untimed and two timed K1
+        launches per set; the fastest set's cube and real are returned and its output image becomes the plan's image for
+        this tile size (so step() runs no further trial).  Same bytes, so results are bit-identical.
+        Returns (cube, real, log)."""
+        torch = nat.require_gpu()
+        npix = cube.numel() // cube.shape[-1]
+        if self.placement_trials <= 1 or npix in self._buf:
+            return cube, real, {}
+        nb = self.table.nb
+
+        def make():
+            return (cube.clone(), real.clone(), eng.alloc_image(torch, nb, npix, self.layout, self.device))
+
+        def k1(cand):
+            c, r, o = cand
+            rr, rl = self._real_image(r, npix)
+            eng.srf_integrate_moments(c, self.table, rr, self.deg, self.ws, mask, self.min_valid, self.min_valid, out=o,
+                                      reduce=False, layout=self.layout, real_layout=rl, scale=self.tile_scale,
+                                      nodata=self.tile_nodata, opts=self.opts)
+        first = (cube, real, eng.alloc_image(torch, nb, npix, self.layout, self.device))
+        (cube, real, out), times = self._trials(first, make, k1)
+        self._buf[npix] = (out, eng.alloc_image(torch, nb, npix, self.layout, self.device))
+        self.placement_log[npix] = times
+        return cube, real, {"joint_ms": times}
 
     def _exchanges(self) -> bool:
         import torch.distributed as dist

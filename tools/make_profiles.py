@@ -76,7 +76,7 @@ def main():
         for i in range(1, 7):
             d = jload(os.path.join(src, pat % i))
             if d:
-                out.append(f"| {i} | {st} | {d['ms_per_step']} | {d['roofline']['kernel_ms']} | {d['roofline']['frac']} | {d['config'].get('output_placement', {}).get('trials_ms')} |")
+                out.append(f"| {i} | {st} | {d['ms_per_step']} | {d['roofline']['kernel_ms']} | {d['roofline']['frac']} | {d['config'].get('placement', {}).get('trials_ms')} |")
     open(os.path.join(P, f"{tag}_fresh_processes.md"), "w").write("\n".join(out) + "\n")
     # ---- batch
     out = [f"# {tag}: batched small tiles (tools/bench_batch.py; 100 x 100 x 285 tiles, deg 3)\n"]

@@ -77,6 +77,8 @@ def parse_args():
     ap.add_argument("--u16-fast", action="store_true",
                     help="with --cube u16: the opt-in fast arithmetic of the uint16 kernel (HSR_SRF_U16_FAST; 1e-6 relative "
                          "off the bit-exact path)")
+    ap.add_argument("--fused-fit", action="store_true",
+                    help="slot reduction + solve inside K1's launch (hsr_srf_integrate_fit); measured 3 us/step slower, off by default")
     ap.add_argument("--no-input-placement", action="store_true",
                     help="keep the synthetic cube / target where the allocator first put them (no placement trials for inputs)")
     ap.add_argument("--event-every", type=int, default=4,
@@ -241,7 +243,7 @@ def main():
                           coeff_sync=args.coeff_sync if (world > 1 or args.force_exchange) else "local",
                           force_exchange=args.force_exchange,
                           reserved_cus=args.reserve_cus if pipelined else 0,   # CUs kept free for the side stream
-                          u16_fast=args.u16_fast)
+                          u16_fast=args.u16_fast, fused_fit=args.fused_fit)
     real = prob.real            # (H, W, row) band-last, like the cube and the reference's (H, W, C) images
     cube = prob.cube
     if args.cube == "u16":      # quantise once, outside the timed region (the writer's arithmetic, on the device)
@@ -359,6 +361,7 @@ def main():
                            "tiles_per_gpu": ntl, "coeff_sync": (args.coeff_sync if world > 1 else "none") +
                            (f" (rehearsal: one-rank RCCL {args.coeff_sync} forced)" if args.force_exchange else ""),
                            "pipeline": f"one tile deep, {args.reserve_cus} CUs reserved" if pipelined else "off",
+                           "launches_per_step": 2 if (args.fused_fit and world == 1 and not args.force_exchange and ntl == 1) else None,
                            "placement": {"trials_ms": plan.placement_log.get(H * W), "joint_with_inputs": input_log is not None,
                                          "note": "before the warm-up K1 is timed on a few candidate allocations, 4 GB apart, of "
                                                  "(cube copy, target copy, output image); the fastest set is kept "

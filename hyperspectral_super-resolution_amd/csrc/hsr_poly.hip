@@ -9,6 +9,7 @@
 #include <string.h>
 
 #include "hsr_common.h"
+#include "hsr_solve.h"
 
 namespace hsr {
 
@@ -152,146 +153,6 @@ __global__ __launch_bounds__(256) void reduce_kernel(const double* __restrict__ 
   for (int row = blockIdx.x * 4 + (threadIdx.x >> 6); row < nrows; row += gridDim.x * 4) {
     const double s = row_sum(partials + row, slots, nrows, lane);
     if (lane == 0) moments[row] = s;
-  }
-}
-
-// ------------------------------------------------------------------------------------------------
-// solve: np.polyfit from the moments
-// ------------------------------------------------------------------------------------------------
-// np.polyfit(x, y, deg): V = vander(x, deg+1) (highest power first), s_j = ||V[:,j]||, least squares
-// of (V/s) c' = y by SVD with rcond = len(x)*eps, c = c'/s.  From the moments:
-//   A_jk = S_{(d-j)+(d-k)} / (s_j s_k),  s_j = sqrt(S_{2(d-j)}),  rhs_j = T_{d-j} / s_j,
-// eigen-decompose A (cyclic Jacobi, <= 5x5) and apply the pseudo-inverse keeping the eigenvalues
-// above rcond^2 * max (singular values of V/s are the square roots).
-// Rank-revealing path: symmetric cyclic Jacobi on the scaled Gram, pseudo-inverse with NumPy's cut-off.
-__host__ __device__ inline void solve_band_jacobi(double (&A)[HSR_MAX_DEG + 1][HSR_MAX_DEG + 1],
-                                                  const double* rhs, const double* s, int n, double count,
-                                                  double* coef) {
-  double V[HSR_MAX_DEG + 1][HSR_MAX_DEG + 1];
-  for (int j = 0; j < n; ++j)
-    for (int k = 0; k < n; ++k) V[j][k] = j == k ? 1.0 : 0.0;
-  for (int sweep = 0; sweep < 40; ++sweep) {
-    double off = 0.0, diag = 0.0;
-    for (int p = 0; p < n; ++p) {
-      diag += A[p][p] * A[p][p];
-      for (int q = p + 1; q < n; ++q) off += A[p][q] * A[p][q];
-    }
-    if (off <= 1e-36 * diag) break;
-    for (int p = 0; p < n; ++p) {
-      for (int q = p + 1; q < n; ++q) {
-        const double apq = A[p][q];
-        if (fabs(apq) < 1e-300) continue;
-        const double theta = (A[q][q] - A[p][p]) / (2.0 * apq);
-        const double tt = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
-        const double c = 1.0 / sqrt(tt * tt + 1.0), sn = tt * c;
-        for (int k = 0; k < n; ++k) {
-          const double akp = A[k][p], akq = A[k][q];
-          A[k][p] = c * akp - sn * akq;
-          A[k][q] = sn * akp + c * akq;
-        }
-        for (int k = 0; k < n; ++k) {
-          const double apk = A[p][k], aqk = A[q][k];
-          A[p][k] = c * apk - sn * aqk;
-          A[q][k] = sn * apk + c * aqk;
-        }
-        for (int k = 0; k < n; ++k) {
-          const double vkp = V[k][p], vkq = V[k][q];
-          V[k][p] = c * vkp - sn * vkq;
-          V[k][q] = sn * vkp + c * vkq;
-        }
-      }
-    }
-  }
-  double lmax = 0.0;
-  for (int i = 0; i < n; ++i) lmax = A[i][i] > lmax ? A[i][i] : lmax;
-  const double rcond = count * 2.220446049250313e-16;
-  const double thresh = rcond * rcond * lmax;
-  for (int j = 0; j < n; ++j) coef[j] = 0.0;
-  for (int i = 0; i < n; ++i) {
-    const double lam = A[i][i];
-    if (!(lam > thresh)) continue;
-    double proj = 0.0;
-    for (int k = 0; k < n; ++k) proj += V[k][i] * rhs[k];
-    proj /= lam;
-    for (int j = 0; j < n; ++j) coef[j] += V[j][i] * proj;
-  }
-  for (int j = 0; j < n; ++j) coef[j] /= s[j];
-}
-
-// Fast path: Cholesky of the scaled Gram with every loop unrolled (N is a template constant, so the
-// whole factorisation lives in registers).  A pivot below 1e-13 (the scaled diagonal is exactly 1, so
-// this is cond(V/s) > ~3e6) hands the band to the rank-revealing Jacobi path, which reproduces
-// np.polyfit's singular-value cut-off; above it both paths agree to ~cond * eps.
-template <int DEG>
-__host__ __device__ inline void solve_band_t(const double* mom, long long min_count, double* coef) {
-  constexpr int n = DEG + 1;
-  const double* S = mom;
-  const double* T = mom + 2 * DEG + 1;
-  const double count = S[0];
-  if (!(count >= (double)min_count) || count < 1.0) {  // reference fallback: identity polynomial
-#pragma unroll
-    for (int j = 0; j < n; ++j) coef[j] = j == n - 2 ? 1.0 : 0.0;
-    return;
-  }
-  double s[HSR_MAX_DEG + 1], A[HSR_MAX_DEG + 1][HSR_MAX_DEG + 1], rhs[HSR_MAX_DEG + 1];
-#pragma unroll
-  for (int j = 0; j < n; ++j) {
-    const double d = S[2 * (DEG - j)];
-    s[j] = d > 0.0 ? sqrt(d) : 1.0;
-  }
-#pragma unroll
-  for (int j = 0; j < n; ++j) {
-    rhs[j] = T[DEG - j] / s[j];
-#pragma unroll
-    for (int k = 0; k < n; ++k) A[j][k] = S[(DEG - j) + (DEG - k)] / (s[j] * s[k]);
-  }
-  double L[n][n];
-  bool ok = true;
-#pragma unroll
-  for (int j = 0; j < n; ++j) {
-    double d = A[j][j];
-#pragma unroll
-    for (int k = 0; k < j; ++k) d -= L[j][k] * L[j][k];
-    ok = ok && (d > 1e-13);
-    const double ljj = sqrt(d > 1e-13 ? d : 1.0);
-    L[j][j] = ljj;
-#pragma unroll
-    for (int i = j + 1; i < n; ++i) {
-      double v = A[i][j];
-#pragma unroll
-      for (int k = 0; k < j; ++k) v -= L[i][k] * L[j][k];
-      L[i][j] = v / ljj;
-    }
-  }
-  if (ok) {
-    double z[n];
-#pragma unroll
-    for (int i = 0; i < n; ++i) {
-      double v = rhs[i];
-#pragma unroll
-      for (int k = 0; k < i; ++k) v -= L[i][k] * z[k];
-      z[i] = v / L[i][i];
-    }
-#pragma unroll
-    for (int i = n - 1; i >= 0; --i) {
-      double v = z[i];
-#pragma unroll
-      for (int k = i + 1; k < n; ++k) v -= L[k][i] * z[k];
-      z[i] = v / L[i][i];
-    }
-#pragma unroll
-    for (int j = 0; j < n; ++j) coef[j] = z[j] / s[j];
-    return;
-  }
-  solve_band_jacobi(A, rhs, s, n, count, coef);
-}
-
-__host__ __device__ inline void solve_band(const double* mom, int deg, long long min_count, double* coef) {
-  switch (deg) {
-    case 1: solve_band_t<1>(mom, min_count, coef); break;
-    case 2: solve_band_t<2>(mom, min_count, coef); break;
-    case 3: solve_band_t<3>(mom, min_count, coef); break;
-    default: solve_band_t<4>(mom, min_count, coef); break;
   }
 }
 

@@ -33,6 +33,7 @@
 // single-tile launch because a tile's slot layout and every summation order depend on its npix only.
 // HBM-bound by construction: 4*B bytes in, 4*nb (+4*nb+1) bytes out/in per pixel, ~0.35 kflop.
 #include "hsr_common.h"
+#include "hsr_solve.h"
 
 namespace hsr {
 
@@ -49,7 +50,18 @@ constexpr int kWeightCap = 1024;  // floats of LDS reserved for compact weight t
 typedef hsr_batch_unit SrfUnit;
 static_assert(sizeof(SrfUnit) == 64 && sizeof(hsr_batch_tile) == 64, "batch records are 64 bytes");
 
+// Fused fit (hsr_fused_fit, single-tile launches): the workgroup that completes a group of slots reduces it, the one
+// that completes the last group reduces the groups, solves and writes moments + coefficients (fused_fit below).
+struct SrfFit {
+  double* gpart;      // [64][nb][M] group sums
+  int32_t* tickets;   // [65] arrival counters, zero between launches; NULL: no fused fit
+  double* moments;    // [nb][M]
+  double* coeffs;     // [nb][deg+1]
+  long long min_count;
+};
+
 struct SrfArgs {
+  SrfFit fit;
   SrfUnit one;            // single-tile launch: the tile (slot = blockIdx.x, part_dev = base of slot 0); partials [slot][band][moment]
   const SrfUnit* units;   // batch launch: the unit table (device)
   int32_t nunits;
@@ -269,7 +281,9 @@ __device__ __forceinline__ void merge_level(double (&v)[NMAX]) {
 }
 
 // Reduce the per-lane power sums of a finished work unit, write them to its partial slot and clear them.
-template <int M, int P, bool LANE_IS_PIXEL>
+// COHERENT: the stores are agent-scope (write-through, `sc1`): another workgroup - on another XCD, behind another L2 -
+// may read the slot in the same launch (fused_fit) without an L2 write-back in between.
+template <int M, int P, bool LANE_IS_PIXEL, bool COHERENT>
 __device__ __forceinline__ void flush_moments(double (&acc_m)[2][M], const bool (&bval)[2], const int (&bidx)[2],
                                               double* part, int lane) {
   constexpr int N = 2 * M;
@@ -308,8 +322,13 @@ __device__ __forceinline__ void flush_moments(double (&acc_m)[2][M], const bool 
       valid = valid && i < N;
     }
     const bool second = i >= M;                            // i = j * M + m
-    if (valid && (second ? bval[1] : bval[0]))
-      part[(size_t)(second ? bidx[1] : bidx[0]) * M + (i - (second ? M : 0))] = v[q];   // slot-major partials: [slot][band][moment]
+    if (valid && (second ? bval[1] : bval[0])) {
+      double* dst = part + (size_t)(second ? bidx[1] : bidx[0]) * M + (i - (second ? M : 0));   // slot-major partials: [slot][band][moment]
+      if (COHERENT)
+        __hip_atomic_store(dst, v[q], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else
+        *dst = v[q];
+    }
   }
 }
 
@@ -320,6 +339,84 @@ __device__ __forceinline__ void zero_stage_pad(float* ostage, int npixels, int n
   const int padc = ops - nb;
   if (padc <= 0) return;
   for (int i = t; i < npixels * padc; i += T) ostage[(i / padc) * ops + nb + (i % padc)] = 0.0f;
+}
+
+// Tail of a single-tile K1+K2 launch with a.fit set: the slot reduction and the solve without a second launch.
+// The summation tree is the one of row_sum (hsr_poly.hip) - lane l of a wave adds slots l, l+64, ... in order, then
+// the xor butterfly 32,16,..,1 over the 64 lanes - cut at the lane sums: the 64 "lanes" are 64 GROUPS of slots
+// (group = slot mod 64).  The workgroup whose ticket completes a group adds that group's slots (level A, one thread per
+// (band, moment) row, coalesced over rows) into gpart; the workgroup whose ticket completes the groups runs the
+// butterfly over the 64 group sums (level B, one wave per row), writes the moments, solves the bands (same
+// solve_band_t as every other path; its Jacobi matrices in LDS) and re-arms the tickets.  Same tree, same adds ->
+// the bits of hsr_moments_reduce_solve on the same partials.
+// Visibility between workgroups on different XCDs (each behind its own L2): every value that crosses is stored and
+// loaded at agent scope (`sc1`: write-through / read-through), the writers wait for their stores (vmcnt(0)) before the
+// barrier that precedes the ticket.  (A release/acquire fence pair instead - buffer_wbl2 / buffer_inv in each of the
+// 512 workgroups, with the output image's dirty lines in L2 - cost 40 us per launch.)
+__device__ __forceinline__ double ld_agent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_agent(double* p, double v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void stores_done_barrier() {
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+}
+
+template <int DEG>
+__device__ __forceinline__ void fused_fit(const SrfFit& f, const double* part, int S, int nb, unsigned char* lds, int t) {
+  constexpr int M = moment_count(DEG);
+  const int R = nb * M;                      // rows, <= 224
+  const int grp = (int)blockIdx.x & 63;
+  int* flag = reinterpret_cast<int*>(lds);
+  double* mom = reinterpret_cast<double*>(lds + 64);
+  double* work = mom + HSR_MAX_BANDS * M;
+  stores_done_barrier();                     // every wave's partial stores are through; the LDS staging is dead
+  if (t == 0) {
+    const int expect = (S - grp + 63) >> 6;  // slots s < S with s mod 64 == grp
+    *flag = __hip_atomic_fetch_add(f.tickets + grp, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == expect - 1;
+  }
+  __syncthreads();
+  if (!*flag) return;
+  if (t < R) {                               // level A: row t of the slots grp, grp + 64, ... (row_sum's lane loop)
+    const double* row = part + t;
+    double s = 0.0;
+    for (int i0 = grp; i0 < S; i0 += 64 * 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + 64 * u;
+        v[u] = i < S ? ld_agent(row + (size_t)i * R) : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    st_agent(f.gpart + (size_t)grp * R + t, s);
+  }
+  stores_done_barrier();
+  const int ngroups = S < 64 ? S : 64;
+  if (t == 0) *flag = __hip_atomic_fetch_add(f.tickets + 64, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngroups - 1;
+  __syncthreads();
+  if (!*flag) return;
+  {                                          // level B: the butterfly over the 64 group sums, one wave per row
+    const int lane = t & 63, wave = t >> 6;
+    constexpr int RW = (HSR_MAX_BANDS * M + 7) / 8;   // rows per wave; all loads first (read-through: ~1 us each)
+    double v[RW];
+#pragma unroll
+    for (int k = 0; k < RW; ++k) {
+      const int r = wave + 8 * k;
+      v[k] = (r < R && lane < ngroups) ? ld_agent(f.gpart + (size_t)lane * R + r) : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < RW; ++k) {
+      const int r = wave + 8 * k;
+      const double s = wave_sum(v[k]);
+      if (lane == 0 && r < R) {
+        mom[r] = s;
+        f.moments[r] = s;
+      }
+    }
+  }
+  __syncthreads();
+  if (t < nb) solve_band_t<DEG, true>(mom + t * M, f.min_count, f.coeffs + (size_t)t * (DEG + 1), work + t * kSolveWork);
+  if (t < 65) __hip_atomic_store(f.tickets + t, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm: every other workgroup has drawn its tickets
 }
 
 template <int DEG, bool FAST, bool WLDS, int P, bool OUTV, bool BATCH>
@@ -443,7 +540,7 @@ __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
         __builtin_amdgcn_global_load_lds((gptr_t)unit_record_addr(a.units, nidx, a.nunits, lane), (lptr_t)ustage, 4, 0, 0);
       if (OUTV) flush_stage<8 * P>(ostage, prev_out, prev_pix0, prev_npx, ops, t);   // no-op before the first group
       if (BATCH && DEG > 0 && pend) {
-        flush_moments<M, P, true>(acc_m, bval, bidx, pend_part, lane);
+        flush_moments<M, P, true, !BATCH>(acc_m, bval, bidx, pend_part, lane);
         pend = false;
       }
     };
@@ -622,7 +719,9 @@ __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
   if (a.stamps && lane == 0)
     for (int k = 0; k < 8; ++k) a.stamps[((size_t)blockIdx.x * NW + wave) * 8 + k] = stamp_acc[k];
 #endif
-  if (DEG > 0 && pend) flush_moments<M, P, true>(acc_m, bval, bidx, pend_part, lane);
+  if (DEG > 0 && pend) flush_moments<M, P, true, !BATCH>(acc_m, bval, bidx, pend_part, lane);
+  if constexpr (DEG > 0 && !BATCH)
+    if (a.fit.tickets) fused_fit<DEG>(a.fit, a.one.part_dev, a.one.slots, a.nb, smem, t);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -848,7 +947,7 @@ __global__ __launch_bounds__(512, 4) void srf_u16_kernel(const SrfArgs a) {
         __builtin_amdgcn_global_load_lds((gptr_t)unit_record_addr(a.units, nidx, a.nunits, lane), (lptr_t)ustage, 4, 0, 0);
       if (OUTV) flush_stage<T>(ostage, prev_out, prev_pix0, prev_npx, ops, t);
       if (BATCH && DEG > 0 && pend) {
-        flush_moments<M, P, false>(acc_m, bval, bidx, pend_part, lane);
+        flush_moments<M, P, false, !BATCH>(acc_m, bval, bidx, pend_part, lane);
         pend = false;
       }
     };
@@ -920,7 +1019,9 @@ __global__ __launch_bounds__(512, 4) void srf_u16_kernel(const SrfArgs a) {
     lds_barrier();
   }
   if (OUTV) flush_stage<T>(ostage, prev_out, prev_pix0, prev_npx, ops, t);
-  if (DEG > 0 && pend) flush_moments<M, P, false>(acc_m, bval, bidx, pend_part, lane);
+  if (DEG > 0 && pend) flush_moments<M, P, false, !BATCH>(acc_m, bval, bidx, pend_part, lane);
+  if constexpr (DEG > 0 && !BATCH)
+    if (a.fit.tickets) fused_fit<DEG>(a.fit, a.one.part_dev, a.one.slots, a.nb, smem, t);
 }
 
 // LDS-DMA issued from inline asm: the compiler's waitcnt pass then does not know a DMA is pending and does
@@ -1093,7 +1194,7 @@ __global__ __launch_bounds__(512, 4) void srf_u16_ring_kernel(const SrfArgs a) {
     fetch_record(next_unit ? nidx + gridDim.x : nidx, cur ^ 1);
     if (OUTV) flush_stage<T>(ostage, prev_out, prev_pix0, prev_npx, ops, t);
     if (BATCH && DEG > 0 && pend) {
-      flush_moments<M, P, false>(acc_m, bval, bidx, pend_part, lane);
+      flush_moments<M, P, false, !BATCH>(acc_m, bval, bidx, pend_part, lane);
       pend = false;
     }
 
@@ -1145,7 +1246,9 @@ __global__ __launch_bounds__(512, 4) void srf_u16_ring_kernel(const SrfArgs a) {
     __syncthreads();
     flush_stage<T>(ostage, prev_out, prev_pix0, prev_npx, ops, t);
   }
-  if (DEG > 0 && pend) flush_moments<M, P, false>(acc_m, bval, bidx, pend_part, lane);
+  if (DEG > 0 && pend) flush_moments<M, P, false, !BATCH>(acc_m, bval, bidx, pend_part, lane);
+  if constexpr (DEG > 0 && !BATCH)
+    if (a.fit.tickets) fused_fit<DEG>(a.fit, a.one.part_dev, a.one.slots, a.nb, smem, t);
 }
 
 template <typename K>
@@ -1388,26 +1491,42 @@ extern "C" int hsr_srf_integrate(const float* cube_dev, int64_t npix, int32_t B,
   return hsr::srf_common(a, k0, klen, 0, opts, (hipStream_t)stream);
 }
 
-extern "C" int hsr_srf_integrate_moments(const float* cube_dev, int64_t npix, int32_t B, const float* wn_dev,
-                                         const int32_t* k0, const int32_t* klen, int32_t nb, float* out_dev,
-                                         int64_t out_bs, int64_t out_ps, const float* real_dev, int64_t real_bs,
-                                         int64_t real_ps, const uint8_t* mask_dev, float min_x, float min_y, int32_t deg,
-                                         double* partials_dev, int32_t* slots_out, const hsr_srf_options* opts,
-                                         hsr_stream_t stream) {
-  HSR_REQUIRE(deg >= 1 && deg <= HSR_MAX_DEG, HSR_ERR_UNSUPPORTED, "hsr_srf_integrate_moments: deg=%d outside [1,%d]",
-              deg, HSR_MAX_DEG);
-  HSR_REQUIRE(real_dev && partials_dev, HSR_ERR_INVALID, "hsr_srf_integrate_moments: NULL pointer");
+// K1+K2 entry shared by the float32 / uint16 and the plain / fused-fit forms.
+static int srf_moments_entry(const char* who, const void* cube_dev, bool u16, float scale, int32_t nodata, int64_t npix,
+                             int32_t B, const float* wn_dev, const int32_t* k0, const int32_t* klen, int32_t nb,
+                             float* out_dev, int64_t out_bs, int64_t out_ps, const float* real_dev, int64_t real_bs,
+                             int64_t real_ps, const uint8_t* mask_dev, float min_x, float min_y, int32_t deg,
+                             double* partials_dev, int32_t* slots_out, const hsr_fused_fit* fit,
+                             const hsr_srf_options* opts, hsr_stream_t stream) {
+  HSR_REQUIRE(deg >= 1 && deg <= HSR_MAX_DEG, HSR_ERR_UNSUPPORTED, "%s: deg=%d outside [1,%d]", who, deg, HSR_MAX_DEG);
+  HSR_REQUIRE(real_dev && partials_dev, HSR_ERR_INVALID, "%s: NULL pointer", who);
   HSR_REQUIRE((real_ps == 1 && real_bs >= npix) || (real_bs == 1 && real_ps >= nb), HSR_ERR_INVALID,
-              "hsr_srf_integrate_moments: real strides (%lld, %lld) are neither band-major nor pixel-major",
-              (long long)real_bs, (long long)real_ps);
-  HSR_REQUIRE(npix > 0, HSR_ERR_INVALID, "hsr_srf_integrate_moments: npix must be > 0");
+              "%s: real strides (%lld, %lld) are neither band-major nor pixel-major", who, (long long)real_bs,
+              (long long)real_ps);
+  HSR_REQUIRE(npix > 0, HSR_ERR_INVALID, "%s: npix must be > 0", who);
+  HSR_REQUIRE(!u16 || nodata <= 0xffff, HSR_ERR_INVALID, "%s: nodata=%d is not a uint16 value (negative = none)", who, nodata);
   hsr::SrfArgs a{};
+  if (fit) {
+    HSR_REQUIRE(fit->group_partials_dev && fit->tickets_dev && fit->moments_dev && fit->coeffs_dev, HSR_ERR_INVALID,
+                "%s: NULL pointer in hsr_fused_fit", who);
+    HSR_REQUIRE(fit->min_count >= 0, HSR_ERR_INVALID, "%s: min_count < 0", who);
+    a.fit.gpart = fit->group_partials_dev;
+    a.fit.tickets = fit->tickets_dev;
+    a.fit.moments = fit->moments_dev;
+    a.fit.coeffs = fit->coeffs_dev;
+    a.fit.min_count = (long long)fit->min_count;
+  }
   a.one.cube_dev = cube_dev;
   a.one.npix = npix;
   a.one.pseudo_dev = out_dev;
   a.one.real_dev = real_dev;
   a.one.mask_dev = mask_dev;
   a.one.part_dev = partials_dev;
+  if (u16) {
+    a.u16 = 1;
+    a.scale = scale;
+    a.nodata = nodata < 0 ? 0x10000u : (uint32_t)nodata;
+  }
   a.B = B;
   a.wn = wn_dev;
   a.nb = nb;
@@ -1420,6 +1539,29 @@ extern "C" int hsr_srf_integrate_moments(const float* cube_dev, int64_t npix, in
   int rc = hsr::srf_common(a, k0, klen, deg, opts, (hipStream_t)stream);
   if (rc == HSR_OK && slots_out) *slots_out = a.one.slots;
   return rc;
+}
+
+extern "C" int hsr_srf_integrate_moments(const float* cube_dev, int64_t npix, int32_t B, const float* wn_dev,
+                                         const int32_t* k0, const int32_t* klen, int32_t nb, float* out_dev,
+                                         int64_t out_bs, int64_t out_ps, const float* real_dev, int64_t real_bs,
+                                         int64_t real_ps, const uint8_t* mask_dev, float min_x, float min_y, int32_t deg,
+                                         double* partials_dev, int32_t* slots_out, const hsr_srf_options* opts,
+                                         hsr_stream_t stream) {
+  return srf_moments_entry("hsr_srf_integrate_moments", cube_dev, false, 0.0f, -1, npix, B, wn_dev, k0, klen, nb, out_dev,
+                           out_bs, out_ps, real_dev, real_bs, real_ps, mask_dev, min_x, min_y, deg, partials_dev, slots_out,
+                           nullptr, opts, stream);
+}
+
+extern "C" int hsr_srf_integrate_fit(const float* cube_dev, int64_t npix, int32_t B, const float* wn_dev,
+                                     const int32_t* k0, const int32_t* klen, int32_t nb, float* out_dev, int64_t out_bs,
+                                     int64_t out_ps, const float* real_dev, int64_t real_bs, int64_t real_ps,
+                                     const uint8_t* mask_dev, float min_x, float min_y, int32_t deg, double* partials_dev,
+                                     int32_t* slots_out, const hsr_fused_fit* fit, const hsr_srf_options* opts,
+                                     hsr_stream_t stream) {
+  HSR_REQUIRE(fit, HSR_ERR_INVALID, "hsr_srf_integrate_fit: NULL hsr_fused_fit");
+  return srf_moments_entry("hsr_srf_integrate_fit", cube_dev, false, 0.0f, -1, npix, B, wn_dev, k0, klen, nb, out_dev,
+                           out_bs, out_ps, real_dev, real_bs, real_ps, mask_dev, min_x, min_y, deg, partials_dev, slots_out,
+                           fit, opts, stream);
 }
 
 extern "C" int hsr_srf_integrate_u16(const uint16_t* cube_dev, int64_t npix, int32_t B, float scale, int32_t nodata,
@@ -1449,36 +1591,21 @@ extern "C" int hsr_srf_integrate_moments_u16(const uint16_t* cube_dev, int64_t n
                                              const uint8_t* mask_dev, float min_x, float min_y, int32_t deg,
                                              double* partials_dev, int32_t* slots_out, const hsr_srf_options* opts,
                                              hsr_stream_t stream) {
-  HSR_REQUIRE(deg >= 1 && deg <= HSR_MAX_DEG, HSR_ERR_UNSUPPORTED, "hsr_srf_integrate_moments_u16: deg=%d outside [1,%d]",
-              deg, HSR_MAX_DEG);
-  HSR_REQUIRE(real_dev && partials_dev, HSR_ERR_INVALID, "hsr_srf_integrate_moments_u16: NULL pointer");
-  HSR_REQUIRE((real_ps == 1 && real_bs >= npix) || (real_bs == 1 && real_ps >= nb), HSR_ERR_INVALID,
-              "hsr_srf_integrate_moments_u16: real strides (%lld, %lld) are neither band-major nor pixel-major",
-              (long long)real_bs, (long long)real_ps);
-  HSR_REQUIRE(npix > 0, HSR_ERR_INVALID, "hsr_srf_integrate_moments_u16: npix must be > 0");
-  HSR_REQUIRE(nodata <= 0xffff, HSR_ERR_INVALID, "hsr_srf_integrate_moments_u16: nodata=%d is not a uint16 value (negative = none)", nodata);
-  hsr::SrfArgs a{};
-  a.one.cube_dev = cube_dev;
-  a.one.npix = npix;
-  a.one.pseudo_dev = out_dev;
-  a.one.real_dev = real_dev;
-  a.one.mask_dev = mask_dev;
-  a.one.part_dev = partials_dev;
-  a.u16 = 1;
-  a.scale = scale;
-  a.nodata = nodata < 0 ? 0x10000u : (uint32_t)nodata;
-  a.B = B;
-  a.wn = wn_dev;
-  a.nb = nb;
-  a.out_bs = out_bs;
-  a.out_ps = out_ps;
-  a.real_bs = real_bs;
-  a.real_ps = real_ps;
-  a.min_x = min_x;
-  a.min_y = min_y;
-  int rc = hsr::srf_common(a, k0, klen, deg, opts, (hipStream_t)stream);
-  if (rc == HSR_OK && slots_out) *slots_out = a.one.slots;
-  return rc;
+  return srf_moments_entry("hsr_srf_integrate_moments_u16", cube_dev, true, scale, nodata, npix, B, wn_dev, k0, klen, nb,
+                           out_dev, out_bs, out_ps, real_dev, real_bs, real_ps, mask_dev, min_x, min_y, deg, partials_dev,
+                           slots_out, nullptr, opts, stream);
+}
+
+extern "C" int hsr_srf_integrate_fit_u16(const uint16_t* cube_dev, int64_t npix, int32_t B, float scale, int32_t nodata,
+                                         const float* wn_dev, const int32_t* k0, const int32_t* klen, int32_t nb,
+                                         float* out_dev, int64_t out_bs, int64_t out_ps, const float* real_dev,
+                                         int64_t real_bs, int64_t real_ps, const uint8_t* mask_dev, float min_x,
+                                         float min_y, int32_t deg, double* partials_dev, int32_t* slots_out,
+                                         const hsr_fused_fit* fit, const hsr_srf_options* opts, hsr_stream_t stream) {
+  HSR_REQUIRE(fit, HSR_ERR_INVALID, "hsr_srf_integrate_fit_u16: NULL hsr_fused_fit");
+  return srf_moments_entry("hsr_srf_integrate_fit_u16", cube_dev, true, scale, nodata, npix, B, wn_dev, k0, klen, nb,
+                           out_dev, out_bs, out_ps, real_dev, real_bs, real_ps, mask_dev, min_x, min_y, deg, partials_dev,
+                           slots_out, fit, opts, stream);
 }
 
 // ---- batched small tiles ---------------------------------------------------------------------------------------

@@ -273,14 +273,24 @@ class MomentWorkspace:
         self.moments = torch.zeros((nb, self.M), dtype=torch.float64, device=device)
         self.coeffs = torch.zeros((nb, deg + 1), dtype=torch.float64, device=device)
         self.slots = 0
+        # fused fit (hsr_srf_integrate_fit): group sums and the arrival tickets (zero between launches)
+        self.group_partials = torch.empty(nat.HSR_FIT_GROUPS * nb * self.M, dtype=torch.float64, device=device)
+        self.tickets = torch.zeros(nat.HSR_FIT_TICKETS, dtype=torch.int32, device=device)
+
+    def fused_fit(self, min_count: int):
+        """The hsr_fused_fit record of this workspace."""
+        return nat.FusedFit(self.group_partials.data_ptr(), self.tickets.data_ptr(), self.moments.data_ptr(),
+                            self.coeffs.data_ptr(), int(min_count))
 
 
 def srf_integrate_moments(cube, table: SrfTable, real, deg: int, ws: MomentWorkspace, mask=None,
                           min_x=_NEG_INF, min_y=_NEG_INF, out=None, events=None, reduce=True,
                           layout: str = PIXMAJOR, real_layout: Optional[str] = None, scale=None,
-                          nodata: Optional[int] = TILE_NODATA, opts=None):
+                          nodata: Optional[int] = TILE_NODATA, opts=None, fit_min_count: Optional[int] = None):
     """K1+K2 fused: pseudo-S2 image and the per-band Vandermonde moments in one cube pass.
     A uint16 cube is decoded inside the kernel (see srf_integrate).
+    ``fit_min_count``: given, the same launch also reduces the slots and solves (hsr_srf_integrate_fit): returns
+    (image, (moments, coeffs)) - the workspace's tensors - and ``reduce`` is ignored.
     ``real``: real-S2 image in ``real_layout`` (default: same as ``layout``).
     ``events``: optional (start, stop) torch.cuda.Event pair recorded on the launch stream right
     around the fused kernel (bench.py's live roofline measurement)."""
@@ -307,7 +317,20 @@ def srf_integrate_moments(cube, table: SrfTable, real, deg: int, ws: MomentWorks
     with _launch(c2) as st:
         if events is not None:
             events[0].record(torch.cuda.current_stream(c2.device))
-        if c2.dtype == torch.uint16:
+        if fit_min_count is not None:
+            fit = ws.fused_fit(fit_min_count)
+            if c2.dtype == torch.uint16:
+                nat.check(lib.hsr_srf_integrate_fit_u16(_ptr(c2), npix, B, _decode_scale(scale),
+                                                        -1 if nodata is None else int(nodata), _ptr(wn), k0p, klp, nb,
+                                                        _ptr(img), bs, ps, _ptr(real), rbs, rps, _ptr(mask), min_x, min_y,
+                                                        deg, _ptr(ws.partials), C.byref(slots), C.byref(fit), _opt(opts), st),
+                          "hsr_srf_integrate_fit_u16")
+            else:
+                nat.check(lib.hsr_srf_integrate_fit(_ptr(c2), npix, B, _ptr(wn), k0p, klp, nb, _ptr(img), bs, ps,
+                                                    _ptr(real), rbs, rps, _ptr(mask), min_x, min_y, deg,
+                                                    _ptr(ws.partials), C.byref(slots), C.byref(fit), _opt(opts), st),
+                          "hsr_srf_integrate_fit")
+        elif c2.dtype == torch.uint16:
             nat.check(lib.hsr_srf_integrate_moments_u16(_ptr(c2), npix, B, _decode_scale(scale),
                                                         -1 if nodata is None else int(nodata), _ptr(wn), k0p, klp, nb,
                                                         _ptr(img), bs, ps, _ptr(real), rbs, rps, _ptr(mask), min_x, min_y,
@@ -321,6 +344,8 @@ def srf_integrate_moments(cube, table: SrfTable, real, deg: int, ws: MomentWorks
         if events is not None:
             events[1].record(torch.cuda.current_stream(c2.device))
     ws.slots = slots.value
+    if fit_min_count is not None:
+        return img, (ws.moments, ws.coeffs)
     if not reduce:                      # caller continues with moments_reduce_solve / moments_reduce
         return img, None
     return img, moments_reduce(ws)

@@ -21,6 +21,8 @@ HSR_MAX_SPECTRAL = 560
 HSR_TILE_PIXELS = 64
 HSR_SRF_U16_FAST = 1
 HSR_MAX_PARTIALS = 4096
+HSR_FIT_GROUPS = 64
+HSR_FIT_TICKETS = 65
 PLANAR = "planar"        # band-major planes: tensor (nb, npix), unit pixel stride
 PIXMAJOR = "pixmajor"    # pixel-major / band-last: tensor (npix, row) with row >= nb, unit band stride
 
@@ -51,6 +53,12 @@ class BatchTile(C.Structure):
 class BatchInfo(C.Structure):
     """hsr_batch_info: what hsr_batch_plan found."""
     _fields_ = [("nunits", _i64), ("total_pixels", _i64), ("max_npix", _i64), ("ntiles", _i32), ("aligned16", _i32)]
+
+
+class FusedFit(C.Structure):
+    """hsr_fused_fit: workspaces and outputs of the reduce + solve folded into K1 (hsr_srf_integrate_fit)."""
+    _fields_ = [("group_partials_dev", _vp), ("tickets_dev", _vp), ("moments_dev", _vp), ("coeffs_dev", _vp),
+                ("min_count", _i64)]
 
 
 BATCH_RECORD_BYTES = 64          # sizeof(hsr_batch_tile) == sizeof(hsr_batch_unit)
@@ -88,6 +96,10 @@ SIGNATURES = {
     "hsr_srf_integrate_moments_u16": (C.c_int, [_vp, _i64, _i32, _f32, _i32, _vp, C.POINTER(_i32), C.POINTER(_i32),
                                                 _i32, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _f32, _f32, _i32, _vp,
                                                 C.POINTER(_i32), _popt, _vp]),
+    "hsr_srf_integrate_fit": (C.c_int, [_vp, _i64, _i32, _vp, _pi32, _pi32, _i32, _vp, _i64, _i64, _vp, _i64, _i64, _vp,
+                                        _f32, _f32, _i32, _vp, _pi32, C.POINTER(FusedFit), _popt, _vp]),
+    "hsr_srf_integrate_fit_u16": (C.c_int, [_vp, _i64, _i32, _f32, _i32, _vp, _pi32, _pi32, _i32, _vp, _i64, _i64, _vp,
+                                            _i64, _i64, _vp, _f32, _f32, _i32, _vp, _pi32, C.POINTER(FusedFit), _popt, _vp]),
     "hsr_batch_partials_bytes": (C.c_size_t, [_i64, _i32, _i32]),
     "hsr_batch_plan": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _popt, _vp, _i64, C.POINTER(BatchInfo)]),
     "hsr_srf_integrate_moments_batched": (C.c_int, [_vp, C.POINTER(BatchInfo), _i32, _f32, _i32, _i32, _vp, _pi32, _pi32,

@@ -101,7 +101,7 @@ class SpectralFusion:
                  group=None, coeff_sync: str = "allreduce", layout: str = nat.PIXMAJOR,
                  force_exchange: bool = False, tile_scale=None, tile_nodata: Optional[int] = eng.TILE_NODATA,
                  reserved_cus: Optional[int] = None, tile_pixels: int = 0, u16_single_buffer: bool = False,
-                 u16_fast: bool = False, placement_trials: int = 6):
+                 u16_fast: bool = False, placement_trials: int = 6, fused_fit: bool = False):
         torch = nat.require_gpu()
         # decode of uint16 cubes (the reference's tile format, tiles_helpers/utils.py:362-374): x = u * tile_scale
         # (default float32(1e-4)), u == tile_nodata -> NaN (None: no nodata value).  Ignored for float32 cubes.
@@ -139,6 +139,12 @@ class SpectralFusion:
         # (results are bit-identical whichever is kept; 0 / 1 = take the first allocation, no host synchronisation).
         self.placement_trials = max(0, int(placement_trials))
         self.placement_log: Dict[int, list] = {}
+        # fused_fit: step() without an exchange lets the slot reduction and the solve ride in K1's launch
+        # (hsr_srf_integrate_fit: the last workgroups to finish reduce and solve) - two launches per step instead of
+        # three, same bits.  Off by default: measured on MI355X the tail costs K1 +13 us (six dependent round trips
+        # through memory-side coherence at ~1.5 us each: ticket, slot loads, group store, ticket, group loads, solve)
+        # against 8.5 us + one launch gap for the separate hsr_moments_reduce_solve - 3 us per step slower.
+        self.fused_fit = bool(fused_fit)
         self._pipe = None                            # state of submit()/flush(), created on first use
         self.ws = eng.MomentWorkspace(self.device, self.table.nb, deg)
         self.table.device_weights(self.device)
@@ -270,14 +276,19 @@ class SpectralFusion:
             pseudo, matched = self._buffers(npix, probe if npix not in self._buf else None)
         else:
             pseudo = matched = None
-        pseudo, _ = eng.srf_integrate_moments(cube, self.table, real, self.deg, self.ws, mask,
-                                              self.min_valid, self.min_valid, out=pseudo, events=k1_events,
-                                              reduce=False, layout=self.layout, real_layout=real_layout,
-                                              scale=self.tile_scale, nodata=self.tile_nodata, opts=self.opts)
-        if self._exchanges():
+        exchanges = self._exchanges()
+        fit = self.min_count if (self.fused_fit and not exchanges) else None
+        pseudo, fitted = eng.srf_integrate_moments(cube, self.table, real, self.deg, self.ws, mask,
+                                                   self.min_valid, self.min_valid, out=pseudo, events=k1_events,
+                                                   reduce=False, layout=self.layout, real_layout=real_layout,
+                                                   scale=self.tile_scale, nodata=self.tile_nodata, opts=self.opts,
+                                                   fit_min_count=fit)
+        if exchanges:
             moments = eng.moments_reduce(self.ws)
             moments, coeffs = exchange_moments(moments, self._solve, self.group, self.coeff_sync)
-        else:                       # no exchange between reduce and solve: one fused launch
+        elif fitted is not None:    # reduce + solve rode in K1's launch
+            moments, coeffs = fitted
+        else:                       # no exchange between reduce and solve: one launch for both
             moments, coeffs = eng.moments_reduce_solve(self.ws, self.min_count)
         matched = eng.poly_apply(pseudo, coeffs, mask if self.apply_mask else None, None, self.clip,
                                  self.layout, out=matched, nb=self.table.nb)

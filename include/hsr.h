@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HSR_ABI_VERSION 2
+#define HSR_ABI_VERSION 3
 
 #define HSR_OK 0
 #define HSR_ERR_INVALID 1      /* bad argument (shape, alignment, NULL)            */
@@ -112,6 +112,35 @@ int hsr_srf_integrate_moments(const float* cube_dev, int64_t npix, int32_t B,
                               float min_x, float min_y, int32_t deg,
                               double* partials_dev, int32_t* slots_out, const hsr_srf_options* opts,
                               hsr_stream_t stream);
+
+/* ---- K1+K2+fit in ONE launch (single tile) ----------------------------------------------------
+ * hsr_srf_integrate_moments followed by hsr_moments_reduce_solve without the second launch: every workgroup draws a
+ * ticket when its slot of partials is written; the workgroup that completes a group of slots (slot mod 64) adds the
+ * group, the one that completes the last group adds the groups, writes the moments, solves the bands and re-arms the
+ * tickets.  The summation tree is the one of hsr_moments_reduce (lane l adds slots l, l+64, ...; butterfly over the
+ * lanes), so moments and coefficients carry the same bits as the two-launch form.
+ *   group_partials_dev  64 * nb * (3deg+2) doubles of scratch
+ *   tickets_dev         65 int32, ZERO before the first launch; the kernel leaves them zero
+ *   moments_dev         (nb, 3deg+2) float64 out;   coeffs_dev (nb, deg+1) float64 out, highest power first
+ *   min_count           as hsr_poly_solve */
+typedef struct hsr_fused_fit {
+  double* group_partials_dev;
+  int32_t* tickets_dev;
+  double* moments_dev;
+  double* coeffs_dev;
+  int64_t min_count;
+} hsr_fused_fit;
+#define HSR_FIT_GROUPS 64
+#define HSR_FIT_TICKETS 65
+
+int hsr_srf_integrate_fit(const float* cube_dev, int64_t npix, int32_t B,
+                          const float* wn_dev, const int32_t* k0, const int32_t* klen, int32_t nb,
+                          float* out_dev, int64_t out_bs, int64_t out_ps,
+                          const float* real_dev, int64_t real_bs, int64_t real_ps,
+                          const uint8_t* mask_dev, float min_x, float min_y, int32_t deg,
+                          double* partials_dev, int32_t* slots_out, const hsr_fused_fit* fit,
+                          const hsr_srf_options* opts, hsr_stream_t stream);
+
 
 /* ---- K2: moments of already materialised planes -----------------------------------------------
  * Same sums as above for x/y planes that exist already (after a percentile stretch, or for the
@@ -214,6 +243,14 @@ int hsr_srf_integrate_moments_u16(const uint16_t* cube_dev, int64_t npix, int32_
                                   int64_t real_bs, int64_t real_ps, const uint8_t* mask_dev, float min_x,
                                   float min_y, int32_t deg, double* partials_dev, int32_t* slots_out,
                                   const hsr_srf_options* opts, hsr_stream_t stream);
+int hsr_srf_integrate_fit_u16(const uint16_t* cube_dev, int64_t npix, int32_t B, float scale, int32_t nodata,
+                              const float* wn_dev, const int32_t* k0, const int32_t* klen, int32_t nb,
+                              float* out_dev, int64_t out_bs, int64_t out_ps,
+                              const float* real_dev, int64_t real_bs, int64_t real_ps,
+                              const uint8_t* mask_dev, float min_x, float min_y, int32_t deg,
+                              double* partials_dev, int32_t* slots_out, const hsr_fused_fit* fit,
+                              const hsr_srf_options* opts, hsr_stream_t stream);
+
 
 /* ---- batched small tiles (the reference's actual problem size) -----------------------------------------------
  * The authors run this pipeline on 100 x 100 EMIT <-> 600 x 600 S2 tile pairs, one independent fit per tile

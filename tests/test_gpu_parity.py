@@ -1706,3 +1706,45 @@ def test_placement_trials_do_not_change_results(torch_gpu):
     assert torch.equal(oa.coeffs.view(torch.int64), oc.coeffs.view(torch.int64))
     assert torch.equal(oa.matched.view(torch.int32), oc.matched.view(torch.int32))
     assert c.place_inputs(p.cube, p.real)[2] == {}               # already placed for this tile size: a no-op
+
+
+@pytest.mark.gpu
+def test_fused_fit_bit_identical_to_reduce_solve(torch_gpu):
+    """hsr_srf_integrate_fit (slot reduction + solve folded into K1's launch: ticket per slot, the workgroup completing a
+    group of slots adds it, the one completing the groups runs the butterfly, solves and re-arms the tickets) against
+    hsr_srf_integrate_moments + hsr_moments_reduce_solve: same moments and coefficients bit for bit - for fewer slots
+    than groups (S < 64), ragged group sizes (S = 496 with 8 reserved CUs, S = 157), every degree, masks, uint16 tiles
+    (ring and single buffer), a rank-deficient band (constant x: the Jacobi path, its matrices in LDS) and an
+    under-populated band (identity fallback); the tickets are left zero, so repeated launches agree too."""
+    torch = torch_gpu
+    from s2_emit import SpectralFusion, _engine as eng
+    w, good = onp.synthetic_wavelengths()
+    srf = onp.synthetic_srf()
+    g = torch.Generator(device="cuda")
+    g.manual_seed(21)
+    cases = [((3, 50), {}), ((100, 100), {}), ((130, 300), {}), ((256, 512), {}), ((256, 512), {"reserved_cus": 8}),
+             ((64, 63), {"u16_single_buffer": True})]
+    for (H, W), kw in cases:
+        cube = torch.rand((H, W, 285), generator=g, device="cuda") * 0.6
+        real = torch.rand((H, W, 12), generator=g, device="cuda")
+        real[..., 5] = -1.0                                   # below min_valid everywhere: identity fallback for band 5
+        mask = (torch.rand(H * W, generator=g, device="cuda") > 0.3).to(torch.uint8)
+        flat = cube.clone()
+        flat[:] = 0.25                                        # every pseudo band constant: singular Gram, Jacobi path
+        for deg in (1, 2, 3, 4):
+            for kind in ("f32", "u16"):
+                for c, m in ((cube, None), (cube, mask), (flat, None)):
+                    cc = c if kind == "f32" else eng.tile_encode_u16(c)
+                    a = SpectralFusion(w, srf, good, deg=deg, min_count=5, placement_trials=0, fused_fit=False, **kw)
+                    b = SpectralFusion(w, srf, good, deg=deg, min_count=5, placement_trials=0, fused_fit=True, **kw)
+                    oa = a.step(cc, real, m)
+                    for rep in range(3):
+                        ob = b.step(cc, real, m)
+                        torch.cuda.synchronize()
+                        tag = ((H, W), kw, deg, kind, m is not None, c is flat, rep)
+                        assert torch.equal(oa.moments.view(torch.int64), ob.moments.view(torch.int64)), tag
+                        assert torch.equal(oa.coeffs.view(torch.int64), ob.coeffs.view(torch.int64)), tag
+                        assert torch.equal(oa.matched.view(torch.int32), ob.matched.view(torch.int32)), tag
+                        assert int(b.ws.tickets.abs().sum()) == 0, tag
+                    assert torch.isfinite(ob.coeffs).all()
+                    assert torch.equal(ob.coeffs[5], torch.tensor([0.0] * (deg - 1) + [1.0, 0.0], dtype=torch.float64, device="cuda"))

@@ -256,7 +256,9 @@ def main():
         # where the resident inputs lie in HBM is the benchmark's to choose: the same slow stretches of device memory that
         # the plan avoids for its own images (profiles/r02_two_speeds.md) slow K1's read streams too, so the cube and the
         # target are cloned into a few regions before the warm-up and the fastest copies kept (same bytes, same results)
+        t_place = time.perf_counter()
         cube, real, input_log = plan.place_inputs(cube, real)
+        input_log["seconds"] = round(time.perf_counter() - t_place, 2)
         if args.cube == "u16":
             prob.cube_u16 = cube
         else:
@@ -363,6 +365,7 @@ def main():
                            "pipeline": f"one tile deep, {args.reserve_cus} CUs reserved" if pipelined else "off",
                            "launches_per_step": 2 if (args.fused_fit and world == 1 and not args.force_exchange and ntl == 1) else None,
                            "placement": {"trials_ms": plan.placement_log.get(H * W), "joint_with_inputs": input_log is not None,
+                                         "search_seconds": (input_log or {}).get("seconds"),
                                          "note": "before the warm-up K1 is timed on a few candidate allocations, 4 GB apart, of "
                                                  "(cube copy, target copy, output image); the fastest set is kept "
                                                  "(profiles/r02_two_speeds.md); same bytes, bit-identical results"},

@@ -162,52 +162,133 @@ __global__ __launch_bounds__(64) void solve_kernel(const double* __restrict__ mo
   if (b < nb) solve_band(moments + (size_t)b * moment_count(deg), deg, min_count, coeffs + (size_t)b * (deg + 1));
 }
 
-// reduce + solve in one launch: one workgroup per band sums its 3deg+2 slot rows (same tree as
-// reduce_kernel: lane-strided sums, then the fixed butterfly), writes the moments, thread 0 solves.
+// The 63 adds of wave_sum's xor butterfly (32, 16, .., 1) over 64 lane sums, done by one thread: t[l] = v[l] + v[l ^ off]
+// for l < off is the value every lane of the pair holds after a level, so a[0] after the last level is wave_sum's result
+// bit for bit.  ``col`` = address of lane 0's sum, ``ld`` doubles between lanes.
+__device__ __forceinline__ double butterfly_tree64(const double* col, int ld) {
+  double a[32];
+#pragma unroll
+  for (int l = 0; l < 32; ++l) a[l] = col[(size_t)l * ld] + col[(size_t)(l + 32) * ld];
+#pragma unroll
+  for (int off = 16; off >= 1; off >>= 1)
+#pragma unroll
+    for (int l = 0; l < off; ++l) a[l] = a[l] + a[l + off];
+  return a[0];
+}
+
+// reduce + solve in one launch: one workgroup per band.  Same tree as row_sum / reduce_kernel - "lane" l adds slots
+// l, l + 64, ... in order, then the butterfly over the 64 lane sums - but laid out for the slot-major partials: a
+// 16-lane group reads the band's 3deg+2 moments of ONE slot (112 contiguous bytes for deg 3), so a load instruction
+// touches 4-8 cache lines instead of 64 (the wave-per-moment gather cost ~8000 line requests through one CU's L1,
+// 4 us of the kernel's 8.6).  The lane sums go through LDS; thread m < M walks the butterfly for moment m.
 __global__ __launch_bounds__(1024) void reduce_solve_kernel(const double* __restrict__ partials, int slots, int deg,
                                                             long long min_count, double* __restrict__ moments,
                                                             double* __restrict__ coeffs) {
-  __shared__ double mom[3 * HSR_MAX_DEG + 2];
+  __shared__ double lsum[64][16];
+  __shared__ double mom[16];
+  __shared__ double work[kSolveWork];
   const int M = moment_count(deg);
   const int b = blockIdx.x;
+  const int stride = (int)gridDim.x * M;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int m = wave; m < M; m += 16) {   // one wave per moment row (M <= 14 < 16 waves)
-    const double s = row_sum(partials + (size_t)b * M + m, slots, (int)gridDim.x * M, lane);
-    if (lane == 0) {
-      mom[m] = s;
-      moments[(size_t)b * M + m] = s;
+  const int l = wave * 4 + (lane >> 4), m = lane & 15;
+  {
+    const double* row = partials + (size_t)b * M + (m < M ? m : 0);
+    double s = 0.0;
+    for (int i0 = l; i0 < slots; i0 += 64 * 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + 64 * u;
+        v[u] = (i < slots && m < M) ? row[(size_t)i * stride] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];   // adding +0.0 for absent slots does not change the sum
     }
+    lsum[l][m] = s;
   }
   __syncthreads();
-  if (threadIdx.x == 0) solve_band(mom, deg, min_count, coeffs + (size_t)b * (deg + 1));
+  if (threadIdx.x < M) {
+    const double s = butterfly_tree64(&lsum[0][threadIdx.x], 16);
+    mom[threadIdx.x] = s;
+    moments[(size_t)b * M + threadIdx.x] = s;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) solve_band_work(mom, deg, min_count, coeffs + (size_t)b * (deg + 1), work);
 }
 
-// Batch form (hsr_moments_reduce_solve_batched): ONE workgroup per tile (16 waves: the nb * M slot rows round-robin
-// over the waves, then one thread per band solves).  The tile's slot block starts at slot0 * nb * M in the batch
-// workspace and has its own slot count.  Same row_sum tree, same solve -> same bits as the single-tile launch on that
-// tile.  (First version: a (band, tile) grid of 1024-thread workgroups with thread 0 solving - 49 us for 256 tiles,
-// six rounds of workgroups; this one is a single round.)
+// Batch form (hsr_moments_reduce_solve_batched): ONE workgroup per tile, the tile's slot block at slot0 * nb * M of the
+// batch workspace with its own slot count.  Same tree as row_sum -> same bits as the single-tile launch on that tile -
+// laid out for the slot-major partials like reduce_solve_kernel: a 16-lane group reads the M moments of one (slot,
+// band) - contiguous - and every thread carries the lane sums of all bands, so the whole tile costs ~2 memory round
+// trips.  Lane sum index l = (lane / 16) * 16 + wave: the butterfly's first two levels (l ^ 32, l ^ 16) are in-wave
+// shuffles, the last four (over the wave index) run from LDS, one thread per (band, moment) row; then one thread per
+// band solves.  (First version: a (band, tile) grid with thread 0 solving, 49 us for 256 tiles; second: one wave per
+// row gathering 8 bytes per cache line, 14.2 us; this one 13.5 us, 11.1 us of it without the solve: 256 tiles of
+// 100 x 100 pixels hold 157 slots x 1344 B each = 54 MB of partials, so the kernel is an HBM read at ~5 TB/s.)
+// NBU: bands carried per thread (>= nb; 8, 12 or 16); TWO: two slots per pass (the registers allow it up to 12 bands).
+template <int NBU, bool TWO>
 __global__ __launch_bounds__(1024) void reduce_solve_batched_kernel(const hsr_batch_tile* __restrict__ tiles,
                                                                     const double* __restrict__ partials, int nb, int deg,
                                                                     long long min_count, double* __restrict__ moments,
                                                                     double* __restrict__ coeffs) {
-  __shared__ double mom[HSR_MAX_BANDS * (3 * HSR_MAX_DEG + 2)];
+  constexpr int RMAX = HSR_MAX_BANDS * (3 * HSR_MAX_DEG + 2);
+  __shared__ double lsum[16][RMAX];
+  __shared__ double mom[RMAX];
+  __shared__ double work[HSR_MAX_BANDS * kSolveWork];   // Jacobi matrices of the rank-deficient bands (no scratch)
   const int M = moment_count(deg);
+  const int R = nb * M;
   const int tile = blockIdx.x;
   const int64_t slot0 = tiles[tile].slot0;
   const int slots = tiles[tile].slots;
-  const double* part = partials + (size_t)slot0 * nb * M;
+  const double* part = partials + (size_t)slot0 * R;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int r = wave; r < nb * M; r += 16) {      // row r = band * M + moment
-    const double s = row_sum(part + r, slots, nb * M, lane);
-    if (lane == 0) {
-      mom[r] = s;
-      moments[(size_t)tile * nb * M + r] = s;
+  const int q = lane >> 4, m = lane & 15;
+  const int l = q * 16 + wave;
+  const bool act = m < M;
+  double s[NBU];
+#pragma unroll
+  for (int bnd = 0; bnd < NBU; ++bnd) s[bnd] = 0.0;
+  for (int i0 = l; i0 < slots; i0 += TWO ? 128 : 64) {   // slots l, l + 64, ... in order
+    double v0[NBU], v1[TWO ? NBU : 1];
+    const double* p0 = part + (size_t)i0 * R + (act ? m : 0);
+    const bool has1 = TWO && i0 + 64 < slots;
+#pragma unroll
+    for (int bnd = 0; bnd < NBU; ++bnd) {
+      const bool on = act && bnd < nb;
+      v0[bnd] = on ? p0[bnd * M] : 0.0;
+      if (TWO) v1[bnd] = (on && has1) ? p0[(size_t)64 * R + bnd * M] : 0.0;
+    }
+#pragma unroll
+    for (int bnd = 0; bnd < NBU; ++bnd) {
+      s[bnd] += v0[bnd];
+      if (TWO) s[bnd] += v1[bnd];                    // +0.0 for an absent slot does not change the sum
+    }
+  }
+#pragma unroll
+  for (int bnd = 0; bnd < NBU; ++bnd) {
+    if (bnd < nb) {
+      double t = s[bnd] + __shfl_xor(s[bnd], 32, 64);
+      t = t + __shfl_xor(t, 16, 64);
+      if (q == 0 && act) lsum[wave][bnd * M + m] = t;
     }
   }
   __syncthreads();
-  if (threadIdx.x < nb)
-    solve_band(mom + threadIdx.x * M, deg, min_count, coeffs + ((size_t)tile * nb + threadIdx.x) * (deg + 1));
+  if ((int)threadIdx.x < R) {
+    double a[8];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) a[w] = lsum[w][threadIdx.x] + lsum[w + 8][threadIdx.x];
+#pragma unroll
+    for (int off = 4; off >= 1; off >>= 1)
+#pragma unroll
+      for (int w = 0; w < off; ++w) a[w] = a[w] + a[w + off];
+    mom[threadIdx.x] = a[0];
+    moments[(size_t)tile * R + threadIdx.x] = a[0];
+  }
+  __syncthreads();
+  if ((int)threadIdx.x < nb)
+    solve_band_work(mom + threadIdx.x * M, deg, min_count, coeffs + ((size_t)tile * nb + threadIdx.x) * (deg + 1),
+                    work + threadIdx.x * kSolveWork);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -688,8 +769,10 @@ extern "C" int hsr_moments_reduce_solve_batched(const hsr_batch_tile* tiles_dev,
   HSR_REQUIRE(ntiles >= 1 && ntiles <= 65535, HSR_ERR_UNSUPPORTED, "hsr_moments_reduce_solve_batched: ntiles=%d outside [1,65535]", ntiles);
   HSR_REQUIRE(nb >= 1 && nb <= HSR_MAX_BANDS && deg >= 1 && deg <= HSR_MAX_DEG, HSR_ERR_UNSUPPORTED,
               "hsr_moments_reduce_solve_batched: nb=%d deg=%d", nb, deg);
-  hipLaunchKernelGGL(reduce_solve_batched_kernel, dim3(ntiles), dim3(1024), 0, (hipStream_t)stream, tiles_dev, partials_dev,
-                     nb, deg, (long long)min_count, moments_dev, coeffs_dev);
+  auto* kern = nb <= 8 ? reduce_solve_batched_kernel<8, true> : nb <= 12 ? reduce_solve_batched_kernel<12, true>
+                                                                           : reduce_solve_batched_kernel<16, false>;
+  hipLaunchKernelGGL(kern, dim3(ntiles), dim3(1024), 0, (hipStream_t)stream, tiles_dev, partials_dev, nb, deg,
+                     (long long)min_count, moments_dev, coeffs_dev);
   HSR_LAUNCH_CHECK("reduce_solve_batched_kernel");
   return HSR_OK;
 }

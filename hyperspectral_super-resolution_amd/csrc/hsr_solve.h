@@ -156,6 +156,17 @@ __host__ __device__ inline void solve_band_t(const double* mom, long long min_co
   solve_band_jacobi(Af, Vf, rf, sf, n, count, coef);
 }
 
+// The same solve with the Jacobi matrices in caller-provided storage (kSolveWork doubles, e.g. LDS): keeps a kernel free
+// of scratch memory.
+__host__ __device__ inline void solve_band_work(const double* mom, int deg, long long min_count, double* coef, double* work) {
+  switch (deg) {
+    case 1: solve_band_t<1, true>(mom, min_count, coef, work); break;
+    case 2: solve_band_t<2, true>(mom, min_count, coef, work); break;
+    case 3: solve_band_t<3, true>(mom, min_count, coef, work); break;
+    default: solve_band_t<4, true>(mom, min_count, coef, work); break;
+  }
+}
+
 __host__ __device__ inline void solve_band(const double* mom, int deg, long long min_count, double* coef) {
   switch (deg) {
     case 1: solve_band_t<1>(mom, min_count, coef); break;

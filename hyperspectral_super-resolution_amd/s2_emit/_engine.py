@@ -355,6 +355,48 @@ def srf_integrate_moments(cube, table: SrfTable, real, deg: int, ws: MomentWorks
 # batched small tiles (hsr.h "batched small tiles"; the reference's 100 x 100 tile pairs,
 # tiles_helpers/utils.py:223-305)
 # ---------------------------------------------------------------------------------------------
+PLACEMENT_PITCH_GB = 16.0
+
+
+def placement_search(first, make, probe, trials: int, pitch_gb: float, device):
+    """Where a buffer lies in device memory changes K1's speed by ~9 % (profiles/r02_two_speeds.md: a map of 28
+    candidate sets per process shows stretches of 15-25 GB where K1 runs at 0.192-0.204 ms between stretches of 20-70 GB
+    where it runs at 0.208-0.227 ms; the speed is a stable property of the allocation, and of the cube's above all).
+    This times ``probe(candidate)`` - one K1 launch - on ``first`` and on up to ``trials - 1`` candidates from
+    ``make()``, one every ``pitch_gb`` GB (a spacer allocation between candidates, held until the end so that the next
+    one lands in another stretch), one untimed and two timed launches each, and returns (fastest candidate, times in ms).
+    Every candidate is timed - the slow class is wide (0.208-0.235 ms) and an early exit on "both speeds seen" stopped
+    inside it.  Same bytes whichever candidate is kept, so results do not change."""
+    torch = nat.require_gpu()
+    stream = torch.cuda.current_stream(device)
+    cands, spacers, times = [first], [], []
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for i in range(max(1, trials)):
+        if i > 0:
+            try:
+                spacers.append(torch.empty(int(pitch_gb * (1 << 30)), dtype=torch.uint8, device=device))
+                cands.append(make())
+            except RuntimeError:          # out of memory: settle for what has been seen
+                break
+        c = cands[-1]
+        probe(c)                           # untimed: first touch of the candidate
+        t = []
+        for _ in range(2):
+            e0.record(stream)
+            probe(c)
+            e1.record(stream)
+            e1.synchronize()
+            t.append(e0.elapsed_time(e1))
+        times.append(min(t))
+    best = min(range(len(times)), key=times.__getitem__)
+    keep = cands[best]
+    # The spacers and the losing candidates go back to torch's caching allocator, NOT to the driver: releasing them
+    # (torch.cuda.empty_cache()) right after the search was measured to cost K1 0.2-3 % again (0.2016-0.2077 ms against
+    # 0.2000-0.2007 ms over three fresh processes each) - unmapping ~190 GB next to the kept buffers is not neutral.
+    del cands, spacers, c
+    return keep, [round(t, 4) for t in times]
+
+
 class TileBatch:
     """Device tables and workspaces of one batch of tiles for the three batched launches.
 
@@ -451,38 +493,21 @@ class TileBatch:
         self.units_dev = torch.frombuffer(bytearray(bytes(units)), dtype=torch.uint8).to(dev)
         self.slots = [int(tiles[i].slots) for i in range(T)]
 
-    def place(self, probe, trials: int):
-        """Placement trials for the batch's output image (see SpectralFusion): ``probe(self)`` enqueues one batched K1
+    def place(self, probe, trials: int, pitch_gb: float = PLACEMENT_PITCH_GB):
+        """Placement trials for the batch's output image (placement_search): ``probe(self)`` enqueues one batched K1
         launch; candidates are fresh allocations of the output image; the fastest is kept."""
         torch = nat.require_gpu()
         if trials <= 1 or self.pseudo.numel() * 4 < (1 << 24):
             return
-        stream = torch.cuda.current_stream(self.device)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        cands, spacers, times, best = [self.pseudo], [], [], None
-        for i in range(trials):
-            if i > 0:
-                try:                                   # candidates 4 GB apart: the speed belongs to a REGION of memory
-                    spacers.append(torch.empty(1 << 32, dtype=torch.uint8, device=self.device))
-                    cands.append(torch.empty_like(cands[0]))
-                except RuntimeError:
-                    break
-                self._build(cands[-1])
+
+        def run(cand):
+            if cand is not self.pseudo:
+                self._build(cand)
             probe(self)
-            t = []
-            for _ in range(2):
-                e0.record(stream)
-                probe(self)
-                e1.record(stream)
-                e1.synchronize()
-                t.append(e0.elapsed_time(e1))
-            times.append(min(t))
-            if best is None or times[-1] < times[best]:
-                best = i
-        del spacers
-        if cands[best] is not self.pseudo:
-            self._build(cands[best])
-        self.placement_log = [round(t, 4) for t in times]
+        keep, times = placement_search(self.pseudo, lambda: torch.empty_like(self.pseudo), run, trials, pitch_gb, self.device)
+        if keep is not self.pseudo:
+            self._build(keep)
+        self.placement_log = times
 
     def tile_rows(self, i: int, image: str = "matched"):
         """(npix_i, row) view of tile i inside the batch's pseudo / matched image."""

@@ -101,7 +101,8 @@ class SpectralFusion:
                  group=None, coeff_sync: str = "allreduce", layout: str = nat.PIXMAJOR,
                  force_exchange: bool = False, tile_scale=None, tile_nodata: Optional[int] = eng.TILE_NODATA,
                  reserved_cus: Optional[int] = None, tile_pixels: int = 0, u16_single_buffer: bool = False,
-                 u16_fast: bool = False, placement_trials: int = 6, fused_fit: bool = False):
+                 u16_fast: bool = False, placement_trials: int = 12, fused_fit: bool = False,
+                 placement_pitch_gb: float = eng.PLACEMENT_PITCH_GB):
         torch = nat.require_gpu()
         # decode of uint16 cubes (the reference's tile format, tiles_helpers/utils.py:362-374): x = u * tile_scale
         # (default float32(1e-4)), u == tile_nodata -> NaN (None: no nodata value).  Ignored for float32 cubes.
@@ -132,12 +133,15 @@ class SpectralFusion:
             reserved_cus = 8 if self._exchanges() else 0
         self.opts = eng.srf_options(tile_pixels, reserved_cus, u16_single_buffer, u16_fast)
         self._batches: Dict[tuple, object] = {}
-        # Placement of the plan-owned output images (profiles/r02_two_speeds.md): K1 runs at one of two speeds, 8 % apart,
-        # depending on where its OUTPUT image happens to lie in physical memory relative to the cube - a property of the
-        # allocation, stable for the life of the buffers.  The plan therefore allocates up to `placement_trials`
-        # candidate images on the first step over a tile size, times one K1 launch on each and keeps the fastest
-        # (results are bit-identical whichever is kept; 0 / 1 = take the first allocation, no host synchronisation).
+        # Placement (profiles/r02_two_speeds.md, eng.placement_search): K1 runs at one of two speeds, ~9 % apart, depending
+        # on which stretch of device memory its operands lie in - the cube above all (its read stream), the output image
+        # and the target a little (3 %).  A property of the allocation, stable for its life.  The plan places what it owns:
+        # on the first step over a tile size it times K1 on up to min(4, placement_trials) candidate output images,
+        # `placement_pitch_gb` apart; place_inputs() searches jointly over copies of a resident tile's inputs (up to
+        # `placement_trials` sets).  Results are bit-identical whichever is kept; 0 / 1 = first allocation, no
+        # host synchronisation.
         self.placement_trials = max(0, int(placement_trials))
+        self.placement_pitch_gb = float(placement_pitch_gb)
         self.placement_log: Dict[int, list] = {}
         # fused_fit: step() without an exchange lets the slot reduction and the solve ride in K1's launch
         # (hsr_srf_integrate_fit: the last workgroups to finish reduce and solve) - two launches per step instead of
@@ -166,55 +170,28 @@ class SpectralFusion:
             self._buf[npix] = (pseudo, eng.alloc_image(torch, nb, npix, self.layout, self.device))
         return self._buf[npix]
 
-    def _trials(self, first, make, probe):
-        """Placement trials: ``first`` and up to placement_trials - 1 further candidates from ``make()``, each 4 GB apart
-        (a spacer allocation held until the end: the speed belongs to a REGION of device memory, and back-to-back
-        allocations land in the same region), ``probe(candidate)`` enqueues one K1 launch using the candidate; one
-        untimed and two timed launches each; returns (fastest candidate, times)."""
-        torch = nat.require_gpu()
-        stream = torch.cuda.current_stream(self.device)
-        cands, spacers, times = [first], [], []
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        for i in range(max(1, self.placement_trials)):
-            if i > 0:
-                try:
-                    spacers.append(torch.empty(1 << 32, dtype=torch.uint8, device=self.device))
-                    cands.append(make())
-                except RuntimeError:          # out of memory: settle for what has been seen
-                    break
-            c = cands[-1]
-            probe(c)                                   # untimed: first touch of the candidate
-            t = []
-            for _ in range(2):
-                e0.record(stream)
-                probe(c)
-                e1.record(stream)
-                e1.synchronize()
-                t.append(e0.elapsed_time(e1))
-            times.append(min(t))
-        best = min(range(len(times)), key=times.__getitem__)
-        keep = cands[best]
-        del cands, spacers
-        return keep, [round(t, 4) for t in times]
+    def _trials(self, first, make, probe, cap=None):
+        n = self.placement_trials if cap is None else min(cap, self.placement_trials)
+        return eng.placement_search(first, make, probe, n, self.placement_pitch_gb, self.device)
 
     def _place(self, npix: int, first, probe):
-        """Time K1 on candidate output images and keep the fastest (profiles/r02_two_speeds.md: in a 3 GB arena offsets
-        below 2 GB were fast and above slow - a step, not a period; in a 40 GB arena the slow stretch was its last 8 GB,
-        for two different cubes alike)."""
+        """Time K1 on candidate output images and keep the fastest (the output's share of the effect is ~3 %: four
+        candidates at most)."""
         torch = nat.require_gpu()
-        keep, times = self._trials(first, lambda: eng.alloc_image(torch, self.table.nb, npix, self.layout, self.device), probe)
+        keep, times = self._trials(first, lambda: eng.alloc_image(torch, self.table.nb, npix, self.layout, self.device), probe, cap=4)
         self.placement_log[npix] = times
         return keep
 
     def place_inputs(self, cube, real, mask=None):
         """Placement trials for a tile that stays resident and is processed many times (a benchmark loop, a resident
-        mosaic).  step() by itself only places the images the plan owns; but the stretches of device memory that slow K1's
-        write stream slow its read streams too, and the effects do not add (one slow operand costs the same 9 % as
-        three), so a search over one operand at a time sees nothing while another one sits in a slow stretch.  This
-        searches JOINTLY: candidate set i = (cube clone, real clone, output image) allocated back to back - one region -
-        with 4 GB between sets; set 0 is the caller's tensors with a fresh output image.  One untimed and two timed K1
-        launches per set; the fastest set's cube and real are returned and its output image becomes the plan's image for
-        this tile size (so step() runs no further trial).  Same bytes, so results are bit-identical.
+        mosaic).  step() by itself only places the images the plan owns, but it is the CUBE's stretch of device memory
+        that carries most of the effect (tools/dbg/placement13.py: the slow set's cube with the fast set's target and
+        output runs slow, the fast set's cube with the slow set's target and output runs fast).  This searches JOINTLY:
+        candidate set i = (cube clone, real clone, output image) allocated back to back - one stretch - with
+        placement_pitch_gb between sets; set 0 is the caller's tensors with a fresh output image.  One untimed and two
+        timed K1 launches per set; the fastest set's cube and real are
+        returned and its output image becomes the plan's image for this tile size (so step() runs no further trial).
+        Same bytes, so results are bit-identical.
         Returns (cube, real, log)."""
         torch = nat.require_gpu()
         npix = cube.numel() // cube.shape[-1]
@@ -322,7 +299,7 @@ class SpectralFusion:
                 self._batches.pop(next(iter(self._batches)))
             tb = eng.TileBatch(cubes, reals, masks, self.table, self.deg, self.opts)
             tb.place(lambda b: eng.batch_srf_integrate_moments(b, self.min_valid, self.min_valid, self.tile_scale, self.tile_nodata),
-                     self.placement_trials)
+                     self.placement_trials, self.placement_pitch_gb)
             self._batches[key] = tb
         eng.batch_srf_integrate_moments(tb, self.min_valid, self.min_valid, self.tile_scale, self.tile_nodata,
                                         events=k1_events)

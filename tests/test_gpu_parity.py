@@ -1687,7 +1687,7 @@ def test_placement_trials_do_not_change_results(torch_gpu):
     b = SpectralFusion(p.emit_w, p.srf, p.good_mask, deg=3, placement_trials=3)
     oa, ob = a.step(p.cube, p.real), b.step(p.cube, p.real)
     torch.cuda.synchronize()
-    assert a.placement_log == {} and len(b.placement_log[384 * 256]) == 3
+    assert a.placement_log == {} and 1 <= len(b.placement_log[384 * 256]) <= 3
     assert torch.equal(oa.coeffs.view(torch.int64), ob.coeffs.view(torch.int64))
     assert torch.equal(oa.matched.view(torch.int32), ob.matched.view(torch.int32))
     assert torch.equal(oa.pseudo.view(torch.int32), ob.pseudo.view(torch.int32))
@@ -1699,7 +1699,7 @@ def test_placement_trials_do_not_change_results(torch_gpu):
     # joint trials for a resident tile: inputs cloned next to candidate output images; the winner seeds the plan's image
     c = SpectralFusion(p.emit_w, p.srf, p.good_mask, deg=3, placement_trials=3)
     cube2, real2, log = c.place_inputs(p.cube, p.real)
-    assert len(log["joint_ms"]) == 3 and torch.equal(cube2, p.cube) and torch.equal(real2, p.real)
+    assert 1 <= len(log["joint_ms"]) <= 3 and torch.equal(cube2, p.cube) and torch.equal(real2, p.real)
     oc = c.step(cube2, real2)
     torch.cuda.synchronize()
     assert c.placement_log[384 * 256] == log["joint_ms"]          # step() ran no further trial

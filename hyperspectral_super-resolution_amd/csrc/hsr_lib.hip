@@ -46,13 +46,15 @@ __global__ __launch_bounds__(256) void probe_read_kernel(const float4* __restric
 // one barrier per slab, nothing read back.  What this kernel reaches is the ceiling of K1's staging structure on
 // this box (round 1 lab: 6.9 TB/s); a plain global_load stream (mode 1) reads 5.6 TB/s.
 constexpr int kProbeSlab = 72 * 1024;
+// SLAB bytes per barrier: 72 KiB = a float32 group of K1 (modes 0), 36 KiB = a uint16 group (modes 2, 3).
+template <int SLAB>
 __global__ __launch_bounds__(512, 4) void probe_lds_dma_kernel(const char* __restrict__ src, int64_t n16, float* __restrict__ sink) {
   extern __shared__ __attribute__((aligned(16))) unsigned char psmem[];
   typedef __attribute__((address_space(1))) const void* gptr_t;
   typedef __attribute__((address_space(3))) void* lptr_t;
   const int lane = threadIdx.x & 63;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  constexpr int kChunks = kProbeSlab / 16;
+  constexpr int kChunks = SLAB / 16;
   const int64_t nslabs = (n16 + kChunks - 1) / kChunks;
   for (int64_t sl = blockIdx.x; sl < nslabs; sl += gridDim.x) {
     const int64_t base = sl * kChunks;
@@ -66,6 +68,18 @@ __global__ __launch_bounds__(512, 4) void probe_lds_dma_kernel(const char* __res
     __syncthreads();
   }
   if (threadIdx.x == 0 && blockIdx.x == 0) sink[0] = reinterpret_cast<const float*>(psmem)[0];   // keeps the LDS image observable
+}
+
+template <int SLAB>
+static int launch_probe_lds(const void* buf, int64_t bytes, int lds_bytes, int grid_cap, float* sink, hipStream_t stream) {
+  auto kern = probe_lds_dma_kernel<SLAB>;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+  (void)hipGetLastError();
+  const int64_t nslabs = (bytes + SLAB - 1) / SLAB;
+  hipLaunchKernelGGL(kern, dim3((unsigned)(nslabs < grid_cap ? nslabs : grid_cap)), dim3(512), lds_bytes, stream,
+                     (const char*)buf, bytes / 16, sink);
+  HSR_LAUNCH_CHECK("probe_lds_dma_kernel");
+  return HSR_OK;
 }
 
 }  // namespace hsr
@@ -84,23 +98,15 @@ extern "C" size_t hsr_partials_bytes(int32_t nb, int32_t deg) {
 extern "C" int hsr_probe_read(const void* buf_dev, int64_t bytes, int32_t mode, float* sink_dev, hsr_stream_t stream) {
   HSR_REQUIRE(buf_dev && sink_dev && bytes >= 16, HSR_ERR_INVALID, "hsr_probe_read: bad argument");
   HSR_REQUIRE(((uintptr_t)buf_dev & 15) == 0, HSR_ERR_INVALID, "hsr_probe_read: buffer not 16-byte aligned");
-  HSR_REQUIRE(mode == 0 || mode == 1, HSR_ERR_INVALID, "hsr_probe_read: mode must be 0 (LDS-DMA nt) or 1 (global_load)");
+  HSR_REQUIRE(mode >= 0 && mode <= 3, HSR_ERR_INVALID, "hsr_probe_read: mode must be 0..3");
   if (mode == 1) {
     hipLaunchKernelGGL(hsr::probe_read_kernel, dim3(2048), dim3(256), 0, (hipStream_t)stream,
                        (const float4*)buf_dev, bytes / 16, sink_dev);
     HSR_LAUNCH_CHECK("probe_read_kernel");
     return HSR_OK;
   }
-  static thread_local bool configured = false;
-  if (!configured) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(hsr::probe_lds_dma_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
-                              hsr::kProbeSlab);
-    (void)hipGetLastError();
-    configured = true;
-  }
-  const int64_t nslabs = (bytes + hsr::kProbeSlab - 1) / hsr::kProbeSlab;
-  hipLaunchKernelGGL(hsr::probe_lds_dma_kernel, dim3((unsigned)(nslabs < 512 ? nslabs : 512)), dim3(512), hsr::kProbeSlab,
-                     (hipStream_t)stream, (const char*)buf_dev, bytes / 16, sink_dev);
-  HSR_LAUNCH_CHECK("probe_lds_dma_kernel");
-  return HSR_OK;
+  // LDS footprint decides how many workgroups share a CU (160 KiB): 72 KiB -> 2, 36 KiB -> 4
+  if (mode == 0) return hsr::launch_probe_lds<hsr::kProbeSlab>(buf_dev, bytes, hsr::kProbeSlab, 512, sink_dev, (hipStream_t)stream);
+  if (mode == 2) return hsr::launch_probe_lds<hsr::kProbeSlab / 2>(buf_dev, bytes, hsr::kProbeSlab, 512, sink_dev, (hipStream_t)stream);
+  return hsr::launch_probe_lds<hsr::kProbeSlab / 2>(buf_dev, bytes, hsr::kProbeSlab / 2, 1024, sink_dev, (hipStream_t)stream);
 }

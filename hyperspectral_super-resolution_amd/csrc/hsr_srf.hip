@@ -1043,6 +1043,17 @@ __device__ __forceinline__ void glds4_asm(const void* gaddr, uint32_t lds_base) 
 // the next top barrier.  Same arithmetic, same summation trees -> same bits as srf_u16_kernel.
 // Batch launches: the group after the last one of a unit is the first group of the workgroup's next unit, so three
 // unit records are alive: cu (being reduced), nu (being prefetched), nn (its record is on its way).
+// Where an iteration goes (r02, -DHSR_PHASE_STAMPS, tools/k1_stamps 1024 1024 64 1, deg 3): wait for the own DMA 3 %,
+// top barrier 13 %, issue of the next group's DMA + flush 32 %, sweep + barrier 22 %, dot products + moments 31 %
+// (the wave with the 48-tap band 2850 cycles, the others ~1770).  The DMA has landed when the waves come back for it; the
+// time goes into the ISSUE of 4-5 global_load_lds per wave, which blocks at HBM pace because the CU's request queue is
+// full (hsr_probe_read mode 2: the same 36 KiB groups with nothing else read 6.9-7.0 TB/s), and a blocked wave computes
+// nothing.  Measured and dropped: the issue spread in five pieces over the iteration (the blocked time moves with it,
+// 0.162 vs 0.159 ms on one box); one producer wave issuing everything and flushing the rows, 7 consumer waves with a
+// consumer-only LDS counter instead of the second barrier (a single wave issues 1 KB per ~155 cycles: 0.178 ms; two
+// producer waves: 0.174 ms - the consumers, whose target loads wait in the same full queue and whose widest band sets
+// the pace, are the critical path then); deferring flags and moments by one iteration to drop the second barrier
+// (43-58 spilled VGPRs in the loop, and scratch waits in the same queue: 0.258 ms).
 template <int DEG, bool OUTV, bool BATCH, bool FASTU>
 __global__ __launch_bounds__(512, 4) void srf_u16_ring_kernel(const SrfArgs a) {
   constexpr int P = 64, T = 512;
@@ -1151,7 +1162,11 @@ __global__ __launch_bounds__(512, 4) void srf_u16_ring_kernel(const SrfArgs a) {
   bool pend = false;
   double* pend_part = nullptr;
 
+#ifdef HSR_PHASE_STAMPS
+  unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
   for (bool more = true; more; cur ^= 1) {
+    HSR_STAMP(st0);
     const int64_t pix0 = (int64_t)g * P;
     const int64_t left = cu.npix - pix0;
     const int npx = left < P ? (int)left : P;
@@ -1163,6 +1178,7 @@ __global__ __launch_bounds__(512, 4) void srf_u16_ring_kernel(const SrfArgs a) {
     if (t < P) fl[t] = 0u;
     // everything this wave issued one iteration ago has landed: group k, its targets, the flush of group k-2
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    HSR_STAMP(st1);
     float yv[kBandSlots];
     static_assert(kBandSlots == 2, "two target registers");
     yv[0] = yn[0];
@@ -1174,6 +1190,7 @@ __global__ __launch_bounds__(512, 4) void srf_u16_ring_kernel(const SrfArgs a) {
       for (int i = t; i < nchunk * 8; i += T) tile[i] = i < n ? src[i] : (uint16_t)0;
     }
     __syncthreads();   // group k (every wave's share of the DMA) and the staged planes of group k-1 are visible
+    HSR_STAMP(st2);
 
     // group k+1: the next group of this unit, or the first group of the workgroup's next unit.
     // Buffer cur^1 was last read before the barrier above.
@@ -1198,9 +1215,11 @@ __global__ __launch_bounds__(512, 4) void srf_u16_ring_kernel(const SrfArgs a) {
       pend = false;
     }
 
+    HSR_STAMP(st3);
     if (has_nodata) u16_nodata_sweep(reinterpret_cast<const uint4*>(tile), nchunk, npx * B, B, nd2, a.nodata, fl, t);
     // flags of group k complete; also orders the flush reads of the staged slab before the writes below
     lds_barrier();
+    HSR_STAMP(st4);
 
     const bool bad = fl[pl] != 0u;
 #pragma unroll
@@ -1225,6 +1244,15 @@ __global__ __launch_bounds__(512, 4) void srf_u16_ring_kernel(const SrfArgs a) {
         }
       }
     }
+#ifdef HSR_PHASE_STAMPS
+    {
+      HSR_STAMP(st5);
+      // 0: own DMA share + stores landed, 1: barrier (slowest wave's share), 2: issue DMA k+1 + flush k-1 (+ batch flush),
+      // 3: sweep + barrier, 4: dots + moments, 5: whole iteration
+      if (a.stamps) { stamp_acc[0] += st1 - st0; stamp_acc[1] += st2 - st1; stamp_acc[2] += st3 - st2; stamp_acc[3] += st4 - st3;
+                      stamp_acc[4] += st5 - st4; stamp_acc[5] += st5 - st0; stamp_acc[6] += 1; }
+    }
+#endif
     prev_out = cu.pseudo_dev;
     prev_pix0 = pix0;
     prev_npx = npx;
@@ -1242,6 +1270,10 @@ __global__ __launch_bounds__(512, 4) void srf_u16_ring_kernel(const SrfArgs a) {
       }
     }
   }
+#ifdef HSR_PHASE_STAMPS
+  if (a.stamps && lane == 0)
+    for (int k = 0; k < 8; ++k) a.stamps[((size_t)blockIdx.x * 8 + wave) * 8 + k] = stamp_acc[k];
+#endif
   if (OUTV) {
     __syncthreads();
     flush_stage<T>(ostage, prev_out, prev_pix0, prev_npx, ops, t);
@@ -1264,6 +1296,9 @@ template <int DEG, bool OUTV, bool BATCH, bool FASTU>
 static int launch_srf_u16_ring(const SrfArgs& a, int grid, hipStream_t stream) {
   const size_t lds = (size_t)2 * 64 * a.B * 2 + 128 * sizeof(uint32_t) + (size_t)a.wtaps * 4 + (OUTV ? (size_t)64 * a.out_ps * 4 : 0);
   auto kern = srf_u16_ring_kernel<DEG, OUTV, BATCH, FASTU>;
+#ifdef HSR_PHASE_STAMPS
+  const_cast<SrfArgs&>(a).stamps = g_stamp_buffer;
+#endif
   static thread_local size_t configured = 0;
   ensure_dynamic_lds(kern, lds, &configured);
   hipLaunchKernelGGL(kern, dim3(grid), dim3(512), lds, stream, a);

@@ -761,7 +761,7 @@ def bilinear_upsample(coarse, Hc: int, Wc: int, factor: int, layout: str = PLANA
 def probe_read_bandwidth(nbytes: int = 1 << 30, iters: int = 10, device="cuda:0", mode: int = 0) -> float:
     """Measured pure-read HBM rate of this box in bytes/s (diagnostic for the roofline report).
     mode 0: K1's own load shape (non-temporal LDS-DMA, 72 KiB slabs, 512 persistent workgroups) - a ceiling for K1;
-    mode 1: a plain 16-byte global_load stream."""
+    mode 1: a plain 16-byte global_load stream; modes 2 / 3: 36 KiB slabs with 2 / 4 workgroups per CU (hsr.h)."""
     torch = nat.require_gpu()
     lib = nat.load()
     buf = torch.empty(nbytes // 4, dtype=torch.float32, device=device).normal_()

@@ -412,7 +412,9 @@ int hsr_bilinear_upsample(const float* in_dev, int64_t in_bs, int64_t in_ps, int
  * Pure streaming read of `bytes` bytes (a multiple of 16, 16-byte aligned base): the measured HBM read ceiling of
  * the box, reported by bench.py beside the vendor peak.  mode 0: K1's own load shape - non-temporal LDS-DMA
  * (global_load_lds_dwordx4 nt), 72 KiB slabs, 512 persistent workgroups, nothing computed (a ceiling for K1);
- * mode 1: plain 16-byte global_load per lane folded into sink_dev[64] (what an ordinary streaming kernel reads). */
+ * mode 1: plain 16-byte global_load per lane folded into sink_dev[64] (what an ordinary streaming kernel reads);
+ * mode 2: as 0 with 36 KiB slabs - the uint16 kernel's group - still 2 workgroups per CU (73 KB per CU in flight);
+ * mode 3: 36 KiB slabs, 4 workgroups per CU (146 KB per CU in flight: what a deeper ring would reach). */
 int hsr_probe_read(const void* buf_dev, int64_t bytes, int32_t mode, float* sink_dev, hsr_stream_t stream);
 
 #ifdef __cplusplus

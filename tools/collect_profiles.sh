@@ -25,6 +25,9 @@ for c in f32 u16; do timeout -k 10 200 python tools/bench_batch.py --tiles 256 -
 timeout -k 10 200 python tools/bench_batch.py --tiles 64 > $O/batch_f32_t64.json 2>/dev/null
 for c in FETCH_SIZE WRITE_SIZE; do timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_batch/$c -o p -- python3 tools/bench_batch.py --tiles 256 --no-loop --rounds 1 --reps 3 > /dev/null 2> $O/pmc_batch_$c.log || echo fail; done
 echo "== feed"; timeout -k 10 400 python tools/bench_feed.py > $O/feed.log 2>&1
-echo "== stamps"; timeout -k 5 120 tools/k1_stamps 1024 1024 64 > $O/k1_stamps.log 2>&1
+echo "== stamps"; timeout -k 5 120 tools/k1_stamps 1024 1024 64 > $O/k1_stamps.log 2>&1; timeout -k 5 120 tools/k1_stamps 1024 1024 64 1 > $O/k1_stamps_u16.log 2>&1
+echo "== probe modes"; timeout -k 10 120 python tools/dbg/probe_modes.py > $O/probe_modes.log 2>&1
+echo "== reduce kernels"; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_rs -o rs -- python3 tools/dbg/rs_time.py > /dev/null 2> $O/trace_rs.log
+echo "== address map"; timeout -k 10 200 python tools/dbg/placement13.py 28 4 > $O/placement_map.log 2>&1
 echo "== placement"; timeout -k 10 200 python tools/placement_probe.py > $O/placement_probe.log 2>&1; timeout -k 10 200 python tools/state_probe.py > $O/state_probe.log 2>&1
 echo done

@@ -79,6 +79,8 @@ def parse_args():
                          "off the bit-exact path)")
     ap.add_argument("--fused-fit", action="store_true",
                     help="slot reduction + solve inside K1's launch (hsr_srf_integrate_fit); measured 3 us/step slower, off by default")
+    ap.add_argument("--settle-ms", type=float, default=250.0,
+                    help="milliseconds of untimed steps before the warm-up, to reach the GPU's settled power state (0: none)")
     ap.add_argument("--no-input-placement", action="store_true",
                     help="keep the synthetic cube / target where the allocator first put them (no placement trials for inputs)")
     ap.add_argument("--event-every", type=int, default=4,
@@ -278,17 +280,31 @@ def main():
             return plan.submit(cube, real, k1_events=k1_events)
         return plan.step(cube, real, k1_events=k1_events)
 
+    # A generation-2 pass of Python's cycle collector takes ~40 ms with torch imported - several times the whole
+    # timed region - and stalls the launch thread (seen in rocprof traces as a 37-50 ms idle gap in front of one
+    # kernel).  As timeit does: collect now, keep the collector off while timing.  (Before the warm-up, not between
+    # warm-up and timed region: 40 ms of idle GPU there put the timed steps into the transient described next.)
+    import gc
+    gc.collect()
+    gc.disable()
+    # Steady state before timing (tools/dbg/ramp.py, profiles/r02_ramp.log): started from a GPU that idled for >= 10 ms,
+    # the first ~10 steps run at full speed, the next ~100 run 6-10 % slower (0.243-0.254 against 0.221 ms) and only
+    # then the step time settles - a power-management transient, longer than a 20-step timed region.  A pipeline that
+    # processes tiles continuously lives in the settled state, so the bench loads the GPU with untimed steps for
+    # --settle-ms before the W warm-up steps; the timed region follows the warm-up with no host work in between.
+    settle_steps = 0
+    if args.settle_ms > 0:
+        t_s = time.perf_counter()
+        while (time.perf_counter() - t_s) * 1e3 < args.settle_ms:
+            for _ in range(25):
+                run_step()
+            settle_steps += 25
+            torch.cuda.synchronize()
     for _ in range(max(args.warmup, 1)):    # always one untimed pass: code-object load and LDS attributes are setup, not a step
         run_step()
     if pipelined:
         plan.flush()
     barrier()
-    # A generation-2 pass of Python's cycle collector takes ~40 ms with torch imported - several times the whole
-    # timed region - and stalls the launch thread (seen in rocprof traces as a 37-50 ms idle gap in front of one
-    # kernel).  As timeit does: collect now, keep the collector off while timing.
-    import gc
-    gc.collect()
-    gc.disable()
     every = max(1, args.event_every)
     ev = {i: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
           for i in range(0, args.steps, every)}
@@ -363,6 +379,9 @@ def main():
                            "tiles_per_gpu": ntl, "coeff_sync": (args.coeff_sync if world > 1 else "none") +
                            (f" (rehearsal: one-rank RCCL {args.coeff_sync} forced)" if args.force_exchange else ""),
                            "pipeline": f"one tile deep, {args.reserve_cus} CUs reserved" if pipelined else "off",
+                           "settle": {"ms": args.settle_ms, "untimed_steps": settle_steps,
+                                      "note": "untimed load before the W warm-up steps: from idle a 20-step region sits in a "
+                                              "power-management transient 6-10 % slower than the continuous-load state"},
                            "launches_per_step": 2 if (args.fused_fit and world == 1 and not args.force_exchange and ntl == 1) else None,
                            "placement": {"trials_ms": plan.placement_log.get(H * W), "joint_with_inputs": input_log is not None,
                                          "search_seconds": (input_log or {}).get("seconds"),

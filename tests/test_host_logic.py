@@ -82,7 +82,7 @@ def test_sizing_helpers_and_error_strings():
     assert lib.hsr_ot_iterate(10, 10, 0, 5, 1e-6, ctypes.c_void_p(8), None, None) == 1 and b"256-byte aligned" in lib.hsr_last_error()
     assert lib.hsr_gram_f64(P, 30, 32, P, 48, 48, 10, P, P, 48, None) == 1
     assert lib.hsr_gram_work_bytes(288, 576, 29127) >= 34 * 18 * 36 * 256 * 8
-    assert lib.hsr_probe_read(P, 1 << 20, 2, P, None) == 1 and b"mode" in lib.hsr_last_error()
+    assert lib.hsr_probe_read(P, 1 << 20, 4, P, None) == 1 and b"mode" in lib.hsr_last_error()
 
 
 def test_batch_plan_host_side():

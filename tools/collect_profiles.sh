@@ -7,7 +7,8 @@ cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 O=gpurun_out/r02final; mkdir -p $O
 echo "== bench default"; timeout -k 10 300 python bench.py > $O/bench_n1.json 2> $O/bench_n1.err; tail -c 300 $O/bench_n1.json
 echo "== six fresh processes"; for i in 1 2 3 4 5 6; do timeout -k 10 200 python bench.py --steps 100 --no-cpu-baseline > $O/fresh_$i.json 2>/dev/null; done
-echo "== driver style (steps 20)"; for i in 1 2 3; do timeout -k 10 200 python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-probe > $O/s20_$i.json 2>/dev/null; done
+echo "== driver style (steps 20)"; for i in 1 2 3; do timeout -k 10 200 python bench.py --gpus 1 --steps 20 --warmup 5 --no-cpu-baseline --no-probe > $O/s20_$i.json 2>/dev/null; done
+timeout -k 10 200 python bench.py --gpus 1 --steps 20 --warmup 5 --settle-ms 0 --no-cpu-baseline --no-probe > $O/s20_nosettle.json 2>/dev/null
 echo "== kernel trace"; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace -o bench -- python3 bench.py --no-cpu-baseline > $O/bench_under_rocprof.json 2> $O/trace.log
 for c in FETCH_SIZE WRITE_SIZE "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_BUSY_CYCLES GRBM_GUI_ACTIVE"; do
   n=$(echo $c | cut -d' ' -f1); echo "== pmc $n"
@@ -28,6 +29,7 @@ echo "== feed"; timeout -k 10 400 python tools/bench_feed.py > $O/feed.log 2>&1
 echo "== stamps"; timeout -k 5 120 tools/k1_stamps 1024 1024 64 > $O/k1_stamps.log 2>&1; timeout -k 5 120 tools/k1_stamps 1024 1024 64 1 > $O/k1_stamps_u16.log 2>&1
 echo "== probe modes"; timeout -k 10 120 python tools/dbg/probe_modes.py > $O/probe_modes.log 2>&1
 echo "== reduce kernels"; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_rs -o rs -- python3 tools/dbg/rs_time.py > /dev/null 2> $O/trace_rs.log
+echo "== ramp"; timeout -k 10 200 python tools/dbg/ramp.py > $O/ramp.log 2>&1
 echo "== address map"; timeout -k 10 200 python tools/dbg/placement13.py 28 4 > $O/placement_map.log 2>&1
 echo "== placement"; timeout -k 10 200 python tools/placement_probe.py > $O/placement_probe.log 2>&1; timeout -k 10 200 python tools/state_probe.py > $O/state_probe.log 2>&1
 echo done

@@ -70,13 +70,16 @@ def main():
                     w.writerow(r)
     # ---- fresh processes
     out = [f"# {tag}: the headline over fresh processes (one box, back to back)\n",
-           "`python bench.py --steps 100 --no-cpu-baseline` six times, then `--steps 20 --warmup 3` (the driver's shape) three times.\n",
+           "`python bench.py --steps 100 --no-cpu-baseline` six times, then `--gpus 1 --steps 20 --warmup 5` (the driver's command) three times.\n",
            "| run | steps | ms/step | K1+K2 ms (HIP events) | frac of 8 TB/s | placement trials (ms) |", "|---|---|---|---|---|---|"]
     for pat, st in (("fresh_%d.json", 100), ("s20_%d.json", 20)):
         for i in range(1, 7):
             d = jload(os.path.join(src, pat % i))
             if d:
                 out.append(f"| {i} | {st} | {d['ms_per_step']} | {d['roofline']['kernel_ms']} | {d['roofline']['frac']} | {d['config'].get('placement', {}).get('trials_ms')} |")
+    d = jload(os.path.join(src, "s20_nosettle.json"))
+    if d:
+        out.append(f"\nThe driver's command with `--settle-ms 0` (timed region started from an idle GPU): {d['ms_per_step']} ms/step, K1+K2 {d['roofline']['kernel_ms']} ms.")
     open(os.path.join(P, f"{tag}_fresh_processes.md"), "w").write("\n".join(out) + "\n")
     # ---- batch
     out = [f"# {tag}: batched small tiles (tools/bench_batch.py; 100 x 100 x 285 tiles, deg 3)\n"]
@@ -132,8 +135,16 @@ def main():
         out.append("8 x 1024 x 1024 x 285 tiles resident on one GPU, one global fit per step (`--tiles-per-gpu 8`): " +
                    json.dumps({"value": d["value"], "ms_per_step": d["ms_per_step"], "step_frac_of_peak": d["roofline"]["step_frac_of_peak"]}) + "\n")
     open(os.path.join(P, f"{tag}_rehearsals.md"), "w").write("\n".join(out) + "\n")
+    ks = kstats(os.path.join(src, "trace_rs"))
+    if ks:
+        out = [f"# {tag}: slot reduction + solve kernels (`rocprofv3 --kernel-trace --stats -- python3 tools/dbg/rs_time.py`)\n",
+               "512 slots of a 512 x 512 tile (single-tile kernels), 256 tiles of 100 x 100 (batched kernel, 157 slots each = 54 MB of partials).\n",
+               "| kernel | calls | avg us | min us | max us |", "|---|---|---|---|---|"]
+        out += [f"| `{n}` | {c} | {a:.2f} | {lo:.2f} | {hi:.2f} |" for n, c, a, lo, hi in ks if "reduce" in n or "solve" in n]
+        open(os.path.join(P, f"{tag}_reduce_solve.md"), "w").write("\n".join(out) + "\n")
     for name, dst in (("feed.log", f"{tag}_feed.md"), ("k1_stamps.log", f"{tag}_k1_phase_stamps.log"), ("placement_probe.log", f"{tag}_placement_probe.log"),
-                      ("state_probe.log", f"{tag}_state_probe.log")):
+                      ("state_probe.log", f"{tag}_state_probe.log"), ("k1_stamps_u16.log", f"{tag}_k1_phase_stamps_u16.log"),
+                      ("probe_modes.log", f"{tag}_probe_modes.log"), ("placement_map.log", f"{tag}_placement_map.log"), ("ramp.log", f"{tag}_ramp.log")):
         s = os.path.join(src, name)
         if os.path.isfile(s):
             txt = "".join(l for l in open(s, errors="replace") if "amdgpu.ids" not in l and "Warning" not in l)

@@ -332,9 +332,20 @@ struct PredArgs {
   const float* bias;           // [T]
   int32_t T, ttiles;           // ttiles = ceil(T / 32)
   int32_t act;                 // 1: sigmoid(clip(z, +-50)); 0: raw
+  int32_t nan_bad;             // 1: a pixel with a non-finite (or nodata) input comes out NaN in every target
+  int32_t use_nodata;
+  float nodata;
   float* out;                  // (T, out_stride)
   int64_t out_stride;
 };
+
+// predict_cube_logit's rule for unusable pixels (Spectral_matching.ipynb raw lines 197-203): any input non-finite, or
+// close to the nodata value in torch.isclose's sense (|x - nd| <= 1e-8 + 1e-5 |nd|, equal infinities close, NaN never).
+__device__ __forceinline__ bool pred_bad_input(float x, int use_nodata, float nd) {
+  const bool nonfinite = (__float_as_uint(x) & 0x7f800000u) == 0x7f800000u;
+  const bool close = use_nodata && (x == nd || fabsf(x - nd) <= 1e-8f + 1e-5f * fabsf(nd));
+  return nonfinite || close;
+}
 
 constexpr int kPredPix = 64;      // pixels per workgroup tile
 constexpr int kPredThreads = 256;
@@ -345,6 +356,7 @@ __global__ __launch_bounds__(kPredThreads) void predict_kernel(const PredArgs a)
   const int ldphi = a.kpad + 1;                      // odd row stride -> conflict-free column walks
   float* phi = reinterpret_cast<float*>(smem);       // [64][ldphi]
   float* zt = phi + kPredPix * ldphi;                // [64][n_in + 1]
+  uint32_t* badl = reinterpret_cast<uint32_t*>(zt + kPredPix * (a.n_in + 1));   // [64]
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int nz = a.n_in + 1;
   for (int64_t tile = blockIdx.x; tile * kPredPix < a.npix; tile += gridDim.x) {
@@ -355,6 +367,12 @@ __global__ __launch_bounds__(kPredThreads) void predict_kernel(const PredArgs a)
       float v = 1.0f;
       if (c < a.n_in) v = (p0 + p < a.npix) ? (a.x[(p0 + p) * a.x_ps + c * a.x_cs] - a.mean[c]) * a.inv[c] : 0.0f;
       zt[p * nz + c] = v;
+    }
+    if (t < kPredPix) {
+      uint32_t bad = 0u;
+      if (a.nan_bad && p0 + t < a.npix)
+        for (int c = 0; c < a.n_in; ++c) bad |= pred_bad_input(a.x[(p0 + t) * a.x_ps + c * a.x_cs], a.use_nodata, a.nodata) ? 1u : 0u;
+      badl[t] = bad;
     }
     __syncthreads();
     for (int i = t; i < kPredPix * a.kpad; i += kPredThreads) {
@@ -402,6 +420,7 @@ __global__ __launch_bounds__(kPredThreads) void predict_kernel(const PredArgs a)
               v = v < -50.0f ? -50.0f : (v > 50.0f ? 50.0f : v);   // NaN falls through, like np.clip
               v = 1.0f / (1.0f + __expf(-v));
             }
+            if (badl[ph + j]) v = __uint_as_float(0x7fc00000u);
             a.out[(size_t)trg * a.out_stride + p] = v;
           }
         }
@@ -495,8 +514,14 @@ __global__ __launch_bounds__(256, 2) void predict103_kernel(const PredArgs a) {
     const int64_t p = tile * 128 + wave * 32 + j;
     const int64_t pc = p < a.npix ? p : a.npix - 1;
     float z[11];
+    bool bad = false;
 #pragma unroll
-    for (int c = 0; c < 10; ++c) z[c] = (a.x[pc * a.x_ps + c * a.x_cs] - a.mean[c]) * a.inv[c];
+    for (int c = 0; c < 10; ++c) {
+      const float xr = a.x[pc * a.x_ps + c * a.x_cs];
+      bad = bad || pred_bad_input(xr, a.use_nodata, a.nodata);
+      z[c] = (xr - a.mean[c]) * a.inv[c];
+    }
+    bad = bad && a.nan_bad != 0;
     z[10] = 1.0f;
     f32x16 acc[TT];
 #pragma unroll
@@ -550,6 +575,7 @@ __global__ __launch_bounds__(256, 2) void predict103_kernel(const PredArgs a) {
               v = v < -50.0f ? -50.0f : (v > 50.0f ? 50.0f : v);
               v = 1.0f / (1.0f + __expf(-v));
             }
+            if (bad) v = __uint_as_float(0x7fc00000u);
             orow[(size_t)tu * ostride] = v;
           }
         }
@@ -582,8 +608,14 @@ __global__ __launch_bounds__(512, 2) void predict103_slice_kernel(const PredArgs
     const int64_t p = tile * 256 + wave * 32 + j;
     const int64_t pc = p < a.npix ? p : a.npix - 1;
     float z[11];
+    bool bad = false;
 #pragma unroll
-    for (int c = 0; c < 10; ++c) z[c] = (a.x[pc * a.x_ps + c * a.x_cs] - a.mean[c]) * a.inv[c];
+    for (int c = 0; c < 10; ++c) {
+      const float xr = a.x[pc * a.x_ps + c * a.x_cs];
+      bad = bad || pred_bad_input(xr, a.use_nodata, a.nodata);
+      z[c] = (xr - a.mean[c]) * a.inv[c];
+    }
+    bad = bad && a.nan_bad != 0;
     z[10] = 1.0f;
     f32x16 acc[TT];
 #pragma unroll
@@ -608,6 +640,7 @@ __global__ __launch_bounds__(512, 2) void predict103_slice_kernel(const PredArgs
               v = v < -50.0f ? -50.0f : (v > 50.0f ? 50.0f : v);
               v = 1.0f / (1.0f + __expf(-v));
             }
+            if (bad) v = __uint_as_float(0x7fc00000u);
             orow[(size_t)tu * ostride] = v;
           }
         }
@@ -817,6 +850,15 @@ extern "C" int hsr_polyfeat_predict(const float* x_dev, int64_t x_ps, int64_t x_
                                     const float* inv_scale_dev, int64_t npix, int32_t n_in, int32_t degree,
                                     const float* w_dev, int64_t ldw, const float* bias_dev, int32_t T,
                                     int32_t activation, float* out_dev, int64_t out_stride, hsr_stream_t stream) {
+  return hsr_polyfeat_predict_cube(x_dev, x_ps, x_cs, mean_dev, inv_scale_dev, npix, n_in, degree, w_dev, ldw, bias_dev, T,
+                                   activation, 0, 0.0f, 0, out_dev, out_stride, stream);
+}
+
+extern "C" int hsr_polyfeat_predict_cube(const float* x_dev, int64_t x_ps, int64_t x_cs, const float* mean_dev,
+                                         const float* inv_scale_dev, int64_t npix, int32_t n_in, int32_t degree,
+                                         const float* w_dev, int64_t ldw, const float* bias_dev, int32_t T,
+                                         int32_t activation, int32_t nan_bad_pixels, float nodata, int32_t use_nodata,
+                                         float* out_dev, int64_t out_stride, hsr_stream_t stream) {
   HSR_REQUIRE(x_dev && mean_dev && inv_scale_dev && w_dev && bias_dev && out_dev, HSR_ERR_INVALID,
               "hsr_polyfeat_predict: NULL pointer");
   HSR_REQUIRE(npix > 0 && T >= 1 && ldw >= T && out_stride >= npix, HSR_ERR_INVALID, "hsr_polyfeat_predict: bad shape");
@@ -839,13 +881,16 @@ extern "C" int hsr_polyfeat_predict(const float* x_dev, int64_t x_ps, int64_t x_
   a.T = T;
   a.ttiles = (T + 31) / 32;
   a.act = activation;
+  a.nan_bad = nan_bad_pixels != 0;
+  a.use_nodata = use_nodata != 0;
+  a.nodata = nodata;
   a.out = out_dev;
   a.out_stride = out_stride;
   if (degree == 3 && try_predict103(a, (hipStream_t)stream)) {
     HSR_LAUNCH_CHECK("predict103_kernel");
     return HSR_OK;
   }
-  const size_t lds = ((size_t)kPredPix * (a.kpad + 1) + (size_t)kPredPix * (n_in + 1)) * sizeof(float);
+  const size_t lds = ((size_t)kPredPix * (a.kpad + 1) + (size_t)kPredPix * (n_in + 1) + kPredPix) * sizeof(float);
   HSR_REQUIRE(lds <= 150 * 1024, HSR_ERR_UNSUPPORTED, "hsr_polyfeat_predict: %zu bytes of LDS needed", lds);
   int64_t tiles = (npix + kPredPix - 1) / kPredPix;
   const int grid = (int)(tiles < 512 ? tiles : 512);

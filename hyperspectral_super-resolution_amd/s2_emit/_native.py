@@ -123,6 +123,8 @@ SIGNATURES = {
     "hsr_gram_f64": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _i64, _vp, _vp, _i64, _vp]),
     "hsr_polyfeat_predict": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _i32, _i32,
                                        _vp, _i64, _vp]),
+    "hsr_polyfeat_predict_cube": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _i32, _i32,
+                                            _i32, _f32, _i32, _vp, _i64, _vp]),
     "hsr_block_mean": (C.c_int, [_vp, _i32, _i64, _i64, _i32, _i32, _i32, _i32, _f32, _vp, _i64, _i64, _vp]),
     "hsr_bilinear_upsample": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _i64, _vp]),
     "hsr_probe_read": (C.c_int, [_vp, _i64, _i32, _vp, _vp]),

@@ -218,7 +218,7 @@ class PolyRidge:
         return self.solve_gram(G, mean, scale, Xd.shape[1], Yd.shape[1])
 
     # ---- predict ------------------------------------------------------------------------------------
-    def _predict_dev(self, x, x_ps: int, x_cs: int, npix: int, activation: int):
+    def _predict_dev(self, x, x_ps: int, x_cs: int, npix: int, activation: int, nan_bad: bool = False, nodata=None):
         torch = nat.require_gpu()
         lib = nat.load()
         if not self._dev:
@@ -226,9 +226,11 @@ class PolyRidge:
         nat.check(lib.hsr_polyfeat_prepare(self.n_in, self.degree), "hsr_polyfeat_prepare")
         d = self._dev
         out = torch.empty((self.n_targets, npix), dtype=torch.float32, device=x.device)
-        nat.check(lib.hsr_polyfeat_predict(_ptr(x), x_ps, x_cs, _ptr(d["mean"]), _ptr(d["inv"]), npix, self.n_in,
-                                           self.degree, _ptr(d["W"]), d["W"].stride(0), _ptr(d["b"]), self.n_targets,
-                                           activation, _ptr(out), out.stride(0), _stream(torch, out)), "hsr_polyfeat_predict")
+        nat.check(lib.hsr_polyfeat_predict_cube(_ptr(x), x_ps, x_cs, _ptr(d["mean"]), _ptr(d["inv"]), npix, self.n_in,
+                                                self.degree, _ptr(d["W"]), d["W"].stride(0), _ptr(d["b"]), self.n_targets,
+                                                activation, 1 if nan_bad else 0, 0.0 if nodata is None else float(nodata),
+                                                0 if nodata is None else 1, _ptr(out), out.stride(0), _stream(torch, out)),
+                  "hsr_polyfeat_predict_cube")
         return out
 
     def predict(self, X):
@@ -245,12 +247,8 @@ class PolyRidge:
         Xd = (X_bhw if _is_torch(X_bhw) else torch.from_numpy(np.ascontiguousarray(X_bhw, dtype=np.float32)))
         Xd = Xd.to("cuda", torch.float32).contiguous()
         Cc, H, W = Xd.shape
-        out = self._predict_dev(Xd, 1, H * W, H * W, 1)
-        x2 = Xd.reshape(Cc, -1)
-        bad = ~torch.isfinite(x2).all(dim=0)
-        if nodata is not None:
-            bad |= torch.isclose(x2, torch.tensor(float(nodata), device=x2.device)).any(dim=0)
-        out[:, bad] = float("nan")
+        # the rule for unusable pixels (non-finite or nodata input -> NaN in every target) is part of the kernel's epilogue
+        out = self._predict_dev(Xd, 1, H * W, H * W, 1, nan_bad=True, nodata=nodata)
         out = out.reshape(self.n_targets, H, W)
         return out if _is_torch(X_bhw) else out.cpu().numpy()
 

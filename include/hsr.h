@@ -395,6 +395,14 @@ int hsr_polyfeat_predict(const float* x_dev, int64_t x_ps, int64_t x_cs, const f
                          const float* inv_scale_dev, int64_t npix, int32_t n_in, int32_t degree,
                          const float* w_dev, int64_t ldw, const float* bias_dev, int32_t T, int32_t activation,
                          float* out_dev, int64_t out_stride, hsr_stream_t stream);
+/* The same with predict_cube_logit's rule for unusable pixels fused into the epilogue (Spectral_matching.ipynb raw
+ * lines 197-203: `bad = ~isfinite(X).all(0) | isclose(X, nodata).any(0); out[:, bad] = nan`): nan_bad_pixels != 0 -> a
+ * pixel with a non-finite input, or (use_nodata) an input within 1e-8 + 1e-5 |nodata| of nodata, is NaN in every target. */
+int hsr_polyfeat_predict_cube(const float* x_dev, int64_t x_ps, int64_t x_cs, const float* mean_dev,
+                              const float* inv_scale_dev, int64_t npix, int32_t n_in, int32_t degree,
+                              const float* w_dev, int64_t ldw, const float* bias_dev, int32_t T,
+                              int32_t activation, int32_t nan_bad_pixels, float nodata, int32_t use_nodata,
+                              float* out_dev, int64_t out_stride, hsr_stream_t stream);
 
 /* ---- f1: grid-aligned resamplers between the phases -----------------------------------------------
  * downsample_s2_to_grid ('average') and reproject_stack_to_grid ('bilinear') of the notebook

@@ -1748,3 +1748,42 @@ def test_fused_fit_bit_identical_to_reduce_solve(torch_gpu):
                         assert int(b.ws.tickets.abs().sum()) == 0, tag
                     assert torch.isfinite(ob.coeffs).all()
                     assert torch.equal(ob.coeffs[5], torch.tensor([0.0] * (deg - 1) + [1.0, 0.0], dtype=torch.float64, device="cuda"))
+
+
+@pytest.mark.gpu
+def test_predict_cube_bad_pixel_rule_in_kernel(torch_gpu):
+    """predict_cube_logit's rule for unusable pixels (Spectral_matching.ipynb raw lines 197-203: any input non-finite, or
+    isclose to nodata -> NaN in every target) is part of the predict kernels' epilogue (hsr_polyfeat_predict_cube): same
+    mask as torch's isfinite / isclose, clean pixels bit-identical to a call on the cleaned cube - for the three kernel
+    families (10 inputs deg 3 with T <= 32 / 33-96 / 285 targets: W resident, chunked, sliced) and the generic kernel."""
+    torch = torch_gpu
+    import s2_emit
+    rng = np.random.default_rng(23)
+    for Cin, deg, T in ((10, 3, 5), (10, 3, 70), (10, 3, 285), (4, 2, 40)):
+        N = 1500
+        base = rng.random((N, 4))
+        X = (600 + 4000 * np.clip(base @ rng.random((4, Cin)) / 2, 0, 1)).astype(np.float32)
+        Y = onp.logit(np.clip(base @ rng.random((4, T)) / 3 + 0.01 * rng.standard_normal((N, T)), 0.001, 0.6))
+        model = s2_emit.PolyRidge(degree=deg, alpha=1.0).fit(X, Y)
+        H, W = 37, 41                                    # 1517 pixels: ragged last tile
+        cube = (600 + 4000 * rng.random((Cin, H, W))).astype(np.float32)
+        clean = torch.from_numpy(cube).cuda()
+        dirty = clean.clone()
+        dirty[0, 3, 4] = float("nan")
+        dirty[Cin - 1, 5, 6] = float("inf")
+        dirty[1, 7, 8] = float("-inf")
+        dirty[2, 9, 10] = -9999.0
+        dirty[3, 36, 40] = -9999.05                      # inside isclose's 1e-5 relative band of the nodata value
+        dirty[2, 11, 12] = -9998.0                       # outside it: a usable (if odd) sample
+        for nodata in (None, -9999.0):
+            got = model.predict_cube(dirty, nodata=nodata)
+            x2 = dirty.reshape(Cin, -1)
+            bad = ~torch.isfinite(x2).all(dim=0)
+            if nodata is not None:
+                bad |= torch.isclose(x2, torch.tensor(float(nodata), device="cuda")).any(dim=0)
+            assert int(bad.sum()) == (3 if nodata is None else 5)
+            g2 = got.reshape(T, -1)
+            assert torch.isnan(g2[:, bad]).all(), (Cin, deg, T, nodata)
+            ref = model.predict_cube(torch.where(bad.reshape(1, H, W), clean, dirty), nodata=None).reshape(T, -1)
+            assert torch.equal(g2[:, ~bad].view(torch.int32), ref[:, ~bad].view(torch.int32)), (Cin, deg, T, nodata)
+            assert torch.isfinite(g2[:, ~bad]).all()

@@ -123,6 +123,10 @@ SIGNATURES = {
     "hsr_gram_f64": (C.c_int, [_vp, _i64, _i32, _vp, _i64, _i32, _i64, _vp, _vp, _i64, _vp]),
     "hsr_polyfeat_predict": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _i32, _i32,
                                        _vp, _i64, _vp]),
+    "hsr_ridge_stats_work_bytes": (C.c_size_t, [_i32]),
+    "hsr_ridge_stats": (C.c_int, [_vp, _i64, _i64, _i64, _i32, _vp, _vp, _vp, _vp, _vp]),
+    "hsr_ridge_assemble": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _f64, _vp, _i32, _vp, _i64, _vp, _vp]),
+    "hsr_ridge_finish": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _i64, _vp, _vp, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp]),
     "hsr_polyfeat_predict_cube": (C.c_int, [_vp, _i64, _i64, _vp, _vp, _i64, _i32, _i32, _vp, _i64, _vp, _i32, _i32,
                                             _i32, _f32, _i32, _vp, _i64, _vp]),
     "hsr_block_mean": (C.c_int, [_vp, _i32, _i64, _i64, _i32, _i32, _i32, _i32, _f32, _vp, _i64, _i64, _vp]),

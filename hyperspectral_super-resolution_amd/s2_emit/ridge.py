@@ -104,14 +104,26 @@ class PolyRidge:
         return Xd, Yd
 
     @staticmethod
+    def _stats_dev(Xd):
+        """(stats, mean, scale) of this shard's inputs on the device: stats = (1 + 2 n_in,) float64 [n, mean..., M2...],
+        mean / scale = StandardScaler's for THIS shard alone (hsr_ridge_stats: two launches)."""
+        torch = nat.require_gpu()
+        lib = nat.load()
+        n, n_in = Xd.shape
+        dev = Xd.device
+        if n == 0:
+            z = torch.zeros(1 + 2 * n_in, dtype=torch.float64, device=dev)
+            return z, z[1:1 + n_in].clone(), torch.ones(n_in, dtype=torch.float64, device=dev)
+        buf = torch.empty(1 + 4 * n_in + lib.hsr_ridge_stats_work_bytes(n_in) // 8, dtype=torch.float64, device=dev)
+        stats, mean, scale, work = buf[:1 + 2 * n_in], buf[1 + 2 * n_in:1 + 3 * n_in], buf[1 + 3 * n_in:1 + 4 * n_in], buf[1 + 4 * n_in:]
+        nat.check(lib.hsr_ridge_stats(_ptr(Xd), Xd.stride(0), Xd.stride(1) if n_in > 1 else 1, n, n_in, _ptr(work),
+                                      _ptr(stats), _ptr(mean), _ptr(scale), _stream(torch, Xd)), "hsr_ridge_stats")
+        return stats, mean, scale
+
+    @staticmethod
     def local_stats(Xd):
         """(1 + 2 n_in,) float64 device tensor [n, mean..., M2...] of this shard's inputs."""
-        torch = nat.require_gpu()
-        X64 = Xd.double()
-        n = X64.shape[0]
-        mean = X64.mean(dim=0) if n else torch.zeros(X64.shape[1], dtype=torch.float64, device=Xd.device)
-        m2 = ((X64 - mean) ** 2).sum(dim=0)
-        return torch.cat([torch.tensor([float(n)], dtype=torch.float64, device=Xd.device), mean, m2])
+        return PolyRidge._stats_dev(Xd)[0]
 
     @staticmethod
     def combine_stats(stats):
@@ -166,32 +178,31 @@ class PolyRidge:
         lib = nat.load()
         nf = lib.hsr_polyfeat_count(n_in, self.degree)
         na = (nf + 1 + 15) // 16 * 16
-        cnt = G[0, 0]
-        s = G[0, 1:nf + 1]                               # column sums of the features
-        ybar = G[0, na:na + T] / cnt
-        Gc = G[1:nf + 1, 1:nf + 1] - torch.outer(s, s) / cnt
-        rhs = G[1:nf + 1, na:na + T] - torch.outer(s, ybar)
-        # (Gc + alpha I) W = rhs by the library's Cholesky (csrc/hsr_chol.hip); padded to a multiple of 32 with an
-        # identity block and zero right-hand-side rows, which leaves the solution untouched
+        # (Phi_c^T Phi_c + alpha I) W = Phi_c^T (Y - ybar) by the library's Cholesky (csrc/hsr_chol.hip), the system padded to
+        # a multiple of 32 with an identity block and zero right-hand-side rows, which leaves the solution untouched;
+        # assembly and model read-out are one launch each (hsr_ridge_assemble / hsr_ridge_finish)
         npad = (nf + 31) // 32 * 32
-        Gp = torch.eye(npad, dtype=torch.float64, device=G.device)
-        Gp[:nf, :nf] = Gc
-        Gp[:nf, :nf].diagonal().add_(self.alpha)
-        Bp = torch.zeros((npad, T), dtype=torch.float64, device=G.device)
-        Bp[:nf] = rhs
-        self._chol_info = torch.zeros(1, dtype=torch.int32, device=G.device)   # 0, or the first non-positive pivot
-        cwork = torch.empty(lib.hsr_chol_work_bytes(npad) // 8, dtype=torch.float64, device=G.device)
+        dev = G.device
+        Gp = torch.empty((npad, npad), dtype=torch.float64, device=dev)
+        Bp = torch.empty((npad, T), dtype=torch.float64, device=dev)
+        self._chol_info = torch.empty(1, dtype=torch.int32, device=dev)        # 0, or the first non-positive pivot
+        st = _stream(torch, G)
+        nat.check(lib.hsr_ridge_assemble(_ptr(G), G.stride(0), na, nf, T, float(self.alpha), _ptr(Gp), npad, _ptr(Bp),
+                                         Bp.stride(0), _ptr(self._chol_info), st), "hsr_ridge_assemble")
+        cwork = torch.empty(lib.hsr_chol_work_bytes(npad) // 8, dtype=torch.float64, device=dev)
         nat.check(lib.hsr_chol_solve_f64(_ptr(Gp), Gp.stride(0), npad, _ptr(Bp), Bp.stride(0), T, _ptr(cwork),
-                                         _ptr(self._chol_info), _stream(torch, self._chol_info)), "hsr_chol_solve_f64")
+                                         _ptr(self._chol_info), st), "hsr_chol_solve_f64")
         Wm = Bp[:nf]                                     # (nf, T)
-        b = ybar - (s / cnt) @ Wm
+        kpad = (nf + 1) // 2 * 2
+        b = torch.empty(T, dtype=torch.float64, device=dev)
+        f32 = torch.empty(kpad * T + T + 2 * n_in, dtype=torch.float32, device=dev)
+        Wf, b32 = f32[:kpad * T].view(kpad, T), f32[kpad * T:kpad * T + T]
+        mean32, inv32 = f32[kpad * T + T:kpad * T + T + n_in], f32[kpad * T + T + n_in:]
+        nat.check(lib.hsr_ridge_finish(_ptr(G), na, nf, T, _ptr(Wm), Bp.stride(0), _ptr(mean), _ptr(scale), n_in, kpad,
+                                       _ptr(b), _ptr(b32), _ptr(Wf), _ptr(mean32), _ptr(inv32), st), "hsr_ridge_finish")
         self.n_in, self.n_feat, self.n_targets = n_in, nf, T
         self._fit64, self._host = (mean, scale, Wm, b), None
-        kpad = (nf + 1) // 2 * 2
-        Wf = torch.zeros((kpad, T), dtype=torch.float32, device=G.device)
-        Wf[:nf] = Wm.float()
-        self._dev = dict(W=Wf, b=b.float().contiguous(), mean=mean.float().contiguous(),
-                         inv=(1.0 / scale).float().contiguous())
+        self._dev = dict(W=Wf, b=b32, mean=mean32, inv=inv32)
         return self
 
     def fit(self, X, Y, group=None, distributed: Optional[bool] = None):
@@ -203,15 +214,13 @@ class PolyRidge:
         if distributed is None:
             import torch.distributed as dist
             distributed = dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1
-        stats = self.local_stats(Xd)
+        stats, mean, scale = self._stats_dev(Xd)
         if distributed:
             import torch.distributed as dist
             world = dist.get_world_size(group)
             gathered = [torch.empty_like(stats) for _ in range(world)]
             dist.all_gather(gathered, stats, group=group)
             mean, scale = self.combine_stats(torch.stack(gathered))
-        else:
-            mean, scale = self.combine_stats(stats[None])
         G = self.local_gram(Xd, Yd, mean, scale)
         if distributed:
             dist.all_reduce(G, op=dist.ReduceOp.SUM, group=group)

@@ -388,6 +388,25 @@ size_t hsr_chol_work_bytes(int32_t n);   /* workspace: the inverses of the 32 x 
 int hsr_chol_solve_f64(double* a_dev, int64_t lda, int32_t n, double* b_dev, int64_t ldb, int32_t nrhs,
                        double* work_dev, int32_t* info_dev, hsr_stream_t stream);
 
+/* The small steps of the fit around Gram and Cholesky (sklearn Pipeline(StandardScaler, PolynomialFeatures, Ridge),
+ * Spectral_matching.ipynb raw lines 475-490), each one launch instead of a dozen tensor operations:
+ * hsr_ridge_stats: stats_dev[1 + 2 n_in] = [n, mean.., M2..] of the n rows of x (float64, shifted-data sums, fixed order),
+ *   mean_dev / scale_dev [n_in] = StandardScaler's mean_ and scale_ (zero variance -> 1); work: hsr_ridge_stats_work_bytes.
+ * hsr_ridge_assemble: from G (na, >= na + T) = [1 | Phi]^T [1 | Phi | Y] (hsr_gram_f64) the centred ridge system
+ *   A (npad, npad) = Phi_c^T Phi_c + alpha I (identity block past nf), B (npad, ldb) = Phi_c^T (Y - ybar) (zero rows past nf);
+ *   *info_dev = 0 for hsr_chol_solve_f64.
+ * hsr_ridge_finish: W (nf, ldw) float64 solution -> intercept (float64 and float32), W as float32 (kpad, T) with zero rows
+ *   past nf, mean and 1 / scale as float32 - the operands of hsr_polyfeat_predict. */
+size_t hsr_ridge_stats_work_bytes(int32_t n_in);
+int hsr_ridge_stats(const float* x_dev, int64_t x_rs, int64_t x_cs, int64_t n, int32_t n_in, double* work_dev,
+                    double* stats_dev, double* mean_dev, double* scale_dev, hsr_stream_t stream);
+int hsr_ridge_assemble(const double* g_dev, int64_t ldg, int32_t na, int32_t nf, int32_t T, double alpha,
+                       double* a_dev, int32_t npad, double* b_dev, int64_t ldb, int32_t* info_dev, hsr_stream_t stream);
+int hsr_ridge_finish(const double* g_dev, int32_t na, int32_t nf, int32_t T, const double* w_dev, int64_t ldw,
+                     const double* mean_dev, const double* scale_dev, int32_t n_in, int32_t kpad,
+                     double* b64_dev, float* b32_dev, float* w32_dev, float* mean32_dev, float* inv32_dev,
+                     hsr_stream_t stream);
+
 /* out[t * out_stride + p] = act(sum_f W[f][t] * phi_f((x_p - mean) * inv_scale) + bias[t]) with the features
  * expanded on chip (v_mfma_f32_32x32x2_f32); W (count rounded up to even rows, ldw) float32 with zero rows past
  * count; activation 1 = sigmoid(clip(z, -50, 50)) (notebook raw lines 178-181), 0 = identity. */

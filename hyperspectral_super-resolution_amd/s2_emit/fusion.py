@@ -150,6 +150,7 @@ class SpectralFusion:
         # against 8.5 us + one launch gap for the separate hsr_moments_reduce_solve - 3 us per step slower.
         self.fused_fit = bool(fused_fit)
         self._pipe = None                            # state of submit()/flush(), created on first use
+        self._pipe_images: Dict[int, list] = {}      # output images placed by place_inputs() for the pipeline's two slots
         self.ws = eng.MomentWorkspace(self.device, self.table.nb, deg)
         self.table.device_weights(self.device)
         self._buf: Dict[int, Tuple[object, object]] = {}
@@ -199,18 +200,22 @@ class SpectralFusion:
             return cube, real, {}
         nb = self.table.nb
 
+        def images():          # the plan's output image for step() and the two of the submit() pipeline, in one stretch
+            return [eng.alloc_image(torch, nb, npix, self.layout, self.device) for _ in range(3)]
+
         def make():
-            return (cube.clone(), real.clone(), eng.alloc_image(torch, nb, npix, self.layout, self.device))
+            return (cube.clone(), real.clone(), images())
 
         def k1(cand):
-            c, r, o = cand
+            c, r, outs = cand
             rr, rl = self._real_image(r, npix)
-            eng.srf_integrate_moments(c, self.table, rr, self.deg, self.ws, mask, self.min_valid, self.min_valid, out=o,
+            eng.srf_integrate_moments(c, self.table, rr, self.deg, self.ws, mask, self.min_valid, self.min_valid, out=outs[0],
                                       reduce=False, layout=self.layout, real_layout=rl, scale=self.tile_scale,
                                       nodata=self.tile_nodata, opts=self.opts)
-        first = (cube, real, eng.alloc_image(torch, nb, npix, self.layout, self.device))
-        (cube, real, out), times = self._trials(first, make, k1)
-        self._buf[npix] = (out, eng.alloc_image(torch, nb, npix, self.layout, self.device))
+        first = (cube, real, images())
+        (cube, real, outs), times = self._trials(first, make, k1)
+        self._buf[npix] = (outs[0], eng.alloc_image(torch, nb, npix, self.layout, self.device))
+        self._pipe_images[npix] = outs[1:]
         self.placement_log[npix] = times
         return cube, real, {"joint_ms": times}
 
@@ -486,10 +491,14 @@ class SpectralFusion:
         if self._pipe is None or self._pipe["npix"] != npix:
             nb = self.table.nb
             slots = []
-            for _ in range(2):
-                pseudo = eng.alloc_image(torch, nb, npix, self.layout, self.device)
-                if probe is not None and self.placement_trials > 1 and npix >= (1 << 16):
-                    pseudo = self._place(npix, pseudo, probe)
+            placed = self._pipe_images.pop(npix, [])
+            for k in range(2):
+                if k < len(placed):                  # placed together with the resident inputs (place_inputs)
+                    pseudo = placed[k]
+                else:
+                    pseudo = eng.alloc_image(torch, nb, npix, self.layout, self.device)
+                    if probe is not None and self.placement_trials > 1 and npix >= (1 << 16):
+                        pseudo = self._place(npix, pseudo, probe)
                 slots.append(dict(pseudo=pseudo,
                                   matched=eng.alloc_image(torch, nb, npix, self.layout, self.device),
                                   ws=eng.MomentWorkspace(self.device, nb, self.deg), mask=None,

@@ -186,7 +186,7 @@ class SpectralFusion:
     def place_inputs(self, cube, real, mask=None):
         """Placement trials for a tile that stays resident and is processed many times (a benchmark loop, a resident
         mosaic).  step() by itself only places the images the plan owns, but it is the CUBE's stretch of device memory
-        that carries most of the effect (tools/dbg/placement13.py: the slow set's cube with the fast set's target and
+        that carries most of the effect (tools/dbg/placement_map.py: the slow set's cube with the fast set's target and
         output runs slow, the fast set's cube with the slow set's target and output runs fast).  This searches JOINTLY:
         candidate set i = (cube clone, real clone, output image) allocated back to back - one stretch - with
         placement_pitch_gb between sets; set 0 is the caller's tensors with a fresh output image.  One untimed and two

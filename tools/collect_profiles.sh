@@ -30,6 +30,6 @@ echo "== stamps"; timeout -k 5 120 tools/k1_stamps 1024 1024 64 > $O/k1_stamps.l
 echo "== probe modes"; timeout -k 10 120 python tools/dbg/probe_modes.py > $O/probe_modes.log 2>&1
 echo "== reduce kernels"; timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_rs -o rs -- python3 tools/dbg/rs_time.py > /dev/null 2> $O/trace_rs.log
 echo "== ramp"; timeout -k 10 200 python tools/dbg/ramp.py > $O/ramp.log 2>&1
-echo "== address map"; timeout -k 10 200 python tools/dbg/placement13.py 28 4 > $O/placement_map.log 2>&1
+echo "== address map"; timeout -k 10 200 python tools/dbg/placement_map.py 28 4 > $O/placement_map.log 2>&1
 echo "== placement"; timeout -k 10 200 python tools/placement_probe.py > $O/placement_probe.log 2>&1; timeout -k 10 200 python tools/state_probe.py > $O/state_probe.log 2>&1
 echo done

@@ -578,6 +578,16 @@ def moments_reduce_solve(ws: MomentWorkspace, min_count: int):
     return ws.moments, ws.coeffs
 
 
+def reduce_solve_slots(partials, slots: int, ws: MomentWorkspace, min_count: int):
+    """hsr_moments_reduce_solve over any [slot][band][moment] float64 array (e.g. the per-tile moments of a mosaic, one
+    "slot" per tile) -> (ws.moments, ws.coeffs)."""
+    lib = nat.load()
+    with _launch(partials) as st:
+        nat.check(lib.hsr_moments_reduce_solve(_ptr(partials), int(slots), ws.nb, ws.deg, int(min_count),
+                                               _ptr(ws.moments), _ptr(ws.coeffs), st), "hsr_moments_reduce_solve")
+    return ws.moments, ws.coeffs
+
+
 def poly_moments(x, y, deg: int, ws: MomentWorkspace, mask=None, min_x=_NEG_INF, min_y=_NEG_INF,
                  lohi_x=None, lohi_y=None, layout: str = PLANAR, nb: Optional[int] = None):
     """K2 on materialised float32 images -> moments (nb, 3deg+2) float64 on the device."""

@@ -313,12 +313,18 @@ class SpectralFusion:
         return BatchOutput(self.names, tb)
 
     # ---- one fit over several tiles on one GPU --------------------------------------------------------
-    def fuse_mosaic(self, tiles, masks=None, k1_events=None):
+    def fuse_mosaic(self, tiles, masks=None, k1_events=None, resident: bool = False):
         """Global fit over a mosaic held by ONE GPU (BASELINE configs[4] on a single device, and the single-process
         twin of the multi-GPU step): K1+K2 per tile, the per-tile moments added in tile order, one solve (plus the
         exchange when a process group is active, so that ranks holding several tiles each still fit one polynomial),
         K3 per tile.  ``tiles``: sequence of (cube, real) GPU tensors as in step(); ``masks`` optional sequence.
-        Returns (coeffs (nb, deg+1), moments, [FusionOutput per tile]) - the outputs own their buffers."""
+        Returns (coeffs (nb, deg+1), moments, [FusionOutput per tile]) - the outputs own their buffers.
+
+        ``resident=True``: the same tiles (same tensors) will be fused again and again - the mosaic then runs through
+        the batch machinery of step_batch() in five launches instead of four per tile: batched K1+K2, batched slot
+        reduction, the sum over the tiles + solve, a broadcast of the coefficients, batched K3.  Per-tile slots and
+        trees are those of the per-tile launches, so the per-tile moments carry the same bits; the outputs are views of
+        the batch's buffers, reused by the next call."""
         torch = nat.require_gpu()
         tiles = list(tiles)
         if not tiles:
@@ -326,6 +332,9 @@ class SpectralFusion:
         masks = list(masks) if masks is not None else [None] * len(tiles)
         if len(masks) != len(tiles):
             raise ValueError("masks must match tiles")
+        band_last = all(self._real_image(r, c.numel() // c.shape[-1])[1] == nat.PIXMAJOR for c, r in tiles)
+        if resident and band_last and self.layout == nat.PIXMAJOR and len(tiles) <= 64:
+            return self._fuse_mosaic_batched(tiles, masks, k1_events)
         total = None
         pseudos = []
         for ti, ((cube, real), mask) in enumerate(zip(tiles, masks)):
@@ -347,6 +356,30 @@ class SpectralFusion:
             matched = eng.poly_apply(pseudo, coeffs, mask if self.apply_mask else None, None, self.clip, self.layout,
                                      nb=self.table.nb)
             outs.append(FusionOutput(self.names, pseudo, total, coeffs, matched, self.layout))
+        return coeffs, total, outs
+
+    def _fuse_mosaic_batched(self, tiles, masks, k1_events):
+        torch = nat.require_gpu()
+        cubes, reals = [c for c, _ in tiles], [r for _, r in tiles]
+        key = ("mosaic",) + tuple((c.data_ptr(), tuple(c.shape), r.data_ptr(), tuple(r.shape), 0 if m is None else m.data_ptr())
+                                  for c, r, m in zip(cubes, reals, masks))
+        tb = self._batches.get(key)
+        if tb is None:
+            if len(self._batches) >= 4:
+                self._batches.pop(next(iter(self._batches)))
+            tb = eng.TileBatch(cubes, reals, masks, self.table, self.deg, self.opts)
+            self._batches[key] = tb
+        eng.batch_srf_integrate_moments(tb, self.min_valid, self.min_valid, self.tile_scale, self.tile_nodata, events=k1_events)
+        eng.batch_reduce_solve(tb, self.min_count)          # per-tile moments (the per-tile coefficients are not used)
+        # the tiles' moments are T "slots" of the same [slot][band][moment] layout: one more fixed-order reduction
+        total, coeffs = eng.reduce_solve_slots(tb.moments, tb.T, self.ws, self.min_count)
+        if self._exchanges():
+            total, coeffs = exchange_moments(total, self._solve, self.group, self.coeff_sync)
+        total, coeffs = total.clone(), coeffs.clone()     # the plan's workspace is rewritten by the next call
+        tb.coeffs.copy_(coeffs.expand(tb.T, -1, -1))
+        eng.batch_poly_apply(tb, use_mask=self.apply_mask, clip=self.clip)
+        outs = [FusionOutput(self.names, tb.tile_rows(i, "pseudo"), total, coeffs, tb.tile_rows(i, "matched"), self.layout)
+                for i in range(tb.T)]
         return coeffs, total, outs
 
     # ---- host -> device tile feed -------------------------------------------------------------------

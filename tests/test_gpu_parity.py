@@ -1309,6 +1309,15 @@ def test_fuse_mosaic_equals_one_big_tile(torch_gpu):
                                    rtol=1e-6, atol=1e-9)
     got = np.concatenate([o.matched.cpu().numpy() for o in outs], 0)
     np.testing.assert_allclose(got[:, :len(plan.names)], big.matched.cpu().numpy()[:, :len(plan.names)], rtol=0, atol=1e-6)
+    # resident mosaic: the same through the batch machinery (five launches), twice (buffers reused)
+    for _ in range(2):
+        c2, m2, outs2 = plan.fuse_mosaic(tiles, resident=True)
+        np.testing.assert_allclose(m2.cpu().numpy(), moments.cpu().numpy(), rtol=1e-13)
+        for b in range(coeffs.shape[0]):
+            np.testing.assert_allclose(np.polyval(c2[b].cpu().numpy(), xs), np.polyval(coeffs[b].cpu().numpy(), xs), rtol=1e-6, atol=1e-9)
+        for o, o2 in zip(outs, outs2):
+            assert torch.equal(o.pseudo.view(torch.int32), o2.pseudo.view(torch.int32))
+            np.testing.assert_allclose(o2.matched.cpu().numpy(), o.matched.cpu().numpy(), rtol=0, atol=1e-6)
     # and differs from per-tile fits (the tiles do not share one polynomial)
     solo = plan.step(*tiles[2], reuse_buffers=False)
     assert not torch.allclose(solo.coeffs, coeffs)
@@ -1528,7 +1537,15 @@ def test_mosaic_8_tiles_1024_on_one_gpu(torch_gpu):
     # the mosaic fit equals the sum of the per-tile moments (tile order), and per-tile local fits differ from it
     local = plan.step(probs[0].cube, probs[0].real, reuse_buffers=False)
     assert not torch.equal(local.coeffs, coeffs)
-    del outs, probs
+    # the resident form (bench.py --tiles-per-gpu 8): batched launches, same fit
+    c2, m2, outs2 = plan.fuse_mosaic([(p.cube, p.real) for p in probs], resident=True)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(m2.cpu().numpy(), moments.cpu().numpy(), rtol=1e-13)
+    xs = np.linspace(0.0, 0.6, 40)          # the sums differ in the last bit (another tree over the tiles); the fit amplifies that
+    for bb in range(nb):
+        np.testing.assert_allclose(np.polyval(c2[bb].cpu().numpy(), xs), np.polyval(co[bb], xs), rtol=1e-7, atol=1e-10)
+    assert torch.equal(outs2[7].pseudo.view(torch.int32), outs[7].pseudo.view(torch.int32))
+    del outs, outs2, probs
     torch.cuda.empty_cache()
 
 

@@ -80,7 +80,7 @@ def parse_args():
     ap.add_argument("--fused-fit", action="store_true",
                     help="slot reduction + solve inside K1's launch (hsr_srf_integrate_fit); measured 3 us/step slower, off by default")
     ap.add_argument("--settle-ms", type=float, default=250.0,
-                    help="milliseconds of untimed steps before the warm-up, to reach the GPU's settled power state (0: none)")
+                    help="untimed load before the warm-up, to reach the GPU's settled power state: settle_ms / 0.25 steps per tile (0: none)")
     ap.add_argument("--no-input-placement", action="store_true",
                     help="keep the synthetic cube / target where the allocator first put them (no placement trials for inputs)")
     ap.add_argument("--event-every", type=int, default=4,
@@ -245,7 +245,8 @@ def main():
                           coeff_sync=args.coeff_sync if (world > 1 or args.force_exchange) else "local",
                           force_exchange=args.force_exchange,
                           reserved_cus=args.reserve_cus if pipelined else 0,   # CUs kept free for the side stream
-                          u16_fast=args.u16_fast, fused_fit=args.fused_fit)
+                          u16_fast=args.u16_fast, fused_fit=args.fused_fit,
+                          placement_trials=0 if args.same_device else 12)
     real = prob.real            # (H, W, row) band-last, like the cube and the reference's (H, W, C) images
     cube = prob.cube
     if args.cube == "u16":      # quantise once, outside the timed region (the writer's arithmetic, on the device)
@@ -254,7 +255,7 @@ def main():
             pr.cube = None
         cube = prob.cube_u16
     input_log = None
-    if ntl == 1 and not args.no_input_placement:
+    if ntl == 1 and not args.no_input_placement and not args.same_device:   # (ranks sharing one GPU would each claim ~200 GB)
         # where the resident inputs lie in HBM is the benchmark's to choose: the same slow stretches of device memory that
         # the plan avoids for its own images (profiles/r02_two_speeds.md) slow K1's read streams too, so the cube and the
         # target are cloned into a few regions before the warm-up and the fastest copies kept (same bytes, same results)
@@ -292,14 +293,13 @@ def main():
     # then the step time settles - a power-management transient, longer than a 20-step timed region.  A pipeline that
     # processes tiles continuously lives in the settled state, so the bench loads the GPU with untimed steps for
     # --settle-ms before the W warm-up steps; the timed region follows the warm-up with no host work in between.
-    settle_steps = 0
-    if args.settle_ms > 0:
-        t_s = time.perf_counter()
-        while (time.perf_counter() - t_s) * 1e3 < args.settle_ms:
-            for _ in range(25):
-                run_step()
-            settle_steps += 25
-            torch.cuda.synchronize()
+    # The number of settle steps is fixed by the arguments, NOT by a clock: with more than one rank every step holds a
+    # collective, and ranks that looped "until 250 ms have passed" would issue different numbers of them.
+    settle_steps = int(args.settle_ms / (0.25 * ntl) + 0.5) if args.settle_ms > 0 else 0
+    for i in range(settle_steps):
+        run_step()
+        if (i + 1) % 50 == 0:
+            torch.cuda.synchronize()     # keep the launch queue short
     for _ in range(max(args.warmup, 1)):    # always one untimed pass: code-object load and LDS attributes are setup, not a step
         run_step()
     if pipelined:

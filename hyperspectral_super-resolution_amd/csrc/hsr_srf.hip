@@ -753,6 +753,7 @@ __device__ __forceinline__ void moments_accumulate(double (&acc)[DEG > 0 ? momen
   }
 }
 
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
 // nodata sweep of one group held in LDS: a 16-bit lane of (v ^ nodata:nodata) is zero exactly where the sample is nodata
 __device__ __forceinline__ void u16_nodata_sweep(const uint4* t4, int nchunk, int nsamples, int B, uint32_t nd2,
                                                  uint32_t nodata, uint32_t* fl, int t) {
@@ -764,13 +765,16 @@ __device__ __forceinline__ void u16_nodata_sweep(const uint4* t4, int nchunk, in
       const int c = c0 + u * T;
       v[u] = t4[c < nchunk ? c : nchunk - 1];
     }
-    uint32_t hit = 0u;
+    // a 16-bit half of (v ^ nodata:nodata) is zero exactly where the sample is nodata: the packed minimum over all
+    // halves is zero iff the batch holds one (xor + v_pk_min_u16 per dword; the carry-trick test it replaces took four)
+    u16x2 mn = {(unsigned short)0xffffu, (unsigned short)0xffffu};
 #pragma unroll
     for (int u = 0; u < kScanBatch; ++u) {
       const uint32_t w[4] = {v[u].x ^ nd2, v[u].y ^ nd2, v[u].z ^ nd2, v[u].w ^ nd2};
 #pragma unroll
-      for (int q = 0; q < 4; ++q) hit |= (w[q] - 0x00010001u) & ~w[q] & 0x80008000u;
+      for (int q = 0; q < 4; ++q) mn = __builtin_elementwise_min(mn, __builtin_bit_cast(u16x2, w[q]));
     }
+    const bool hit = mn.x == 0 || mn.y == 0;
     if (hit) {  // rare
 #pragma unroll
       for (int u = 0; u < kScanBatch; ++u) {

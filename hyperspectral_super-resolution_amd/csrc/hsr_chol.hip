@@ -7,8 +7,8 @@
 // Here:
 //   chol_factor_kernel  ONE workgroup of 1024 threads runs the whole right-looking blocked factorisation
 //                       (block 32): diagonal block factored in LDS with one barrier per column, the panel below
-//                       solved one row per thread (row in registers, L broadcast from LDS), the trailing matrix
-//                       updated from the LDS-resident panel with 4 x 4 register tiles.
+//                       staged in LDS and solved four lanes per row, the trailing matrix updated from the
+//                       LDS-resident panel in 16 x 16 tiles on v_mfma_f64_16x16x4_f64.
 //   chol_diag_inverse_kernel  inverses of the diagonal blocks, so that
 //   chol_solve_kernel   (forward and backward substitution, one wave per right-hand side) needs a 32 x 32
 //                       matrix-vector product per block instead of a serial 32-step chain; the updates below /
@@ -24,12 +24,43 @@ namespace hsr {
 constexpr int kCb = 32;        // block size
 constexpr int kCs = kCb + 1;   // LDS row stride (doubles)
 
+typedef double chol_f64x4 __attribute__((ext_vector_type(4)));
+
+// 1 / d to the last bit or two: v_rcp_f64 and two Newton steps (a full IEEE division is ~3x the instructions, and the
+// factorisation's column steps are latency chains)
+__device__ __forceinline__ double rcp_nr(double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = fma(fma(-d, r, 1.0), r, r);
+  r = fma(fma(-d, r, 1.0), r, r);
+  return r;
+}
+
+// sum over the 4 lanes of a quad (two DPP quad permutes per half), in every lane
+__device__ __forceinline__ double quad_sum(double v) {
+  v += __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), 0xB1, 0xf, 0xf, false),
+                        __builtin_amdgcn_update_dpp(0, __double2loint(v), 0xB1, 0xf, 0xf, false));
+  v += __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x4E, 0xf, 0xf, false),
+                        __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x4E, 0xf, 0xf, false));
+  return v;
+}
+
+// Where the first version (one panel row per thread, 4 x 4 register tiles for the trailing update) spent its 236 us
+// (cycle stamps, n = 288): diagonal block 26 %, panel 30 %, trailing update 42 %.  The panel row is a 32-step chain of
+// up to 31 dependent fma + a division; the update ran at 22 % of the CU's float64 rate because its 4 x 4 tiles read
+// 4 bytes of LDS per fma.  Now: the panel is staged in LDS and every row is solved by FOUR lanes (each owns a quarter
+// of the row's x, partial dot products joined by two DPP quad adds, reciprocals of the diagonal from LDS); the
+// trailing update is 16 x 16 tiles on v_mfma_f64_16x16x4_f64 with both operands read from the LDS-resident panel
+// (1 byte of LDS per fma; same peak as the vector unit on CDNA4, but reachable), a wave's tiles loaded from global
+// memory up front so that their latency hides under the matrix instructions; the diagonal block multiplies by a
+// Newton-refined reciprocal instead of dividing.
 __global__ __launch_bounds__(1024) void chol_factor_kernel(double* __restrict__ A, int64_t lda, int n, int* info) {
   extern __shared__ __attribute__((aligned(16))) double chol_lds[];
   double (*D)[kCs] = reinterpret_cast<double (*)[kCs]>(chol_lds);                      // diagonal block
   double (*P)[kCs] = reinterpret_cast<double (*)[kCs]>(chol_lds + kCb * kCs);           // panel below, (n - 32) rows
   __shared__ int bad_pivot;
+  __shared__ double invd[kCb];
   const int tid = threadIdx.x, ti = tid >> 5, tj = tid & 31;
+  const int lane = tid & 63, wave = tid >> 6;
   if (tid == 0) {
     *info = 0;
     bad_pivot = 0x7fffffff;
@@ -37,12 +68,13 @@ __global__ __launch_bounds__(1024) void chol_factor_kernel(double* __restrict__ 
   for (int kb = 0; kb < n; kb += kCb) {
     const int m = n - kb - kCb;   // rows below the diagonal block
     D[ti][tj] = tj <= ti ? A[(int64_t)(kb + ti) * lda + kb + tj] : 0.0;
+    for (int e = tid; e < m * kCb; e += 1024) P[e >> 5][e & 31] = A[(int64_t)(kb + kCb + (e >> 5)) * lda + kb + (e & 31)];
     __syncthreads();
     // 32 x 32 block, one barrier per column: the Schur update of step j is applied with the UNSCALED column j
     // (D[i][l] -= D[i][j] D[l][j] / D[j][j]); D[j][j] is then the squared pivot and the columns are scaled once at
     // the end.  (Scaling each column first needs three barriers per step: 96 instead of 33 per block.)
     for (int j = 0; j < kCb - 1; ++j) {
-      if (ti > j && tj > j && tj <= ti) D[ti][tj] -= D[ti][j] * D[tj][j] / D[j][j];
+      if (ti > j && tj > j && tj <= ti) D[ti][tj] -= D[ti][j] * D[tj][j] * rcp_nr(D[j][j]);
       __syncthreads();
     }
     double piv = 1.0;
@@ -57,61 +89,71 @@ __global__ __launch_bounds__(1024) void chol_factor_kernel(double* __restrict__ 
       const double l = ti == tj ? piv : D[ti][tj] / piv;
       D[ti][tj] = l;
       A[(int64_t)(kb + ti) * lda + kb + tj] = l;
+      if (ti == tj) invd[ti] = 1.0 / piv;
     }
     __syncthreads();
-    // panel below: row r of the panel solves x L^T = a, one thread per row, the row in registers, L broadcast from LDS
-    if (tid < m) {
-      const int r = tid;
-      double* arow = A + (int64_t)(kb + kCb + r) * lda + kb;
-      double x[kCb];
+    // panel below: row r solves x L^T = a.  Four lanes per row; lane q owns x[q], x[q+4], ..  D's upper triangle is zero
+    // and x starts at zero, so every partial dot product may run over all of a lane's columns below c.
+    for (int r = tid >> 2; r < m; r += 256) {
+      const int q = tid & 3;
+      double x[kCb / 4];
 #pragma unroll
-      for (int c = 0; c < kCb; ++c) x[c] = arow[c];
-#pragma unroll
-      for (int c = 0; c < kCb; ++c) {
-        double s = x[c];
-#pragma unroll
-        for (int p = 0; p < kCb; ++p)
-          if (p < c) s -= x[p] * D[c][p];
-        x[c] = s / D[c][c];
-      }
+      for (int k = 0; k < kCb / 4; ++k) x[k] = 0.0;
 #pragma unroll
       for (int c = 0; c < kCb; ++c) {
-        arow[c] = x[c];
-        P[r][c] = x[c];
-      }
-    }
-    __syncthreads();
-    // trailing update, lower triangle in 4 x 4 tiles: A[i][j] -= sum_p P[i][p] P[j][p]
-    {
-      const int m4 = m >> 2;
-      const int ntile = m4 * (m4 + 1) / 2;
-      for (int t = tid; t < ntile; t += 1024) {
-        int bi = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
-        while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
-        while (bi * (bi + 1) / 2 > t) --bi;
-        const int bj = t - bi * (bi + 1) / 2;
-        double acc[4][4];
+        double part = 0.0;
 #pragma unroll
-        for (int x = 0; x < 4; ++x)
-#pragma unroll
-          for (int y = 0; y < 4; ++y) acc[x][y] = 0.0;
-        for (int p = 0; p < kCb; ++p) {
-          double a[4], b[4];
-#pragma unroll
-          for (int x = 0; x < 4; ++x) {
-            a[x] = P[4 * bi + x][p];
-            b[x] = P[4 * bj + x][p];
-          }
-#pragma unroll
-          for (int x = 0; x < 4; ++x)
-#pragma unroll
-            for (int y = 0; y < 4; ++y) acc[x][y] += a[x] * b[y];
+        for (int k = 0; k < kCb / 4; ++k)
+          if (4 * k < c) part = fma(x[k], D[c][q + 4 * k], part);
+        part = quad_sum(part);
+        const double xc = (P[r][c] - part) * invd[c];
+        if (q == (c & 3)) {
+          x[c >> 2] = xc;
+          P[r][c] = xc;
         }
-        double* dst = A + (int64_t)(kb + kCb + 4 * bi) * lda + kb + kCb + 4 * bj;
+      }
+    }
+    __syncthreads();
+    for (int e = tid; e < m * kCb; e += 1024) A[(int64_t)(kb + kCb + (e >> 5)) * lda + kb + (e & 31)] = P[e >> 5][e & 31];
+    // trailing update, lower triangle in 16 x 16 tiles on the float64 matrix cores: C[I][J] -= P_I P_J^T.
+    // Lane (col = lane & 15, kk = lane >> 4): A operand P[16 I + col][4 s + kk], B operand P[16 J + col][4 s + kk],
+    // accumulator register g = element (row kk + 4 g, column col) of the tile (layout as in csrc/hsr_ridge.hip).
+    {
+      const int mt = m >> 4;                       // m is a multiple of 32
+      const int ntile = mt * (mt + 1) / 2;
+      const int col = lane & 15, kk = lane >> 4;
+      constexpr int kMaxTiles = 30;                // n <= 512: 30 tile rows -> 465 tiles over 16 waves
+      for (int t0 = wave; t0 < ntile; t0 += 16 * 5) {
+        double creg[5][4];
+        int bis[5], bjs[5];
 #pragma unroll
-        for (int x = 0; x < 4; ++x)
+        for (int u = 0; u < 5; ++u) {
+          const int t = t0 + 16 * u;
+          int bi = (int)((sqrt(8.0 * (double)(t < ntile ? t : 0) + 1.0) - 1.0) * 0.5);
+          while ((bi + 1) * (bi + 2) / 2 <= t && bi < kMaxTiles) ++bi;
+          while (bi * (bi + 1) / 2 > t && bi > 0) --bi;
+          bis[u] = bi;
+          bjs[u] = (t < ntile ? t : 0) - bi * (bi + 1) / 2;
+          if (t < ntile) {
+            const double* src = A + (int64_t)(kb + kCb + 16 * bi + kk) * lda + kb + kCb + 16 * bjs[u] + col;
 #pragma unroll
-          for (int y = 0; y < 4; ++y) dst[(int64_t)x * lda + y] -= acc[x][y];
+            for (int g = 0; g < 4; ++g) creg[u][g] = src[(int64_t)(4 * g) * lda];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < 5; ++u) {
+          const int t = t0 + 16 * u;
+          if (t < ntile) {
+            chol_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+            const double* pa = &P[16 * bis[u] + col][kk];
+            const double* pb = &P[16 * bjs[u] + col][kk];
+#pragma unroll
+            for (int st = 0; st < kCb / 4; ++st) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[4 * st], pb[4 * st], acc, 0, 0, 0);
+            double* dst = A + (int64_t)(kb + kCb + 16 * bis[u] + kk) * lda + kb + kCb + 16 * bjs[u] + col;
+#pragma unroll
+            for (int g = 0; g < 4; ++g) dst[(int64_t)(4 * g) * lda] = creg[u][g] - acc[g];
+          }
+        }
       }
     }
     __syncthreads();

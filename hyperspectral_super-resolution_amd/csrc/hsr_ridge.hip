@@ -853,33 +853,42 @@ extern "C" int hsr_gram_f64(const double* a_dev, int64_t lda, int32_t na, const 
 constexpr int kStatsBlocks = 64;
 
 // per-block sums of d = x - K and d^2 (K = the column's first sample: the "shifted data" form, so that
-// M2 = sum d^2 - (sum d)^2 / n loses nothing to a large mean); fixed order inside the block
+// M2 = sum d^2 - (sum d)^2 / n loses nothing to a large mean); fixed order inside the block: every thread walks its rows
+// once with all columns in registers, lanes are joined by the xor butterfly, the four waves in wave order
 __global__ __launch_bounds__(256) void ridge_stats_partial_kernel(const float* __restrict__ x, int64_t x_rs, int64_t x_cs,
                                                                   int64_t n, int n_in, double* __restrict__ work) {
-  __shared__ double red[256];
-  const int t = threadIdx.x;
+  __shared__ double red[4][32];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int64_t rows = (n + gridDim.x - 1) / gridDim.x;
   const int64_t r0 = (int64_t)blockIdx.x * rows;
   const int64_t r1 = r0 + rows < n ? r0 + rows : n;
-  for (int c = 0; c < n_in; ++c) {
-    const double K = (double)x[c * x_cs];
-    double s1 = 0.0, s2 = 0.0;
-    for (int64_t r = r0 + t; r < r1; r += 256) {
-      const double d = (double)x[r * x_rs + c * x_cs] - K;
-      s1 += d;
-      s2 += d * d;
-    }
-    for (int pass = 0; pass < 2; ++pass) {
-      red[t] = pass == 0 ? s1 : s2;
-      __syncthreads();
-      for (int off = 128; off >= 1; off >>= 1) {
-        if (t < off) red[t] += red[t + off];
-        __syncthreads();
+  double s1[16], s2[16], K[16];
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    s1[c] = s2[c] = 0.0;
+    K[c] = c < n_in ? (double)x[c * x_cs] : 0.0;
+  }
+  for (int64_t r = r0 + t; r < r1; r += 256) {
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+      if (c < n_in) {
+        const double d = (double)x[r * x_rs + c * x_cs] - K[c];
+        s1[c] += d;
+        s2[c] += d * d;
       }
-      if (t == 0) work[((size_t)blockIdx.x * n_in + c) * 2 + pass] = red[0];
-      __syncthreads();
+  }
+#pragma unroll
+  for (int c = 0; c < 16; ++c) {
+    if (c < n_in) {
+      const double a1 = wave_sum(s1[c]), a2 = wave_sum(s2[c]);
+      if (lane == 0) {
+        red[wave][2 * c] = a1;
+        red[wave][2 * c + 1] = a2;
+      }
     }
   }
+  __syncthreads();
+  if (t < 2 * n_in) work[(size_t)blockIdx.x * n_in * 2 + t] = ((red[0][t] + red[1][t]) + red[2][t]) + red[3][t];
 }
 
 // blocks added in order -> [n, mean.., M2..] (the layout of PolyRidge.local_stats), mean and scale (zero variance -> 1)
@@ -935,25 +944,40 @@ __global__ __launch_bounds__(256) void ridge_assemble_kernel(const double* __res
 }
 
 // W (nf, T) float64 solution -> intercept b = ybar - (s / cnt) . W (float64 and float32), W as float32 with a zero row up
-// to kpad, mean and 1 / scale as float32: everything the predict kernels read.
+// to kpad, mean and 1 / scale as float32: everything the predict kernels read.  A block owns 32 targets: s / cnt goes to
+// LDS once, eight thread groups take every eighth feature (coalesced over the targets), partial sums joined in group
+// order.  (First version: one thread per target walking all features with a division per step - 65 us for T = 32.)
 __global__ __launch_bounds__(256) void ridge_finish_kernel(const double* __restrict__ G, int na, int nf, int T,
                                                            const double* __restrict__ Wm, int64_t ldw, const double* __restrict__ mean,
                                                            const double* __restrict__ scale, int n_in, int kpad,
                                                            double* __restrict__ b64, float* __restrict__ b32,
                                                            float* __restrict__ W32, float* __restrict__ mean32,
                                                            float* __restrict__ inv32) {
+  __shared__ double sc[kMaxFeat];
+  __shared__ double part[8][32];
   const double cnt = G[0];
-  const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x, gsz = (int64_t)gridDim.x * 256;
-  for (int64_t t = gid; t < T; t += gsz) {
-    double acc = 0.0;
-    for (int f = 0; f < nf; ++f) acc += (G[1 + f] / cnt) * Wm[(size_t)f * ldw + t];
-    const double b = G[na + t] / cnt - acc;
+  const int tid = threadIdx.x;
+  for (int f = tid; f < nf; f += 256) sc[f] = G[1 + f] / cnt;
+  __syncthreads();
+  const int grp = tid >> 5, tt = tid & 31;
+  const int t = blockIdx.x * 32 + tt;
+  double acc = 0.0;
+  if (t < T)
+    for (int f = grp; f < nf; f += 8) acc += sc[f] * Wm[(size_t)f * ldw + t];
+  part[grp][tt] = acc;
+  __syncthreads();
+  if (grp == 0 && t < T) {
+    double a = part[0][tt];
+#pragma unroll
+    for (int g = 1; g < 8; ++g) a += part[g][tt];
+    const double b = G[na + t] / cnt - a;
     b64[t] = b;
     b32[t] = (float)b;
   }
+  const int64_t gid = (int64_t)blockIdx.x * 256 + tid, gsz = (int64_t)gridDim.x * 256;
   for (int64_t e = gid; e < (int64_t)kpad * T; e += gsz) {
-    const int f = (int)(e / T), t = (int)(e % T);
-    W32[e] = f < nf ? (float)Wm[(size_t)f * ldw + t] : 0.0f;
+    const int f = (int)(e / T), tq = (int)(e % T);
+    W32[e] = f < nf ? (float)Wm[(size_t)f * ldw + tq] : 0.0f;
   }
   for (int64_t c = gid; c < n_in; c += gsz) {
     mean32[c] = (float)mean[c];
@@ -1001,8 +1025,8 @@ extern "C" int hsr_ridge_finish(const double* g_dev, int32_t na, int32_t nf, int
               HSR_ERR_INVALID, "hsr_ridge_finish: NULL pointer");
   HSR_REQUIRE(nf >= 1 && na >= nf + 1 && T >= 1 && ldw >= T && kpad >= nf && n_in >= 1, HSR_ERR_INVALID,
               "hsr_ridge_finish: bad shape");
-  const int64_t total = (int64_t)kpad * T;
-  const int grid = (int)((total + 255) / 256 < 512 ? (total + 255) / 256 : 512);
+  HSR_REQUIRE(nf <= kMaxFeat, HSR_ERR_UNSUPPORTED, "hsr_ridge_finish: nf=%d > %d", nf, kMaxFeat);
+  const int grid = (T + 31) / 32;                 // a block per 32 targets (the float32 copies ride along grid-strided)
   hipLaunchKernelGGL(ridge_finish_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, g_dev, na, nf, T, w_dev, ldw, mean_dev,
                      scale_dev, n_in, kpad, b64_dev, b32_dev, w32_dev, mean32_dev, inv32_dev);
   HSR_LAUNCH_CHECK("ridge_finish_kernel");

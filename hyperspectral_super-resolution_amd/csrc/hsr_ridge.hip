@@ -891,19 +891,18 @@ __global__ __launch_bounds__(256) void ridge_stats_partial_kernel(const float* _
   if (t < 2 * n_in) work[(size_t)blockIdx.x * n_in * 2 + t] = ((red[0][t] + red[1][t]) + red[2][t]) + red[3][t];
 }
 
-// blocks added in order -> [n, mean.., M2..] (the layout of PolyRidge.local_stats), mean and scale (zero variance -> 1)
-__global__ __launch_bounds__(64) void ridge_stats_finish_kernel(const float* __restrict__ x, int64_t x_cs, int64_t n, int n_in,
-                                                                int nblocks, const double* __restrict__ work,
-                                                                double* __restrict__ stats, double* __restrict__ mean_out,
-                                                                double* __restrict__ scale_out) {
-  const int c = threadIdx.x;
-  if (c == 0) stats[0] = (double)n;
+// the blocks' sums joined (one wave per column, a lane per block, xor butterfly: a fixed order) -> [n, mean.., M2..] (the
+// layout of PolyRidge.local_stats), mean and scale (zero variance -> 1)
+__global__ __launch_bounds__(1024) void ridge_stats_finish_kernel(const float* __restrict__ x, int64_t x_cs, int64_t n, int n_in,
+                                                                  int nblocks, const double* __restrict__ work,
+                                                                  double* __restrict__ stats, double* __restrict__ mean_out,
+                                                                  double* __restrict__ scale_out) {
+  const int c = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (threadIdx.x == 0) stats[0] = (double)n;
   if (c >= n_in) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int b = 0; b < nblocks; ++b) {
-    s1 += work[((size_t)b * n_in + c) * 2];
-    s2 += work[((size_t)b * n_in + c) * 2 + 1];
-  }
+  const double s1 = wave_sum(lane < nblocks ? work[((size_t)lane * n_in + c) * 2] : 0.0);
+  const double s2 = wave_sum(lane < nblocks ? work[((size_t)lane * n_in + c) * 2 + 1] : 0.0);
+  if (lane != 0) return;
   const double K = (double)x[c * x_cs];
   const double mean = K + s1 / (double)n;
   double m2 = s2 - s1 * s1 / (double)n;
@@ -997,7 +996,8 @@ extern "C" int hsr_ridge_stats(const float* x_dev, int64_t x_rs, int64_t x_cs, i
   if (nblocks > kStatsBlocks) nblocks = kStatsBlocks;
   hipLaunchKernelGGL(ridge_stats_partial_kernel, dim3(nblocks), dim3(256), 0, (hipStream_t)stream, x_dev, x_rs, x_cs, n, n_in,
                      work_dev);
-  hipLaunchKernelGGL(ridge_stats_finish_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, x_dev, x_cs, n, n_in, nblocks,
+  static_assert(kStatsBlocks <= 64, "one lane per block");
+  hipLaunchKernelGGL(ridge_stats_finish_kernel, dim3(1), dim3(64 * n_in), 0, (hipStream_t)stream, x_dev, x_cs, n, n_in, nblocks,
                      work_dev, stats_dev, mean_dev, scale_dev);
   HSR_LAUNCH_CHECK("ridge_stats_kernel");
   return HSR_OK;
@@ -1026,7 +1026,9 @@ extern "C" int hsr_ridge_finish(const double* g_dev, int32_t na, int32_t nf, int
   HSR_REQUIRE(nf >= 1 && na >= nf + 1 && T >= 1 && ldw >= T && kpad >= nf && n_in >= 1, HSR_ERR_INVALID,
               "hsr_ridge_finish: bad shape");
   HSR_REQUIRE(nf <= kMaxFeat, HSR_ERR_UNSUPPORTED, "hsr_ridge_finish: nf=%d > %d", nf, kMaxFeat);
-  const int grid = (T + 31) / 32;                 // a block per 32 targets (the float32 copies ride along grid-strided)
+  int grid = (T + 31) / 32;                       // a block per 32 targets; the float32 copies ride along grid-strided,
+  const int64_t cpy = ((int64_t)kpad * T + 1023) / 1024;   // so there are at least enough blocks for 4 elements per thread
+  if (cpy > grid) grid = (int)(cpy < 64 ? cpy : 64);
   hipLaunchKernelGGL(ridge_finish_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, g_dev, na, nf, T, w_dev, ldw, mean_dev,
                      scale_dev, n_in, kpad, b64_dev, b32_dev, w32_dev, mean32_dev, inv32_dev);
   HSR_LAUNCH_CHECK("ridge_finish_kernel");

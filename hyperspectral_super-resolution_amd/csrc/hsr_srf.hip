@@ -145,7 +145,17 @@ static int srf_slots(int64_t npix, int P, int reserved_cus) {
   int64_t groups = (npix + P - 1) / P;
   if (groups < 1) groups = 1;
   const int64_t cap = (int64_t)(256 - reserved_cus) * (P == 64 ? 2 : 4);  // CUs x resident workgroups
-  return (int)(groups < cap ? groups : cap);
+  // Up to 64 groups: a slot per group.  65 .. 512 groups (tiles up to ~180 x 180, whose stand-alone step is launch-bound
+  // anyway): four groups per slot, at least 64 slots - so that a batch of small tiles does not flush and re-read one
+  // 1.3 KB partial per 64-pixel group (a 100 x 100 tile: 64 slots of 2-3 groups instead of 157 of one; batched K1+K2 of
+  // 256 such tiles 5 % faster on float32, 13-16 % on uint16 tiles).  More than 512 groups: one slot per resident workgroup
+  // as before (coarsening there costs a stand-alone 256 x 256 tile 8 %).
+  int64_t slots = groups;
+  if (groups > 64 && groups <= 512) {
+    slots = (groups + 3) / 4;
+    if (slots < 64) slots = 64;
+  }
+  return (int)(slots < cap ? slots : cap);
 }
 
 typedef __attribute__((address_space(1))) const void* gptr_t;

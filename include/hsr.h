@@ -70,10 +70,11 @@ int hsr_abi_version(void);
 const char* hsr_last_error(void);
 /* Number of moments per band for a degree: 3*deg + 2. */
 int hsr_moment_count(int32_t deg);
-/* Partial-sum slots a K1 launch over a tile of `npix` pixels uses: min(pixel groups, resident workgroups), a
- * function of npix and *opts (tile_pixels, reserved_cus) only - never of the device state - so the summation tree,
- * and with it every bit of the fitted coefficients, is reproducible.  Group g of the tile accumulates into slot
- * g % slots, in increasing g.  (hsr_poly_moments / _f64 use the default geometry: min(ceil(npix/64), 512).) */
+/* Partial-sum slots a K1 launch over a tile of `npix` pixels uses.  With G = ceil(npix / 64) pixel groups: G for
+ * G <= 64; max(64, ceil(G / 4)) for 65 <= G <= 512 (small tiles: coarser units keep a batch's partial traffic down);
+ * min(G, resident workgroups) above.  A function of npix and *opts (tile_pixels, reserved_cus) only - never of the
+ * device state - so the summation tree, and with it every bit of the fitted coefficients, is reproducible.  Group g
+ * of the tile accumulates into slot g % slots, in increasing g.  (hsr_poly_moments / _f64 use the default geometry: min(ceil(npix/64), 512).) */
 int hsr_partial_slots(int64_t npix, const hsr_srf_options* opts);
 /* Bytes of the partials workspace for (nb, deg): nb * (3deg+2) * HSR_MAX_PARTIALS doubles. */
 size_t hsr_partials_bytes(int32_t nb, int32_t deg);

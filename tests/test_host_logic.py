@@ -102,7 +102,7 @@ def test_batch_plan_host_side():
     nb, deg, M = 12, 3, 11
     assert lib.hsr_batch_plan(tiles, T, nb, deg, None, None, None, 0, ctypes.byref(info)) == 0
     slots = [lib.hsr_partial_slots(n, None) for n in npix]
-    assert [tiles[i].slots for i in range(T)] == slots == [157, 1, 2, 512, 157, 1]
+    assert [tiles[i].slots for i in range(T)] == slots == [64, 1, 2, 512, 64, 1]     # 157 groups -> 64 slots (hsr.h)
     assert [tiles[i].ngroups for i in range(T)] == [157, 1, 2, 16384, 157, 1]
     assert [tiles[i].slot0 for i in range(T)] == list(np.cumsum([0] + slots[:-1]))
     assert info.nunits == sum(slots) and info.total_pixels == sum(npix) and info.max_npix == 1 << 20
@@ -129,7 +129,7 @@ def test_batch_plan_host_side():
     # options: reserved CUs shrink the slot cap of the big tile only
     o = nat.SrfOptions(0, 8, 0, 0)
     assert lib.hsr_batch_plan(tiles, T, nb, deg, None, ctypes.byref(o), None, 0, ctypes.byref(info)) == 0
-    assert tiles[3].slots == 496 and tiles[0].slots == 157
+    assert tiles[3].slots == 496 and tiles[0].slots == 64
     # validation
     tiles[1].npix = 0
     assert lib.hsr_batch_plan(tiles, T, nb, deg, None, None, None, 0, ctypes.byref(info)) == 1 and b"npix" in lib.hsr_last_error()

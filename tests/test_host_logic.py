@@ -83,6 +83,18 @@ def test_sizing_helpers_and_error_strings():
     assert lib.hsr_gram_f64(P, 30, 32, P, 48, 48, 10, P, P, 48, None) == 1
     assert lib.hsr_gram_work_bytes(288, 576, 29127) >= 34 * 18 * 36 * 256 * 8
     assert lib.hsr_probe_read(P, 1 << 20, 4, P, None) == 1 and b"mode" in lib.hsr_last_error()
+    # entry points added in round 2 validate the same way (no launch without a GPU: every call below fails its checks first)
+    assert lib.hsr_srf_integrate_fit(P, 10, 285, P, k, k, 1, P, 1, 16, P, 1, 16, None, 0.0, 0.0, 3, P, None, None, None, None) == 1
+    assert b"NULL hsr_fused_fit" in lib.hsr_last_error()
+    bad_fit = nat.FusedFit(0, 0, 0, 0, 50)
+    assert lib.hsr_srf_integrate_fit(P, 10, 285, P, k, k, 1, P, 1, 16, P, 1, 16, None, 0.0, 0.0, 3, P, None, ctypes.byref(bad_fit), None, None) == 1
+    assert b"NULL pointer in hsr_fused_fit" in lib.hsr_last_error()
+    assert lib.hsr_ridge_stats_work_bytes(10) == 64 * 10 * 2 * 8 and lib.hsr_ridge_stats_work_bytes(17) == 0
+    assert lib.hsr_ridge_stats(P, 10, 1, 0, 10, P, P, P, P, None) == 1 and b"hsr_ridge_stats" in lib.hsr_last_error()
+    assert lib.hsr_ridge_assemble(P, 300, 288, 285, 32, 1.0, P, 256, P, 32, P, None) == 1 and b"bad shape" in lib.hsr_last_error()   # npad < nf
+    assert lib.hsr_ridge_finish(P, 288, 285, 32, P, 16, P, P, 10, 286, P, P, P, P, P, None) == 1                                  # ldw < T
+    assert lib.hsr_polyfeat_predict_cube(None, 1, 1, P, P, 10, 10, 3, P, 32, P, 32, 1, 1, -9999.0, 1, P, 10, None) == 1 and b"NULL" in lib.hsr_last_error()
+    assert lib.hsr_interleave_to_bip(P, 0, 3, 4, 4, 4, P, 0, None) == 1
 
 
 def test_batch_plan_host_side():

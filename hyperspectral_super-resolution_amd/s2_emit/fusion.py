@@ -290,6 +290,18 @@ class SpectralFusion:
         masks: optional sequence of uint8 (npix) tensors / None.  The returned BatchOutput (and the batch's buffers)
         are reused by the next step_batch() call on the same input tensors."""
         torch = nat.require_gpu()
+        # stacked inputs seen before: no per-tile slicing on the host (at T = 256 the slices and the per-tile key cost more
+        # host time than the three launches take on the GPU)
+        stack_key = None
+        if masks is None and hasattr(cubes, "dim") and hasattr(reals, "dim") and cubes.dim() == 4 and reals.dim() == 4:
+            stack_key = ("stack", cubes.data_ptr(), tuple(cubes.shape), reals.data_ptr(), tuple(reals.shape))
+            tb = self._batches.get(stack_key)
+            if tb is not None:
+                eng.batch_srf_integrate_moments(tb, self.min_valid, self.min_valid, self.tile_scale, self.tile_nodata,
+                                                events=k1_events)
+                eng.batch_reduce_solve(tb, self.min_count)
+                eng.batch_poly_apply(tb, use_mask=self.apply_mask, clip=self.clip)
+                return BatchOutput(self.names, tb)
         if hasattr(cubes, "dim"):
             cubes = [cubes[i] for i in range(cubes.shape[0])] if cubes.dim() == 4 else [cubes]
         if hasattr(reals, "dim"):
@@ -300,12 +312,14 @@ class SpectralFusion:
                     for c, r, m in zip(cubes, reals, masks))
         tb = self._batches.get(key)
         if tb is None:
-            if len(self._batches) >= 4:           # a few live batch plans at most
+            if len(self._batches) >= 8:           # a few live batch plans at most (stacked inputs hold two keys)
                 self._batches.pop(next(iter(self._batches)))
             tb = eng.TileBatch(cubes, reals, masks, self.table, self.deg, self.opts)
             tb.place(lambda b: eng.batch_srf_integrate_moments(b, self.min_valid, self.min_valid, self.tile_scale, self.tile_nodata),
                      self.placement_trials, self.placement_pitch_gb)
             self._batches[key] = tb
+        if stack_key is not None:
+            self._batches[stack_key] = tb              # same batch, found without slicing next time
         eng.batch_srf_integrate_moments(tb, self.min_valid, self.min_valid, self.tile_scale, self.tile_nodata,
                                         events=k1_events)
         eng.batch_reduce_solve(tb, self.min_count)

@@ -1804,3 +1804,25 @@ def test_predict_cube_bad_pixel_rule_in_kernel(torch_gpu):
             ref = model.predict_cube(torch.where(bad.reshape(1, H, W), clean, dirty), nodata=None).reshape(T, -1)
             assert torch.equal(g2[:, ~bad].view(torch.int32), ref[:, ~bad].view(torch.int32)), (Cin, deg, T, nodata)
             assert torch.isfinite(g2[:, ~bad]).all()
+
+
+@pytest.mark.gpu
+def test_place_batch_inputs_keeps_results(torch_gpu):
+    """place_batch_inputs(): copies of a stacked batch tried in other stretches of device memory - same bytes, so the batch
+    on the returned tensors is bit-identical to the batch on the originals, and step_batch() finds the cached plan."""
+    torch = torch_gpu
+    from s2_emit import SpectralFusion
+    from s2_emit.synthetic import device_problem
+    p = device_problem(64 * 4, 64, 285, deg=3, seed=9)
+    cubes, reals = p.cube.reshape(4, 64, 64, 285), p.real.reshape(4, 64, 64, -1)
+    a = SpectralFusion(p.emit_w, p.srf, p.good_mask, deg=3, placement_trials=0)
+    b = SpectralFusion(p.emit_w, p.srf, p.good_mask, deg=3, placement_trials=3, placement_pitch_gb=1.0)
+    oa = a.step_batch(cubes, reals)
+    c2, r2, log = b.place_batch_inputs(cubes, reals)
+    assert len(log["joint_ms"]) == 3 and torch.equal(c2, cubes) and torch.equal(r2, reals)
+    nb_before = len(b._batches)
+    ob = b.step_batch(c2, r2)
+    torch.cuda.synchronize()
+    assert len(b._batches) == nb_before                     # the placed batch was reused
+    assert torch.equal(oa.coeffs.view(torch.int64), ob.coeffs.view(torch.int64))
+    assert torch.equal(oa.matched.view(torch.int32), ob.matched.view(torch.int32))

@@ -1826,3 +1826,33 @@ def test_place_batch_inputs_keeps_results(torch_gpu):
     assert len(b._batches) == nb_before                     # the placed batch was reused
     assert torch.equal(oa.coeffs.view(torch.int64), ob.coeffs.view(torch.int64))
     assert torch.equal(oa.matched.view(torch.int32), ob.matched.view(torch.int32))
+
+
+@pytest.mark.gpu
+def test_step_batch_other_band_counts(torch_gpu):
+    """The batched slot reduction has one instantiation per band-count class (<= 8, <= 12, <= 16 bands): 3, 7 and 13
+    supported bands, every tile still bit-identical to its own step()."""
+    torch = torch_gpu
+    from s2_emit import SpectralFusion
+    w, _ = onp.synthetic_wavelengths()
+    full = onp.synthetic_srf()
+    names = list(full)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(31)
+    shapes = [(100, 100), (9, 40), (64, 65)]
+    for pick in (names[1:4], names[:7], names):            # good_mask None: all 13 bands have support
+        srf = {k: full[k] for k in pick}
+        plan = SpectralFusion(w, srf, None, deg=2, min_count=5)
+        nb = len(plan.names)
+        assert nb == len(pick)
+        row = (nb + 3) // 4 * 4
+        cubes = [torch.rand((H, W, 285), generator=g, device="cuda") * 0.6 for H, W in shapes]
+        reals = [torch.rand((H, W, row), generator=g, device="cuda") for H, W in shapes]
+        out = plan.step_batch(cubes, reals)
+        torch.cuda.synchronize()
+        for i in range(len(shapes)):
+            o = plan.step(cubes[i], reals[i], reuse_buffers=False)
+            ti = out.tile(i)
+            assert torch.equal(o.moments.view(torch.int64), ti.moments.view(torch.int64)), (nb, i)
+            assert torch.equal(o.coeffs.view(torch.int64), ti.coeffs.view(torch.int64)), (nb, i)
+            assert torch.equal(o.matched.view(torch.int32), ti.matched.view(torch.int32)), (nb, i)

@@ -326,6 +326,14 @@ class SpectralFusion:
         eng.batch_poly_apply(tb, use_mask=self.apply_mask, clip=self.clip)
         return BatchOutput(self.names, tb)
 
+    @staticmethod
+    def release_search_memory():
+        """The placement searches leave their spacers and losing candidates (up to ~200 GB) in torch's caching allocator, where
+        later torch allocations reuse them.  This hands them back to the driver (torch.cuda.empty_cache()) for allocators
+        that do not go through torch - at a price: measured right after a search it cost K1 0.2-3 % of the speed the search
+        had just found (eng.placement_search), so call it only if that memory is needed elsewhere."""
+        nat.require_gpu().cuda.empty_cache()
+
     def place_batch_inputs(self, cubes, reals):
         """place_inputs() for a resident batch given as stacked tensors (T, H, W, B) / (T, H, W, C): candidate sets = (copy
         of the stacked cube, copy of the stacked targets, the batch's own output images) one stretch of device memory each,

@@ -1723,6 +1723,12 @@ def test_placement_trials_do_not_change_results(torch_gpu):
     assert torch.equal(oa.coeffs.view(torch.int64), oc.coeffs.view(torch.int64))
     assert torch.equal(oa.matched.view(torch.int32), oc.matched.view(torch.int32))
     assert c.place_inputs(p.cube, p.real)[2] == {}               # already placed for this tile size: a no-op
+    # a spacer that cannot be allocated ends the search with what has been seen (no exception)
+    d = SpectralFusion(p.emit_w, p.srf, p.good_mask, deg=3, placement_trials=3, placement_pitch_gb=400.0)
+    od = d.step(p.cube, p.real)
+    torch.cuda.synchronize()
+    assert len(d.placement_log[384 * 256]) == 1
+    assert torch.equal(oa.matched.view(torch.int32), od.matched.view(torch.int32))
 
 
 @pytest.mark.gpu

@@ -1,20 +1,23 @@
 #!/usr/bin/env python3
 """Headline benchmark: fused EMIT->S2 spectral matching throughput in Mpixel*bands/s.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python bench.py [--gpus N] [--steps K] [--warmup W]            (N > 1: this process starts the N ranks itself)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-           --master-port P bench.py --gpus N --steps K --warmup W
+           --master-port P bench.py --gpus N --steps K --warmup W   (the wrapped form works too)
 
 A step = one pass of the hot path over one batch of synthetic input: per GPU one 1024x1024x285
 EMIT-like cube + matching real-S2 planes (BASELINE.json configs[2]; weak scaling: one tile per GPU,
 configs[3]/[4]) -> K1+K2 (SRF integration + Vandermonde moments, one pass over the cube) ->
 C1 (RCCL exchange, N>1) -> polynomial solve (degree 3, per band, all valid pixels) -> K3 (apply).
 Inputs are resident in HBM before the timed region.  value = N*H*W*285*K / t / 1e6.
+`--scaling strong` splits ONE HxW cube into N row blocks (H/N rows per rank, one global fit): value = H*W*285*K / t / 1e6.
 
 The JSON line also carries:
   roofline     dominant kernel (K1+K2 fused): algorithmic bytes = H*W*285*4 per launch (the cube read
                exactly once) / its average duration measured with HIP events on the
                launch stream inside the timed region, against the 8 TB/s HBM3E peak.
+  cold         the same step on the caller's first allocations, with no placement trials and no settle phase
+               (what a caller who just allocates and runs gets), measured in the same process before the search.
   cpu_baseline the oracle (NumPy restatement in the reference's operation order) timed on this box's
                host cores on a bounded row-slab of the same workload (rank 0, N=1 only).
 """
@@ -34,9 +37,10 @@ for p in (ROOT, os.path.join(ROOT, "hyperspectral_super-resolution_amd")):
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 HBM_PEAK_GBS = 8000.0          # MI355X HBM3E vendor peak (MI355X_MICROARCH.md)
+TRAFFIC_FILE = os.path.join("profiles", "traffic.json")
 
 
-def parse_args():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
@@ -45,6 +49,10 @@ def parse_args():
     ap.add_argument("--width", type=int, default=1024)
     ap.add_argument("--bands", type=int, default=285)
     ap.add_argument("--deg", type=int, default=3)
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: one HxW tile per GPU (per-GPU work fixed).  strong: ONE HxW cube split into N row blocks of "
+                         "H/N rows, one per rank, and one global fit over all of them (total work fixed; SURVEY.md 8e "
+                         "'row-blocks H/G')")
     ap.add_argument("--coeff-sync", default="allreduce", choices=["local", "allreduce", "broadcast"])
     ap.add_argument("--cpu-rows", type=int, default=256,
                     help="rows of the cube the single-thread CPU baseline processes (the all-cores run takes the whole cube)")
@@ -83,10 +91,70 @@ def parse_args():
                     help="untimed load before the warm-up, to reach the GPU's settled power state: settle_ms / 0.25 steps per tile (0: none)")
     ap.add_argument("--no-input-placement", action="store_true",
                     help="keep the synthetic cube / target where the allocator first put them (no placement trials for inputs)")
+    ap.add_argument("--placement-trials", type=int, default=12,
+                    help="candidate allocations the placement search may time (0: none; the search is opt-in in the library)")
+    ap.add_argument("--placement-budget-gb", type=float, default=200.0,
+                    help="device memory the placement search may hold (spacers + candidates); the library's own default is half "
+                         "of the free memory")
+    ap.add_argument("--cold-steps", type=int, default=20,
+                    help="steps of the 'cold' region (first allocations, no placement trials, no settle), run before everything "
+                         "else and reported as line['cold'] (0: skip)")
     ap.add_argument("--event-every", type=int, default=4,
                     help="bracket the K1+K2 kernel with HIP events on every n-th timed step (each pair of event "
                          "records costs ~12 us of launch gap, so not on every step)")
-    return ap.parse_args()
+    ap.add_argument("--dist-timeout", type=float, default=180.0,
+                    help="seconds a rank waits in init_process_group or in any collective before the run is aborted (N > 1)")
+    ap.add_argument("--deadline", type=float, default=900.0,
+                    help="N > 1: hard limit per rank in seconds - a rank still alive then dumps its stacks and exits non-zero "
+                         "(0: none).  The self-launching parent gives the whole job this long plus a minute.")
+    return ap.parse_args(argv)
+
+
+# ----------------------------------------------------------------------------------------------------------
+# --gpus N without a launcher: start the ranks from here
+# ----------------------------------------------------------------------------------------------------------
+def _free_port() -> int:
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def self_launch(args, argv) -> int:
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: this process - which never touches the GPU and
+    replaces nothing by exec - starts `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` as a
+    child, relays rank 0's single JSON line to its own stdout and returns the child's exit status (non-zero if any rank
+    failed, if the job outlived its deadline, or if no line was produced)."""
+    import subprocess
+    if not args.same_device:
+        import torch                                   # device_count() does not initialise the GPU
+        ndev = torch.cuda.device_count()
+        if args.gpus > ndev:
+            sys.stderr.write(f"[bench] --gpus {args.gpus} needs {args.gpus} visible GPUs on this node, {ndev} found "
+                             f"(rehearse the control flow of more ranks than GPUs with --backend gloo --same-device)\n")
+            return 2
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    limit = args.deadline + 60.0 if args.deadline > 0 else None
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        out, _ = proc.communicate(timeout=limit)
+    except subprocess.TimeoutExpired:
+        import signal
+        os.killpg(proc.pid, signal.SIGKILL)             # the launcher and every rank: exactly the group started above
+        proc.wait()
+        sys.stderr.write(f"[bench] {args.gpus}-rank job still running after {limit:.0f} s: killed\n")
+        return 3
+    lines = [ln for ln in out.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    if proc.returncode != 0:
+        sys.stderr.write(f"[bench] {args.gpus}-rank job failed (exit status {proc.returncode})\n")
+        return proc.returncode if 0 < proc.returncode < 256 else 1
+    if not lines:
+        sys.stderr.write("[bench] the ranks exited cleanly but rank 0 printed no JSON line\n")
+        return 4
+    sys.stdout.write(lines[-1] + "\n")
+    sys.stdout.flush()
+    return 0
 
 
 def _claim_stdout() -> int:
@@ -99,46 +167,86 @@ def _claim_stdout() -> int:
     return saved
 
 
-def _noop(_):
-    return os.getpid()
-
-
-def _cpu_slab(job):
+# ----------------------------------------------------------------------------------------------------------
+# CPU baseline (the oracle on host cores)
+# ----------------------------------------------------------------------------------------------------------
+def _cpu_slab(shared, job):
     """Worker of the all-cores CPU run: SRF integration (the reference's 13 float64 passes) of rows [r0, r1)."""
     import numpy as np
-    from multiprocessing import shared_memory
     from oracle import oracle_np as onp
-    name, shape, r0, r1 = job
-    shm = shared_memory.SharedMemory(name=name)
-    try:
-        R = np.ndarray(shape, dtype=np.float32, buffer=shm.buf)[r0:r1]
-        srf = onp.synthetic_srf()
-        w, good = onp.synthetic_wavelengths(shape[2])
-        ps = onp.pseudo_s2_srf_integral(R, w, srf, good)
-        return r0, np.stack([v for v in ps.values() if v is not None]).astype(np.float32)      # poly_regression.py:104
-    finally:
-        shm.close()
+    shape, r0, r1 = job
+    R = np.frombuffer(shared, dtype=np.float32, count=shape[0] * shape[1] * shape[2]).reshape(shape)[r0:r1]
+    srf = onp.synthetic_srf()
+    w, good = onp.synthetic_wavelengths(shape[2])
+    ps = onp.pseudo_s2_srf_integral(R, w, srf, good)
+    return r0, np.stack([v for v in ps.values() if v is not None]).astype(np.float32)      # poly_regression.py:104
+
+
+def _cpu_worker(shared, jobs, results):
+    while True:
+        job = jobs.get()
+        if job is None:
+            return
+        try:
+            results.put((True, _cpu_slab(shared, job)))
+        except BaseException as e:          # report, do not die silently: the parent waits for one result per job
+            results.put((False, repr(e)))
+
+
+class CpuPool:
+    """n worker processes forked at construction - BEFORE anything touches the GPU (a forked child of a process with a
+    live HIP runtime is not something to rely on; an executor that forks on demand would do exactly that later) - which
+    sleep on a queue until cpu_baseline() hands them row slabs.  The cube reaches them through an anonymous shared
+    mapping created before the fork and inherited (no named shared-memory segment, hence nothing for a resource tracker
+    to complain about at exit)."""
+
+    def __init__(self, n: int, nbytes: int):
+        import mmap
+        import multiprocessing as mp
+        ctx = mp.get_context("fork")
+        self.shared = mmap.mmap(-1, max(int(nbytes), mmap.PAGESIZE))
+        self.jobs, self.results = ctx.SimpleQueue(), ctx.SimpleQueue()
+        self.procs = [ctx.Process(target=_cpu_worker, args=(self.shared, self.jobs, self.results), daemon=True)
+                      for _ in range(n)]
+        for p in self.procs:
+            p.start()
+
+    def map(self, jobs):
+        jobs = list(jobs)
+        for j in jobs:
+            self.jobs.put(j)
+        out = []
+        for _ in jobs:
+            ok, res = self.results.get()
+            if not ok:
+                raise RuntimeError(f"CPU baseline worker failed: {res}")
+            out.append(res)
+        return out
+
+    def shutdown(self):
+        for _ in self.procs:
+            self.jobs.put(None)
+        for p in self.procs:
+            p.join(timeout=10)
+        self.shared.close()
 
 
 def start_cpu_pool(args):
-    """Fork the CPU workers BEFORE anything touches the GPU (a forked child of a process with a live HIP runtime is
-    not something to rely on); they sleep until cpu_baseline() hands them row slabs through shared memory."""
-    import multiprocessing as mp
-    from concurrent.futures import ProcessPoolExecutor
     n = args.cpu_workers if args.cpu_workers > 0 else min(16, os.cpu_count() or 1)
-    pool = ProcessPoolExecutor(max_workers=n, mp_context=mp.get_context("fork"))
-    pids = set(pool.map(_noop, range(4 * n)))
-    return pool, n, len(pids)
+    pool = CpuPool(n, args.height * args.width * args.bands * 4)
+    alive = sum(p.is_alive() for p in pool.procs)
+    if alive != n:
+        raise RuntimeError(f"only {alive} of {n} CPU workers started")
+    return pool, n, alive
 
 
 def cpu_baseline(args, pool, nworkers, cube_host, real_host, gpu_pseudo, gpu_matched):
     """The oracle ('port' of the reference's NumPy path: 13 full-cube float64 SRF passes, np.polyfit, np.polyval) on the
     SAME cube the GPU processed:
       * single thread (NumPy elementwise is single-threaded: the reference's actual behaviour) on the first --cpu-rows rows;
-      * row-sharded over the host cores (ProcessPoolExecutor) on the whole cube, SURVEY.md 8(d) - its outputs are the
+      * row-sharded over the host cores on the whole cube, SURVEY.md 8(d) - its outputs are the
         full-size parity reference for the GPU's pseudo / matched images (max_rel_err)."""
     import numpy as np
-    from multiprocessing import shared_memory
     from oracle import oracle_np as onp
     H, W, B = cube_host.shape
     srf = onp.synthetic_srf()
@@ -152,21 +260,18 @@ def cpu_baseline(args, pool, nworkers, cube_host, real_host, gpu_pseudo, gpu_mat
            "sample": f"first {rows} rows of the {H}x{W}x{B} cube the GPU processed: SRF (13 float64 passes) + deg-{args.deg} "
                      f"np.polyfit per band + np.polyval apply, single-thread NumPy, {dt1:.1f} s"}
     # all cores, whole cube
-    shm = shared_memory.SharedMemory(create=True, size=cube_host.nbytes)
-    try:
-        np.ndarray(cube_host.shape, dtype=np.float32, buffer=shm.buf)[...] = cube_host
-        slab = max(8, min(64, H // max(1, 2 * nworkers)))
-        jobs = [(shm.name, cube_host.shape, r0, min(H, r0 + slab)) for r0 in range(0, H, slab)]
-        t0 = time.perf_counter()
-        parts = dict(pool.map(_cpu_slab, jobs))
-        pseudo = np.concatenate([parts[r0] for r0 in sorted(parts)], axis=1)               # (nb, H, W) float32
-        valid = np.ones(pseudo.shape[1:], dtype=bool)
-        coeffs, _ = onp.fit_per_band_poly(pseudo, real_host, valid, args.deg, 0.0, 50)
-        matched = onp.apply_poly_planes(pseudo, coeffs, None, clip=True)
-        dtn = time.perf_counter() - t0
-    finally:
-        shm.close()
-        shm.unlink()
+    if cube_host.nbytes > len(pool.shared):
+        raise RuntimeError("CPU pool was sized for a smaller cube")
+    np.frombuffer(pool.shared, dtype=np.float32, count=cube_host.size).reshape(cube_host.shape)[...] = cube_host
+    slab = max(8, min(64, H // max(1, 2 * nworkers)))
+    jobs = [(tuple(cube_host.shape), r0, min(H, r0 + slab)) for r0 in range(0, H, slab)]
+    t0 = time.perf_counter()
+    parts = dict(pool.map(jobs))
+    pseudo = np.concatenate([parts[r0] for r0 in sorted(parts)], axis=1)               # (nb, H, W) float32
+    valid = np.ones(pseudo.shape[1:], dtype=bool)
+    coeffs, _ = onp.fit_per_band_poly(pseudo, real_host, valid, args.deg, 0.0, 50)
+    matched = onp.apply_poly_planes(pseudo, coeffs, None, clip=True)
+    dtn = time.perf_counter() - t0
     out["all_cores"] = {"value": round(H * W * B / dtn / 1e6, 1), "cores": nworkers, "seconds": round(dtn, 2),
                         "sample": f"whole {H}x{W}x{B} cube, SRF row-sharded over {nworkers} processes ({slab}-row slabs), "
                                   f"polyfit + polyval in the parent"}
@@ -180,26 +285,33 @@ def cpu_baseline(args, pool, nworkers, cube_host, real_host, gpu_pseudo, gpu_mat
     return out, err
 
 
-def main():
-    args = parse_args()
+# ----------------------------------------------------------------------------------------------------------
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args, argv))
     real_stdout = _claim_stdout()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    want_cpu = world == 1 and rank == 0 and not args.no_cpu_baseline and args.tiles_per_gpu == 1 and args.cube == "f32"
+    if world > 1 and args.deadline > 0:
+        import faulthandler
+        faulthandler.dump_traceback_later(args.deadline, exit=True)     # a wedged rank ends non-zero, with its stacks on stderr
+    strong = args.scaling == "strong"
+    want_cpu = (world == 1 and rank == 0 and not args.no_cpu_baseline and args.tiles_per_gpu == 1 and args.cube == "f32")
     pool = nworkers = None
     if want_cpu:
         pool, nworkers, _ = start_cpu_pool(args)          # forked before the GPU is initialised
+    import datetime
     import torch
     import torch.distributed as dist
     from s2_emit import SpectralFusion
     from s2_emit import _engine as eng
     from s2_emit.synthetic import device_problem
 
-    if world > 1 and world != args.gpus:
+    if world != args.gpus and not (world == 1 and args.gpus <= 1):
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("for --gpus N > 1 launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
     if args.same_device:
         if args.backend != "gloo":
             raise SystemExit("--same-device is a rehearsal mode and needs --backend gloo (RCCL wants one GPU per rank)")
@@ -209,10 +321,16 @@ def main():
         raise SystemExit(f"[bench] rank {rank}: local rank {local_rank} needs cuda:{local_rank}, but only {ndev} device(s) are visible. "
                          f"--gpus N needs N visible GPUs on this node (rehearse the control flow of more ranks than GPUs with "
                          f"--backend gloo --same-device).")
+    if strong and (args.height % world or args.tiles_per_gpu != 1):
+        raise SystemExit(f"--scaling strong needs --height ({args.height}) divisible by the number of ranks ({world}) and one tile per GPU")
+    if strong and world > 1 and args.coeff_sync == "local":
+        raise SystemExit("--scaling strong fits ONE polynomial over all row blocks: --coeff-sync must not be 'local'")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if args.force_exchange and world != 1:
         raise SystemExit("--force-exchange is a one-process rehearsal")
+    exchange_ranks = None
+    dist_timeout = datetime.timedelta(seconds=args.dist_timeout)
     if world > 1 or args.force_exchange:
         def rccl_options():
             # RCCL's internal stream must not share a hardware queue with the stream K1 runs on (streams of the default
@@ -221,32 +339,39 @@ def main():
             opts.is_high_priority_stream = True
             return opts
         if args.force_exchange:
-            dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29531", rank=0, world_size=1, device_id=device,
-                                    pg_options=rccl_options())
+            dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1, device_id=device,
+                                    pg_options=rccl_options(), timeout=dist_timeout)
         elif args.backend == "nccl":
             # No fallback: a backend chosen per rank after a partial RCCL failure would leave some ranks inside an RCCL
             # collective and others in gloo (a hang), and a host-staged gloo number must not pass for an xGMI one.
-            dist.init_process_group("nccl", device_id=device, pg_options=rccl_options())     # "nccl" is RCCL on ROCm
-            probe = torch.ones(1, device=device)
-            dist.all_reduce(probe)                                 # the communicator really works, on every rank
-            torch.cuda.synchronize()
-            if int(probe.item()) != world:
-                raise SystemExit(f"[bench] RCCL all-reduce of ones gave {probe.item()} on {world} ranks")
+            dist.init_process_group("nccl", device_id=device, pg_options=rccl_options(), timeout=dist_timeout)   # "nccl" is RCCL on ROCm
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=dist_timeout)
+        # the communicator really works, on every rank: an all-reduce of ones must count the ranks (reported as rccl_ranks)
+        probe = torch.ones(1, device=device if args.backend == "nccl" or args.force_exchange else "cpu")
+        dist.all_reduce(probe)
+        if probe.is_cuda:
+            torch.cuda.synchronize()
+        exchange_ranks = int(probe.item())
+        if exchange_ranks != world:
+            raise SystemExit(f"[bench] all-reduce of ones gave {exchange_ranks} on {world} ranks")
 
-    H, W, B = args.height, args.width, args.bands
+    Hfull, W, B = args.height, args.width, args.bands
+    H = Hfull // world if strong else Hfull            # rows this rank holds
     ntl = max(1, args.tiles_per_gpu)
     probs = [device_problem(H, W, B, deg=args.deg, seed=rank * ntl + i, device=device) for i in range(ntl)]
     prob = probs[0]
-    pipelined = ntl == 1 and (args.pipeline == "on" or (args.pipeline == "auto" and (world > 1 or args.force_exchange)))
-    plan = SpectralFusion(prob.emit_w, prob.srf, prob.good_mask, deg=args.deg, min_valid=0.0, min_count=50,
-                          clip=True, device=device, group=None,
-                          coeff_sync=args.coeff_sync if (world > 1 or args.force_exchange) else "local",
-                          force_exchange=args.force_exchange,
-                          reserved_cus=args.reserve_cus if pipelined else 0,   # CUs kept free for the side stream
-                          u16_fast=args.u16_fast, fused_fit=args.fused_fit,
-                          placement_trials=0 if args.same_device else 12)
+    exchanging = world > 1 or args.force_exchange
+    pipelined = ntl == 1 and (args.pipeline == "on" or (args.pipeline == "auto" and exchanging))
+
+    def make_plan(trials):
+        return SpectralFusion(prob.emit_w, prob.srf, prob.good_mask, deg=args.deg, min_valid=0.0, min_count=50,
+                              clip=True, device=device, group=None,
+                              coeff_sync=args.coeff_sync if exchanging else "local",
+                              force_exchange=args.force_exchange,
+                              reserved_cus=args.reserve_cus if pipelined else 0,   # CUs kept free for the side stream
+                              u16_fast=args.u16_fast, fused_fit=args.fused_fit, placement_trials=trials,
+                              placement_budget_gb=args.placement_budget_gb)
     real = prob.real            # (H, W, row) band-last, like the cube and the reference's (H, W, C) images
     cube = prob.cube
     if args.cube == "u16":      # quantise once, outside the timed region (the writer's arithmetic, on the device)
@@ -254,8 +379,73 @@ def main():
             pr.cube_u16 = eng.tile_encode_u16(pr.cube)
             pr.cube = None
         cube = prob.cube_u16
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def runner(plan_, cube_, real_, tiles_):
+        def run_step(k1_events=None):
+            if ntl > 1:
+                return plan_.fuse_mosaic(tiles_, k1_events=k1_events, resident=True)
+            if pipelined:
+                return plan_.submit(cube_, real_, k1_events=k1_events)
+            return plan_.step(cube_, real_, k1_events=k1_events)
+        return run_step
+
+    def timed_region(plan_, run_step, steps, warm, settle_steps):
+        """settle (untimed load) -> W warm-up steps -> barrier -> exactly `steps` timed steps -> barrier."""
+        for i in range(settle_steps):
+            run_step()
+            if (i + 1) % 50 == 0:
+                torch.cuda.synchronize()     # keep the launch queue short
+        for _ in range(max(warm, 1)):        # always one untimed pass: code-object load and LDS attributes are setup, not a step
+            run_step()
+        if pipelined:
+            plan_.flush()
+        barrier()
+        every = max(1, args.event_every)
+        ev = {i: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+              for i in range(0, steps, every)}
+        t0 = time.perf_counter()
+        for i in range(steps):
+            run_step(ev.get(i))
+        if pipelined:
+            plan_.flush()            # the last tile's apply belongs to the timed region
+        barrier()
+        return time.perf_counter() - t0, ev
+
+    def max_over_ranks(x):
+        tt = torch.tensor([x], dtype=torch.float64, device=device)
+        if world > 1:
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        return float(tt.item())
+
+    # A generation-2 pass of Python's cycle collector takes ~40 ms with torch imported - several times the whole
+    # timed region - and stalls the launch thread (seen in rocprof traces as a 37-50 ms idle gap in front of one
+    # kernel).  As timeit does: collect now, keep the collector off while timing.  (Before the warm-up, not between
+    # warm-up and timed region: 40 ms of idle GPU there put the timed steps into the transient described below.)
+    import gc
+    gc.collect()
+    gc.disable()
+
+    # ---- cold region: what a caller gets who allocates, builds a plan and runs (no placement trials, no settle) ----
+    cold = None
+    if args.cold_steps > 0 and ntl == 1:
+        cold_plan = make_plan(0)
+        dtc, evc = timed_region(cold_plan, runner(cold_plan, cube, real, None), args.cold_steps, 1, 0)
+        dtc = max_over_ranks(dtc)
+        kc = [a.elapsed_time(b) for a, b in evc.values()]
+        cold = {"ms_per_step": round(dtc / args.cold_steps * 1e3, 4), "kernel_ms": round(sum(kc) / max(1, len(kc)), 4),
+                "steps": args.cold_steps,
+                "note": "same step, same process, BEFORE the placement trials: inputs and images where the allocator first put "
+                        "them, one untimed step (code-object load), no settle phase - the speed a caller's own tensors get"}
+        del cold_plan, evc
+
+    plan = make_plan(0 if args.same_device else args.placement_trials)
     input_log = None
-    if ntl == 1 and not args.no_input_placement and not args.same_device:   # (ranks sharing one GPU would each claim ~200 GB)
+    if ntl == 1 and not args.no_input_placement and not args.same_device and args.placement_trials > 1:
         # where the resident inputs lie in HBM is the benchmark's to choose: the same slow stretches of device memory that
         # the plan avoids for its own images (profiles/r02_two_speeds.md) slow K1's read streams too, so the cube and the
         # target are cloned into a few regions before the warm-up and the fastest copies kept (same bytes, same results)
@@ -268,26 +458,8 @@ def main():
             prob.cube = cube
         prob.real = real
     tiles = [((pr.cube_u16 if args.cube == "u16" else pr.cube), pr.real) for pr in probs]
+    run_step = runner(plan, cube, real, tiles)
 
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    def run_step(k1_events=None):
-        if ntl > 1:
-            return plan.fuse_mosaic(tiles, k1_events=k1_events, resident=True)
-        if pipelined:
-            return plan.submit(cube, real, k1_events=k1_events)
-        return plan.step(cube, real, k1_events=k1_events)
-
-    # A generation-2 pass of Python's cycle collector takes ~40 ms with torch imported - several times the whole
-    # timed region - and stalls the launch thread (seen in rocprof traces as a 37-50 ms idle gap in front of one
-    # kernel).  As timeit does: collect now, keep the collector off while timing.  (Before the warm-up, not between
-    # warm-up and timed region: 40 ms of idle GPU there put the timed steps into the transient described next.)
-    import gc
-    gc.collect()
-    gc.disable()
     # Steady state before timing (tools/dbg/ramp.py, profiles/r02_ramp.log): started from a GPU that idled for >= 10 ms,
     # the first ~10 steps run at full speed, the next ~100 run 6-10 % slower (0.243-0.254 against 0.221 ms) and only
     # then the step time settles - a power-management transient, longer than a 20-step timed region.  A pipeline that
@@ -295,26 +467,9 @@ def main():
     # --settle-ms before the W warm-up steps; the timed region follows the warm-up with no host work in between.
     # The number of settle steps is fixed by the arguments, NOT by a clock: with more than one rank every step holds a
     # collective, and ranks that looped "until 250 ms have passed" would issue different numbers of them.
-    settle_steps = int(args.settle_ms / (0.25 * ntl) + 0.5) if args.settle_ms > 0 else 0
-    for i in range(settle_steps):
-        run_step()
-        if (i + 1) % 50 == 0:
-            torch.cuda.synchronize()     # keep the launch queue short
-    for _ in range(max(args.warmup, 1)):    # always one untimed pass: code-object load and LDS attributes are setup, not a step
-        run_step()
-    if pipelined:
-        plan.flush()
-    barrier()
-    every = max(1, args.event_every)
-    ev = {i: (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-          for i in range(0, args.steps, every)}
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        run_step(ev.get(i))
-    if pipelined:
-        plan.flush()            # the last tile's apply belongs to the timed region
-    barrier()
-    dt = time.perf_counter() - t0
+    per_step_ms = 0.25 * ntl * H / Hfull
+    settle_steps = int(args.settle_ms / max(per_step_ms, 0.02) + 0.5) if args.settle_ms > 0 else 0
+    dt, ev = timed_region(plan, run_step, args.steps, args.warmup, settle_steps)
     gc.enable()
 
     # the same K1+K2 launch, event-bracketed every time, outside the timed region: >= 20 launches for roofline.frac
@@ -330,15 +485,12 @@ def main():
     extra = [a.elapsed_time(b) for a, b in ev2]
     k1_all = in_region + extra
     k1_ms = sum(k1_all) / max(1, len(k1_all))
-    tt = torch.tensor([dt], dtype=torch.float64, device=device)
-    if world > 1:
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-    dt_max = float(tt.item())
+    dt_max = max_over_ranks(dt)
 
     if rank == 0:
         nb = len(prob.names)
-        npb = H * W * B
-        value = world * ntl * npb * args.steps / dt_max / 1e6
+        npb = H * W * B                              # pixel*bands one rank processes per step and tile
+        value = world * ntl * npb * args.steps / dt_max / 1e6          # strong: world * (Hfull / world) rows = the one cube
         esz = 4 if args.cube == "f32" else 2
         cube_bytes = npb * esz
         full_bytes = H * W * (esz * B + 16 * nb)        # + pseudo write, real read, apply read + write (no mask in this run)
@@ -346,20 +498,22 @@ def main():
         achieved = launch_bytes / (k1_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": "srf_kernel<deg,fast> (K1+K2 fused)" if args.cube == "f32" else "srf_u16_ring_kernel<deg> (K1+K2 fused, uint16 tile decode%s)" % (", fast arithmetic" if args.u16_fast else ""), "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None, "algorithmic_bytes": launch_bytes, "kernel_ms": round(k1_ms, 4),
+                "traffic": None, "traffic_source": None, "algorithmic_bytes": launch_bytes, "kernel_ms": round(k1_ms, 4),
                 "kernel_launches_timed": len(k1_all),
                 "kernel_ms_in_timed_region": round(sum(in_region) / max(1, len(in_region)), 4), "launches_in_timed_region": len(in_region),
                 "kernel_ms_after_region": round(sum(extra) / max(1, len(extra)), 4) if extra else None,
-                "agrees_with": "profiles/r02_kernel_stats.csv (rocprofv3 --kernel-trace --stats of this command): average duration of "
+                "agrees_with": "profiles/r03_kernel_stats.csv (rocprofv3 --kernel-trace --stats of this command): average duration of "
                                "the srf_kernel / srf_u16_ring_kernel row; HIP-event brackets add ~10 us of record overhead per launch",
                 "step_frac_of_peak": round(ntl * cube_bytes * args.steps / dt_max / 1e9 / HBM_PEAK_GBS, 4),
                 "total_fraction": round(ntl * full_bytes * args.steps / dt_max / 1e9 / HBM_PEAK_GBS, 4),
                 "total_bytes_per_step": ntl * full_bytes}
-        tf = os.path.join(ROOT, "profiles", "traffic.json")
-        if ntl == 1 and os.path.isfile(tf):       # the PMC figure is per single-tile launch
+        tf = os.path.join(ROOT, TRAFFIC_FILE)
+        if ntl == 1 and (H, W, B) == (1024, 1024, 285) and os.path.isfile(tf):       # the PMC figure is per single-tile launch of this shape
             try:
                 roof["traffic"] = json.load(open(tf)).get("srf_kernel_hbm_bytes_per_launch" if args.cube == "f32"
                                                           else "srf_u16_kernel_hbm_bytes_per_launch")
+                roof["traffic_source"] = (f"{TRAFFIC_FILE}: FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024 per launch from separate "
+                                          f"rocprofv3 --pmc passes over this command (committed file, not measured in this run)")
             except Exception:
                 pass
         if not args.no_probe:
@@ -367,31 +521,45 @@ def main():
             roof["measured_read_peak"] = round(eng.probe_read_bandwidth(1 << 30, 10, device, mode=0) / 1e9, 1)
             roof["measured_plain_read"] = round(eng.probe_read_bandwidth(1 << 30, 10, device, mode=1) / 1e9, 1)
         degraded = world > 1 and args.backend != "nccl"
+        if strong:
+            wl = (f"ONE {Hfull}x{W}x{B} EMIT-like cube + {nb} real-S2 planes split into {world} row block(s) of {H} rows, one per "
+                  f"GPU, deg-{args.deg} per-band least squares over all valid pixels of the whole cube: one global fit per step "
+                  f"(BASELINE.json configs[2] at N GPUs; SURVEY.md 8e row blocks)")
+        else:
+            wl = (f"{H}x{W}x{B} EMIT-like cube{' stored as uint16 x 10000 tiles (decode fused into K1)' if args.cube == 'u16' else ''} + {nb} real-S2 planes, "
+                  f"{ntl} tile{'s' if ntl > 1 else ''} per GPU, deg-{args.deg} per-band least squares over all valid pixels "
+                  + ("(BASELINE.json configs[2]; one tile per GPU for N>1)" if ntl == 1 else
+                     f"of all {world * ntl} tiles: ONE global fit per step (BASELINE.json configs[3]/[4] mosaic)"))
         line = {"metric": "Mpixel*bands/s fused (SRF + deg-%d per-band LSQ fit + apply)" % args.deg,
                 "value": round(value, 1), "unit": "Mpixel*bands/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": round(dt_max / args.steps * 1e3, 4),
-                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
                 "dtype": "f32" if args.cube == "f32" else "u16->f32",
                 "data": "synthetic",
-                "config": {"workload": f"{H}x{W}x{B} EMIT-like cube{' stored as uint16 x 10000 tiles (decode fused into K1)' if args.cube == 'u16' else ''} + {nb} real-S2 planes, "
-                                       f"{ntl} tile{'s' if ntl > 1 else ''} per GPU, deg-{args.deg} per-band least squares over all valid pixels "
-                                       + ("(BASELINE.json configs[2]; one tile per GPU for N>1)" if ntl == 1 else
-                                          f"of all {world * ntl} tiles: ONE global fit per step (BASELINE.json configs[3]/[4] mosaic)"),
-                           "tiles_per_gpu": ntl, "coeff_sync": (args.coeff_sync if world > 1 else "none") +
+                "world_size": world, "rccl_ranks": exchange_ranks if (args.backend == "nccl" or args.force_exchange) else None,
+                "exchange_ranks": exchange_ranks,
+                "config": {"workload": wl,
+                           "tiles_per_gpu": ntl, "rows_per_gpu": H, "coeff_sync": (args.coeff_sync if world > 1 else "none") +
                            (f" (rehearsal: one-rank RCCL {args.coeff_sync} forced)" if args.force_exchange else ""),
                            "pipeline": f"one tile deep, {args.reserve_cus} CUs reserved" if pipelined else "off",
                            "settle": {"ms": args.settle_ms, "untimed_steps": settle_steps,
                                       "note": "untimed load before the W warm-up steps: from idle a 20-step region sits in a "
                                               "power-management transient 6-10 % slower than the continuous-load state"},
                            "launches_per_step": 2 if (args.fused_fit and world == 1 and not args.force_exchange and ntl == 1) else None,
-                           "placement": {"trials_ms": plan.placement_log.get(H * W), "joint_with_inputs": input_log is not None,
+                           "placement": {"trials": plan.placement_trials, "trials_ms": plan.placement_log.get(H * W),
+                                         "joint_with_inputs": input_log is not None,
                                          "search_seconds": (input_log or {}).get("seconds"),
-                                         "note": "before the warm-up K1 is timed on a few candidate allocations, 4 GB apart, of "
-                                                 "(cube copy, target copy, output image); the fastest set is kept "
-                                                 "(profiles/r02_two_speeds.md); same bytes, bit-identical results"},
+                                         "pitch_gb": plan.placement_pitch_gb, "budget_gb": args.placement_budget_gb,
+                                         "held_gb": round(plan.placement_held_gb, 1),
+                                         "note": f"before the warm-up K1 is timed on candidate allocations, {plan.placement_pitch_gb:g} GB "
+                                                 f"apart, of (cube copy, target copy, output image); the fastest set is kept "
+                                                 f"(profiles/r02_two_speeds.md, r03_placement_mechanism.md); same bytes, bit-identical "
+                                                 f"results; line['cold'] is the step without any of this"},
                            "backend": (args.backend if world > 1 else "none") +
                            (" (rehearsal: all ranks on cuda:0)" if args.same_device else "")},
                 "roofline": roof}
+        if cold is not None:
+            line["cold"] = cold
         if degraded:
             line["degraded"] = True         # exchange over gloo (host staged): a rehearsal, not an RCCL/xGMI measurement
         if want_cpu:

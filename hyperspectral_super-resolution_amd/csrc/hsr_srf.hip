@@ -82,6 +82,7 @@ struct SrfArgs {
   uint32_t nodata;   // > 0xffff: no nodata value
 #ifdef HSR_PHASE_STAMPS
   unsigned long long* stamps;
+  unsigned long long* stamps2;   // [grid][4]: REFCLK (100 MHz) at workgroup entry and exit, XCC id, HW_ID
 #endif
 };
 
@@ -89,6 +90,12 @@ struct SrfArgs {
 // Diagnostic build only (tools/k1_lab): per-phase s_memtime stamps, written to a buffer nothing else
 // reads.  Never compiled into libhsr_mi355x.so.
 unsigned long long* g_stamp_buffer = nullptr;
+unsigned long long* g_stamp_buffer2 = nullptr;
+__device__ __forceinline__ unsigned long long real_time() {   // constant 100 MHz counter, the same on every XCD
+  unsigned long long t;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
 __device__ __forceinline__ unsigned long long phase_stamp() {
   unsigned long long t;
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
@@ -167,18 +174,22 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-// Loads the compiler's waitcnt pass does not see (see load_targets in the kernel): the caller must wait
-// (s_waitcnt vmcnt(0)) before the first use and pin the registers behind that wait.
-__device__ __forceinline__ float load_f32_async(const float* p) {
-  float v;
-  asm volatile("global_load_dword %0, %1, off" : "=v"(v) : "v"(p) : "memory");
-  return v;
+// Fit targets (2 float32 per thread + the pixel's mask byte) travel HBM -> LDS by per-lane LDS-DMA, issued right behind
+// the group's own DMA and read back with ordinary ds_reads after the group barrier.  Round 1/2 loaded them with inline-asm
+// global_load_dword / _ubyte (invisible to hipcc's waitcnt pass, which otherwise drains vmcnt(0) between ordinary loads
+// and LDS-DMA: +20 us on the kernel) and retired them with a hand-written s_waitcnt - correct only as long as the
+// compiler placed no copy or spill of the "=v" result between the load and the wait (one such copy was seen: a masked
+// tile's moments changed from launch to launch).  An LDS-DMA has no destination register, the compiler itself orders the
+// ds_reads behind it, and there is nothing left to inspect per compiler version.  Lane i's dword lands at stage + 4 i;
+// a byte load lands zero-extended in the same dword slot.
+__device__ __forceinline__ void stage_f32(const float* p, float* stage_wave_uniform) {
+  __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)stage_wave_uniform, 4, 0, 0);
 }
-__device__ __forceinline__ uint32_t load_u8_async(const uint8_t* p) {
-  uint32_t v;
-  asm volatile("global_load_ubyte %0, %1, off" : "=v"(v) : "v"(p) : "memory");
-  return v;
+__device__ __forceinline__ void stage_u8(const uint8_t* p, uint32_t* stage_wave_uniform) {
+  __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)stage_wave_uniform, 1, 0, 0);
 }
+constexpr int kTargetStageBytesPerBand = 64 * 4;   // ystage[band][64 lanes]; + 64 dwords for the mask bytes
+__host__ __device__ constexpr size_t target_stage_bytes(int nb) { return (size_t)nb * kTargetStageBytesPerBand + 64 * 4; }
 
 // ---- batch launches: the record of a workgroup's NEXT unit travels HBM -> LDS by a 64-byte LDS-DMA issued by 16
 // lanes of wave 0 right behind the group's own DMA: no destination register (an inline-asm load into a VGPR that is
@@ -442,10 +453,16 @@ __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
   const float* wl = reinterpret_cast<const float*>(flags + 64 + (BATCH ? 16 : 0));  // 16-byte aligned
   float* ostage = const_cast<float*>(wl) + (WLDS ? a.wtaps : 0);  // [P][out_ps] output slab (OUTV only)
   const int ops = (int)a.out_ps;
+  static_assert(P == 64, "one pixel per lane: the target stage is indexed by lane");
+  float* ystage = ostage + (OUTV ? P * ops : 0);                  // [nb][64] fit targets of the group (DEG > 0)
+  uint32_t* mstage = reinterpret_cast<uint32_t*>(ystage + a.nb * 64);   // [64] mask bytes, one dword slot per lane
   float* prev_out = nullptr;
   int64_t prev_pix0 = 0;
   int prev_npx = 0;
 
+#ifdef HSR_PHASE_STAMPS
+  const unsigned long long rt_begin = real_time();
+#endif
   const int t = threadIdx.x;
   const int lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -510,36 +527,24 @@ __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
     const float* src = reinterpret_cast<const float*>(cu.cube_dev) + pix0 * B;
     const bool pvalid = pl < npx;
 
-    // operands of the fused fit (2 target values + 1 mask byte per thread).  hipcc drains vmcnt to 0
-    // whenever ordinary VGPR loads and LDS-DMA mix (before the DMA issue if the loads come first, before
-    // the loads if they come second), which exposed one extra HBM round trip per group (+20 us on the
-    // kernel).  So these loads are issued from inline asm, invisible to the waitcnt pass, right after the
-    // DMA; they retire under the same wait as the group (explicit vmcnt(0) after the barrier) and the
-    // registers are pinned there so that no use can be scheduled ahead of it.
+    // operands of the fused fit (2 target values + 1 mask byte per thread): staged in LDS by per-lane LDS-DMA right
+    // after the group's DMA (stage_f32 / stage_u8 above), read after the group barrier
     float yv[kBandSlots];
     uint32_t mraw = 1u;
     auto load_targets = [&]() {
       if (DEG > 0) {
         const int64_t pc = pvalid ? pix0 + pl : cu.npix - 1;   // clamped: always a valid address, no branch
 #pragma unroll
-        for (int j = 0; j < kBandSlots; ++j) {
-          const int bb = bidx[j];
-          yv[j] = load_f32_async(cu.real_dev + bb * a.real_bs + pc * a.real_ps);
-        }
-        // Batch launches: the mask comes and goes from unit to unit.  An inline-asm load under a condition that
-        // changes inside the loop is merged with the default value by a register copy the compiler may place BEFORE the
-        // data has landed (seen: a masked tile's moments changed from launch to launch).  So the byte is loaded
-        // unconditionally - from any valid address when there is no mask - and selected after the wait.
-        if (BATCH) mraw = load_u8_async(cu.mask_dev != nullptr ? cu.mask_dev + pc : reinterpret_cast<const uint8_t*>(cu.real_dev));
-        else if (cu.mask_dev != nullptr) mraw = load_u8_async(cu.mask_dev + pc);
+        for (int j = 0; j < kBandSlots; ++j)
+          if (bval[j]) stage_f32(cu.real_dev + bidx[j] * a.real_bs + pc * a.real_ps, ystage + bidx[j] * 64);
+        if (cu.mask_dev != nullptr && wave == NW - 1) stage_u8(cu.mask_dev + pc, mstage);   // same pixels in every wave
       }
     };
-    auto wait_targets = [&]() {
+    auto wait_targets = [&]() {      // behind the group barrier: every wave's DMA has landed
       if (DEG > 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        static_assert(kBandSlots == 2, "pin list below");
-        asm volatile("" : "+v"(yv[0]), "+v"(yv[1]), "+v"(mraw));
-        if (BATCH && cu.mask_dev == nullptr) mraw = 1u;
+#pragma unroll
+        for (int j = 0; j < kBandSlots; ++j) yv[j] = bval[j] ? ystage[bidx[j] * 64 + lane] : 0.0f;
+        mraw = cu.mask_dev != nullptr ? (mstage[lane] & 0xffu) : 1u;
       }
     };
     // everything that fills the wait for the DMA: targets, the next unit record, the previous group's output slab,
@@ -732,6 +737,15 @@ __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
   if (DEG > 0 && pend) flush_moments<M, P, true, !BATCH>(acc_m, bval, bidx, pend_part, lane);
   if constexpr (DEG > 0 && !BATCH)
     if (a.fit.tickets) fused_fit<DEG>(a.fit, a.one.part_dev, a.one.slots, a.nb, smem, t);
+#ifdef HSR_PHASE_STAMPS
+  if (a.stamps2 && t == 0) {
+    uint32_t xcc, hw;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+    unsigned long long* o = a.stamps2 + (size_t)blockIdx.x * 4;
+    o[0] = rt_begin; o[1] = real_time(); o[2] = xcc; o[3] = hw;
+  }
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -873,6 +887,8 @@ __global__ __launch_bounds__(512, 4) void srf_u16_kernel(const SrfArgs a) {
   const bool wlds = a.wtaps > 0;
   float* ostage = const_cast<float*>(wl) + a.wtaps;
   const int ops = (int)a.out_ps;
+  float* ystage = ostage + (OUTV ? P * ops : 0);                  // [nb][64] fit targets of the group (DEG > 0)
+  uint32_t* mstage = reinterpret_cast<uint32_t*>(ystage + a.nb * 64);
   float* prev_out = nullptr;
   int64_t prev_pix0 = 0;
   int prev_npx = 0;
@@ -935,24 +951,23 @@ __global__ __launch_bounds__(512, 4) void srf_u16_kernel(const SrfArgs a) {
     const bool pvalid = pl < npx;
     const int nchunk = (npx * B + 7) >> 3;  // 16-byte chunks (8 samples) holding the group
 
-    // targets of the fused fit: inline-asm loads right after the DMA (see srf_kernel for why)
+    // targets of the fused fit: per-lane LDS-DMA right after the group's DMA (see srf_kernel)
     float yv[kBandSlots];
     uint32_t mraw = 1u;
     auto load_targets = [&]() {
       if (DEG > 0) {
         const int64_t pc = pvalid ? pix0 + pl : cu.npix - 1;
 #pragma unroll
-        for (int j = 0; j < kBandSlots; ++j) yv[j] = load_f32_async(cu.real_dev + bidx[j] * a.real_bs + pc * a.real_ps);
-        if (BATCH) mraw = load_u8_async(cu.mask_dev != nullptr ? cu.mask_dev + pc : reinterpret_cast<const uint8_t*>(cu.real_dev));
-        else if (cu.mask_dev != nullptr) mraw = load_u8_async(cu.mask_dev + pc);     // see srf_kernel
+        for (int j = 0; j < kBandSlots; ++j)
+          if (bval[j]) stage_f32(cu.real_dev + bidx[j] * a.real_bs + pc * a.real_ps, ystage + bidx[j] * 64);
+        if (cu.mask_dev != nullptr && wave == 7) stage_u8(cu.mask_dev + pc, mstage);   // every wave maps lanes to pixels alike
       }
     };
     auto wait_targets = [&]() {
       if (DEG > 0) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        static_assert(kBandSlots == 2, "pin list below");
-        asm volatile("" : "+v"(yv[0]), "+v"(yv[1]), "+v"(mraw));
-        if (BATCH && cu.mask_dev == nullptr) mraw = 1u;
+#pragma unroll
+        for (int j = 0; j < kBandSlots; ++j) yv[j] = bval[j] ? ystage[bidx[j] * 64 + lane] : 0.0f;
+        mraw = cu.mask_dev != nullptr ? (mstage[lane] & 0xffu) : 1u;
       }
     };
     auto behind_the_dma = [&]() {
@@ -1325,7 +1340,8 @@ static int launch_srf_u16_ring(const SrfArgs& a, int grid, hipStream_t stream) {
 
 template <int DEG, bool FAST, bool OUTV, bool BATCH>
 static int launch_srf_u16(const SrfArgs& a, int grid, hipStream_t stream) {
-  const size_t lds = (size_t)64 * a.B * 2 + 64 * sizeof(uint32_t) + (size_t)a.wtaps * 4 + (OUTV ? (size_t)64 * a.out_ps * 4 : 0);
+  const size_t lds = (size_t)64 * a.B * 2 + (64 + (BATCH ? 16 : 0)) * sizeof(uint32_t) + (size_t)a.wtaps * 4 +
+                     (OUTV ? (size_t)64 * a.out_ps * 4 : 0) + (DEG > 0 ? target_stage_bytes(a.nb) : 0);
   auto kern = srf_u16_kernel<DEG, FAST, OUTV, BATCH>;
   static thread_local size_t configured = 0;
   ensure_dynamic_lds(kern, lds, &configured);
@@ -1369,13 +1385,14 @@ static int dispatch_u16(const SrfArgs& a, int deg, bool fast, bool ring, int gri
 
 template <int DEG, bool FAST, bool WLDS, int P, bool OUTV, bool BATCH>
 static int launch_srf(const SrfArgs& a, int grid, hipStream_t stream) {
-  const size_t lds = (size_t)P * a.ldsB * 4 + 64 * sizeof(uint32_t) + (WLDS ? (size_t)a.wtaps * 4 : 0) +
-                     (OUTV ? (size_t)P * a.out_ps * 4 : 0);
+  const size_t lds = (size_t)P * a.ldsB * 4 + (64 + (BATCH ? 16 : 0)) * sizeof(uint32_t) + (WLDS ? (size_t)a.wtaps * 4 : 0) +
+                     (OUTV ? (size_t)P * a.out_ps * 4 : 0) + (DEG > 0 ? target_stage_bytes(a.nb) : 0);
   auto kern = srf_kernel<DEG, FAST, WLDS, P, OUTV, BATCH>;
   static thread_local size_t configured = 0;
   ensure_dynamic_lds(kern, lds, &configured);
 #ifdef HSR_PHASE_STAMPS
   const_cast<SrfArgs&>(a).stamps = g_stamp_buffer;
+  const_cast<SrfArgs&>(a).stamps2 = g_stamp_buffer2;
 #endif
   hipLaunchKernelGGL(kern, dim3(grid), dim3(8 * P), lds, stream, a);
   HSR_LAUNCH_CHECK("srf_kernel");
@@ -1511,7 +1528,6 @@ static int srf_common(SrfArgs& a, const int32_t* k0, const int32_t* klen, int32_
   if (a.wtaps == 0) P = 64;  // the generic fallback kernel exists for 64-pixel groups only
   a.one.ngroups = (int32_t)((a.one.npix + P - 1) / P);
   a.one.slots = srf_slots(a.one.npix, P, tn.reserved_cus);
-  if (!a.u16 && a.wtaps == 0) a.one.slots = a.one.ngroups < 512 ? a.one.ngroups : 512;
   a.one.slot = 0;
   a.nunits = a.one.slots;
   const bool aligned = (((uintptr_t)a.one.cube_dev) & 15) == 0;

@@ -358,26 +358,47 @@ def srf_integrate_moments(cube, table: SrfTable, real, deg: int, ws: MomentWorks
 PLACEMENT_PITCH_GB = 16.0
 
 
-def placement_search(first, make, probe, trials: int, pitch_gb: float, device):
+_placement_logged = False
+
+
+def placement_search(first, make, probe, trials: int, pitch_gb: float, device, budget_gb: Optional[float] = None,
+                     candidate_bytes: int = 0, stats: Optional[dict] = None):
     """Where a buffer lies in device memory changes K1's speed by ~9 % (profiles/r02_two_speeds.md: a map of 28
     candidate sets per process shows stretches of 15-25 GB where K1 runs at 0.192-0.204 ms between stretches of 20-70 GB
-    where it runs at 0.208-0.227 ms; the speed is a stable property of the allocation, and of the cube's above all).
+    where it runs at 0.208-0.227 ms; the speed is a stable property of the allocation; profiles/r03_placement_mechanism.md:
+    not address translation, not the allocator - no allocation recipe avoids the slow class, so the only lever is to look).
     This times ``probe(candidate)`` - one K1 launch - on ``first`` and on up to ``trials - 1`` candidates from
     ``make()``, one every ``pitch_gb`` GB (a spacer allocation between candidates, held until the end so that the next
     one lands in another stretch), one untimed and two timed launches each, and returns (fastest candidate, times in ms).
     Every candidate is timed - the slow class is wide (0.208-0.235 ms) and an early exit on "both speeds seen" stopped
-    inside it.  Same bytes whichever candidate is kept, so results do not change."""
+    inside it.  Same bytes whichever candidate is kept, so results do not change.
+
+    MEMORY.  Every extra candidate pins ``pitch_gb`` GB of spacer plus ``candidate_bytes`` until the search ends, and all of
+    it stays in torch's caching allocator afterwards (SpectralFusion.release_search_memory()).  The search is therefore
+    BOUNDED: it never holds more than ``budget_gb`` GB (default: half of the device memory free when it starts), it asks
+    torch.cuda.mem_get_info before every allocation instead of running into an out-of-memory error (whose handling
+    makes torch flush and retry its cache), and it stops at the first candidate that does not fit.  ``stats`` (a dict)
+    receives what was held.  The first search of a process is logged once on the "s2_emit" logger."""
+    global _placement_logged
     torch = nat.require_gpu()
     stream = torch.cuda.current_stream(device)
     cands, spacers, times = [first], [], []
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    free0, _total = torch.cuda.mem_get_info(device)
+    budget = 0.5 * free0 if budget_gb is None else min(float(budget_gb) * (1 << 30), float(free0))
+    per_trial = int(pitch_gb * (1 << 30)) + int(candidate_bytes)
+    held = 0
     for i in range(max(1, trials)):
         if i > 0:
+            free, _ = torch.cuda.mem_get_info(device)
+            if held + per_trial > budget or per_trial + (1 << 30) > free:        # would exceed the budget / leave < 1 GB free
+                break
             try:
                 spacers.append(torch.empty(int(pitch_gb * (1 << 30)), dtype=torch.uint8, device=device))
                 cands.append(make())
-            except RuntimeError:          # out of memory: settle for what has been seen
+            except RuntimeError:          # out of memory after all (another process allocated meanwhile)
                 break
+            held += per_trial
         c = cands[-1]
         probe(c)                           # untimed: first touch of the candidate
         t = []
@@ -390,6 +411,16 @@ def placement_search(first, make, probe, trials: int, pitch_gb: float, device):
         times.append(min(t))
     best = min(range(len(times)), key=times.__getitem__)
     keep = cands[best]
+    if stats is not None:
+        stats["held_gb"] = stats.get("held_gb", 0.0) + held / (1 << 30)
+        stats["budget_gb"] = budget / (1 << 30)
+    if not _placement_logged and len(times) > 1:
+        _placement_logged = True
+        import logging
+        logging.getLogger("s2_emit").info(
+            "placement search: %d candidate allocations timed (%.4f - %.4f ms), %.1f GB of spacers and losing candidates left "
+            "in torch's caching allocator (budget %.1f GB; SpectralFusion.release_search_memory() returns them to the driver)",
+            len(times), min(times), max(times), held / (1 << 30), budget / (1 << 30))
     # The spacers and the losing candidates go back to torch's caching allocator, NOT to the driver: releasing them
     # (torch.cuda.empty_cache()) right after the search was measured to cost K1 0.2-3 % again (0.2016-0.2077 ms against
     # 0.2000-0.2007 ms over three fresh processes each) - unmapping ~190 GB next to the kept buffers is not neutral.
@@ -493,7 +524,7 @@ class TileBatch:
         self.units_dev = torch.frombuffer(bytearray(bytes(units)), dtype=torch.uint8).to(dev)
         self.slots = [int(tiles[i].slots) for i in range(T)]
 
-    def place(self, probe, trials: int, pitch_gb: float = PLACEMENT_PITCH_GB):
+    def place(self, probe, trials: int, pitch_gb: float = PLACEMENT_PITCH_GB, budget_gb: Optional[float] = None, stats=None):
         """Placement trials for the batch's output image (placement_search): ``probe(self)`` enqueues one batched K1
         launch; candidates are fresh allocations of the output image; the fastest is kept."""
         torch = nat.require_gpu()
@@ -504,7 +535,8 @@ class TileBatch:
             if cand is not self.pseudo:
                 self._build(cand)
             probe(self)
-        keep, times = placement_search(self.pseudo, lambda: torch.empty_like(self.pseudo), run, trials, pitch_gb, self.device)
+        keep, times = placement_search(self.pseudo, lambda: torch.empty_like(self.pseudo), run, trials, pitch_gb, self.device,
+                                       budget_gb, self.pseudo.numel() * 4, stats)
         if keep is not self.pseudo:
             self._build(keep)
         self.placement_log = times

@@ -18,21 +18,22 @@ import numpy as np
 from . import _native as nat
 
 
+def _finite_rows(image, mask):
+    rows = np.asarray(image)[mask].reshape(-1, 3).astype(np.float64)
+    return rows[np.isfinite(rows).all(axis=1)]
+
+
 def sample_pairs(src_rgb, ref_rgb, mask, n_samples, seed, min_rows):
-    """Rows inside the mask, non-finite rows dropped for X and Y independently, then
-    ``default_rng(seed).choice(..., replace=False)`` for X then Y (poly_regression.py:31-47)."""
-    rng = np.random.default_rng(seed)
-    X_all = np.asarray(src_rgb)[mask].reshape(-1, 3).astype(np.float64)
-    Y_all = np.asarray(ref_rgb)[mask].reshape(-1, 3).astype(np.float64)
-    X_all = X_all[np.isfinite(X_all).all(axis=1)]
-    Y_all = Y_all[np.isfinite(Y_all).all(axis=1)]
-    if X_all.shape[0] < min_rows or Y_all.shape[0] < min_rows:
+    """Source and reference sample rows for the OT fit, or None when either side has fewer than ``min_rows`` usable rows.
+    Contract (poly_regression.py:31-47): rows inside the mask; rows with a non-finite channel dropped for the two images
+    independently; ONE ``default_rng(seed)`` generator draws without replacement first the source rows, then the
+    reference rows - that order is what makes the draw reproduce the reference's PCG64 stream."""
+    pools = [_finite_rows(src_rgb, mask), _finite_rows(ref_rgb, mask)]
+    if min(len(p) for p in pools) < min_rows:
         return None
-    ns = min(n_samples, X_all.shape[0])
-    nt = min(n_samples, Y_all.shape[0])
-    X = X_all[rng.choice(X_all.shape[0], size=ns, replace=False)]
-    Y = Y_all[rng.choice(Y_all.shape[0], size=nt, replace=False)]
-    return X, Y
+    gen = np.random.default_rng(seed)
+    picked = [p[gen.choice(len(p), size=min(n_samples, len(p)), replace=False)] for p in pools]    # source first
+    return picked[0], picked[1]
 
 
 def sample_pairs_device(src, ref, mask, n_samples, seed, min_rows):

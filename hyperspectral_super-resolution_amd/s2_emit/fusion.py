@@ -26,6 +26,12 @@ from . import _native as nat
 COEFF_SYNC_MODES = ("local", "allreduce", "broadcast")
 
 
+def _tkey(t):
+    """Identity of a tensor's storage view for the batch-plan cache: a reinterpreted view (view(dtype)), another stride or
+    another device at the same address and shape is a different key."""
+    return (t.data_ptr(), tuple(t.shape), tuple(t.stride()), str(t.dtype), str(t.device))
+
+
 @dataclass
 class FusionOutput:
     names: List[str]           # supported bands, srf_dict order
@@ -101,8 +107,16 @@ class SpectralFusion:
                  group=None, coeff_sync: str = "allreduce", layout: str = nat.PIXMAJOR,
                  force_exchange: bool = False, tile_scale=None, tile_nodata: Optional[int] = eng.TILE_NODATA,
                  reserved_cus: Optional[int] = None, tile_pixels: int = 0, u16_single_buffer: bool = False,
-                 u16_fast: bool = False, placement_trials: int = 12, fused_fit: bool = False,
-                 placement_pitch_gb: float = eng.PLACEMENT_PITCH_GB):
+                 u16_fast: bool = False, placement_trials: int = 0, fused_fit: bool = False,
+                 placement_pitch_gb: float = eng.PLACEMENT_PITCH_GB, placement_budget_gb: Optional[float] = None):
+        """``placement_trials`` (default 0 = OFF: the plan allocates once and never synchronises with the host): opt in to
+        the placement search of eng.placement_search for tiles of >= 65 536 pixels - up to min(4, trials) candidate output
+        images on the first step()/submit()/step_batch() over a tile size, up to ``trials`` candidate (cube, target, image)
+        sets in place_inputs().  Each extra candidate pins ``placement_pitch_gb`` GB of spacer (+ the candidate) while the
+        search runs, and the memory stays in torch's caching allocator afterwards (release_search_memory()); the search
+        never holds more than ``placement_budget_gb`` GB (default: half of the device memory that is free when it starts)
+        and skips candidates that do not fit - on a GPU shared with other allocators pass a small budget or leave it off.
+        ``placement_held_gb`` records what the searches of this plan held."""
         torch = nat.require_gpu()
         # decode of uint16 cubes (the reference's tile format, tiles_helpers/utils.py:362-374): x = u * tile_scale
         # (default float32(1e-4)), u == tile_nodata -> NaN (None: no nodata value).  Ignored for float32 cubes.
@@ -138,11 +152,13 @@ class SpectralFusion:
         # and the target a little (3 %).  A property of the allocation, stable for its life.  The plan places what it owns:
         # on the first step over a tile size it times K1 on up to min(4, placement_trials) candidate output images,
         # `placement_pitch_gb` apart; place_inputs() searches jointly over copies of a resident tile's inputs (up to
-        # `placement_trials` sets).  Results are bit-identical whichever is kept; 0 / 1 = first allocation, no
-        # host synchronisation.
+        # `placement_trials` sets).  Results are bit-identical whichever is kept; 0 / 1 (the default) = first allocation,
+        # no host synchronisation, no extra memory.  Opt-in and bounded by placement_budget_gb (see the docstring).
         self.placement_trials = max(0, int(placement_trials))
         self.placement_pitch_gb = float(placement_pitch_gb)
+        self.placement_budget_gb = None if placement_budget_gb is None else float(placement_budget_gb)
         self.placement_log: Dict[int, list] = {}
+        self._placement_stats: Dict[str, float] = {}
         # fused_fit: step() without an exchange lets the slot reduction and the solve ride in K1's launch
         # (hsr_srf_integrate_fit: the last workgroups to finish reduce and solve) - two launches per step instead of
         # three, same bits.  Off by default: measured on MI355X the tail costs K1 +13 us (six dependent round trips
@@ -171,15 +187,28 @@ class SpectralFusion:
             self._buf[npix] = (pseudo, eng.alloc_image(torch, nb, npix, self.layout, self.device))
         return self._buf[npix]
 
-    def _trials(self, first, make, probe, cap=None):
-        n = self.placement_trials if cap is None else min(cap, self.placement_trials)
-        return eng.placement_search(first, make, probe, n, self.placement_pitch_gb, self.device)
+    @property
+    def placement_held_gb(self) -> float:
+        """GB of spacers and losing candidates this plan's searches left in torch's caching allocator."""
+        return float(self._placement_stats.get("held_gb", 0.0))
 
-    def _place(self, npix: int, first, probe):
+    def _trials(self, first, make, probe, cap=None, candidate_bytes: int = 0):
+        n = self.placement_trials if cap is None else min(cap, self.placement_trials)
+        return eng.placement_search(first, make, probe, n, self.placement_pitch_gb, self.device, self.placement_budget_gb,
+                                    candidate_bytes, self._placement_stats)
+
+    def _place(self, npix: int, first, probe, count: int = 1):
         """Time K1 on candidate output images and keep the fastest (the output's share of the effect is ~3 %: four
-        candidates at most)."""
+        candidates at most).  ``count`` > 1: a candidate is ``count`` images allocated back to back (the two slots of the
+        submit() pipeline are searched ONCE, together); ``first`` is then a list and a list is returned."""
         torch = nat.require_gpu()
-        keep, times = self._trials(first, lambda: eng.alloc_image(torch, self.table.nb, npix, self.layout, self.device), probe, cap=4)
+        nb = self.table.nb
+        one = lambda: eng.alloc_image(torch, nb, npix, self.layout, self.device)
+        if count == 1:
+            keep, times = self._trials(first, one, probe, cap=4, candidate_bytes=first.numel() * 4)
+        else:
+            keep, times = self._trials(list(first), lambda: [one() for _ in range(count)], lambda c: probe(c[0]), cap=4,
+                                       candidate_bytes=count * first[0].numel() * 4)
         self.placement_log[npix] = times
         return keep
 
@@ -213,7 +242,8 @@ class SpectralFusion:
                                       reduce=False, layout=self.layout, real_layout=rl, scale=self.tile_scale,
                                       nodata=self.tile_nodata, opts=self.opts)
         first = (cube, real, images())
-        (cube, real, outs), times = self._trials(first, make, k1)
+        cand_bytes = cube.numel() * cube.element_size() + real.numel() * 4 + 3 * npix * eng.padded_row(nb) * 4
+        (cube, real, outs), times = self._trials(first, make, k1, candidate_bytes=cand_bytes)
         self._buf[npix] = (outs[0], eng.alloc_image(torch, nb, npix, self.layout, self.device))
         self._pipe_images[npix] = outs[1:]
         self.placement_log[npix] = times
@@ -294,7 +324,7 @@ class SpectralFusion:
         # host time than the three launches take on the GPU)
         stack_key = None
         if masks is None and hasattr(cubes, "dim") and hasattr(reals, "dim") and cubes.dim() == 4 and reals.dim() == 4:
-            stack_key = ("stack", cubes.data_ptr(), tuple(cubes.shape), reals.data_ptr(), tuple(reals.shape))
+            stack_key = ("stack", _tkey(cubes), _tkey(reals))
             tb = self._batches.get(stack_key)
             if tb is not None:
                 eng.batch_srf_integrate_moments(tb, self.min_valid, self.min_valid, self.tile_scale, self.tile_nodata,
@@ -308,15 +338,14 @@ class SpectralFusion:
             reals = [reals[i] for i in range(reals.shape[0])] if reals.dim() == 4 else [reals]
         cubes, reals = list(cubes), list(reals)
         masks = list(masks) if masks is not None else [None] * len(cubes)
-        key = tuple((c.data_ptr(), tuple(c.shape), r.data_ptr(), tuple(r.shape), 0 if m is None else m.data_ptr())
-                    for c, r, m in zip(cubes, reals, masks))
+        key = tuple((_tkey(c), _tkey(r), None if m is None else _tkey(m)) for c, r, m in zip(cubes, reals, masks))
         tb = self._batches.get(key)
         if tb is None:
             if len(self._batches) >= 8:           # a few live batch plans at most (stacked inputs hold two keys)
                 self._batches.pop(next(iter(self._batches)))
             tb = eng.TileBatch(cubes, reals, masks, self.table, self.deg, self.opts)
             tb.place(lambda b: eng.batch_srf_integrate_moments(b, self.min_valid, self.min_valid, self.tile_scale, self.tile_nodata),
-                     self.placement_trials, self.placement_pitch_gb)
+                     self.placement_trials, self.placement_pitch_gb, self.placement_budget_gb, self._placement_stats)
             self._batches[key] = tb
         if stack_key is not None:
             self._batches[stack_key] = tb              # same batch, found without slicing next time
@@ -325,6 +354,12 @@ class SpectralFusion:
         eng.batch_reduce_solve(tb, self.min_count)
         eng.batch_poly_apply(tb, use_mask=self.apply_mask, clip=self.clip)
         return BatchOutput(self.names, tb)
+
+    def clear_batches(self):
+        """Drop the cached batch plans of step_batch() / fuse_mosaic(resident=True).  A cached plan holds the device tables
+        of its tiles AND references to the caller's tensors (the tables store raw pointers); the cache is keyed by each
+        tensor's address, shape, strides, dtype and device and keeps at most 8 plans."""
+        self._batches.clear()
 
     @staticmethod
     def release_search_memory():
@@ -349,11 +384,13 @@ class SpectralFusion:
 
         def k1(cand):
             eng.batch_srf_integrate_moments(cand[2], self.min_valid, self.min_valid, self.tile_scale, self.tile_nodata)
-        (cubes, reals, tb), times = self._trials(build(cubes, reals), lambda: build(cubes.clone(), reals.clone()), k1)
+        cand_bytes = cubes.numel() * cubes.element_size() + reals.numel() * 4
+        (cubes, reals, tb), times = self._trials(build(cubes, reals), lambda: build(cubes.clone(), reals.clone()), k1,
+                                                 candidate_bytes=cand_bytes)
         tb.placement_log = times
         if len(self._batches) >= 8:
             self._batches.pop(next(iter(self._batches)))
-        self._batches[("stack", cubes.data_ptr(), tuple(cubes.shape), reals.data_ptr(), tuple(reals.shape))] = tb
+        self._batches[("stack", _tkey(cubes), _tkey(reals))] = tb
         return cubes, reals, {"joint_ms": times}
 
     # ---- one fit over several tiles on one GPU --------------------------------------------------------
@@ -405,8 +442,7 @@ class SpectralFusion:
     def _fuse_mosaic_batched(self, tiles, masks, k1_events):
         torch = nat.require_gpu()
         cubes, reals = [c for c, _ in tiles], [r for _, r in tiles]
-        key = ("mosaic",) + tuple((c.data_ptr(), tuple(c.shape), r.data_ptr(), tuple(r.shape), 0 if m is None else m.data_ptr())
-                                  for c, r, m in zip(cubes, reals, masks))
+        key = ("mosaic",) + tuple((_tkey(c), _tkey(r), None if m is None else _tkey(m)) for c, r, m in zip(cubes, reals, masks))
         tb = self._batches.get(key)
         if tb is None:
             if len(self._batches) >= 4:
@@ -568,14 +604,13 @@ class SpectralFusion:
         if self._pipe is None or self._pipe["npix"] != npix:
             nb = self.table.nb
             slots = []
-            placed = self._pipe_images.pop(npix, [])
+            placed = self._pipe_images.pop(npix, [])         # placed together with the resident inputs (place_inputs)
+            if len(placed) < 2:
+                placed = [eng.alloc_image(torch, nb, npix, self.layout, self.device) for _ in range(2)]
+                if probe is not None and self.placement_trials > 1 and npix >= (1 << 16):
+                    placed = self._place(npix, placed, probe, count=2)     # ONE search for both slots' images
             for k in range(2):
-                if k < len(placed):                  # placed together with the resident inputs (place_inputs)
-                    pseudo = placed[k]
-                else:
-                    pseudo = eng.alloc_image(torch, nb, npix, self.layout, self.device)
-                    if probe is not None and self.placement_trials > 1 and npix >= (1 << 16):
-                        pseudo = self._place(npix, pseudo, probe)
+                pseudo = placed[k]
                 slots.append(dict(pseudo=pseudo,
                                   matched=eng.alloc_image(torch, nb, npix, self.layout, self.device),
                                   ws=eng.MomentWorkspace(self.device, nb, self.deg), mask=None,

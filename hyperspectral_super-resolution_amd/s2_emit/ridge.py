@@ -226,6 +226,32 @@ class PolyRidge:
             dist.all_reduce(G, op=dist.ReduceOp.SUM, group=group)
         return self.solve_gram(G, mean, scale, Xd.shape[1], Yd.shape[1])
 
+    @classmethod
+    def from_params(cls, mean, scale, coef, intercept, degree: int = 3, alpha: float = 1.0):
+        """A model from given parameters - e.g. a scikit-learn pipeline fitted elsewhere (``scaler.mean_``, ``scaler.scale_``,
+        ``ridge.coef_`` (T, n_features), ``ridge.intercept_``) - ready for predict() / predict_cube() on the GPU."""
+        torch = nat.require_gpu()
+        lib = nat.load()
+        mean = np.ascontiguousarray(mean, dtype=np.float64).reshape(-1)
+        scale = np.ascontiguousarray(scale, dtype=np.float64).reshape(-1)
+        coef = np.atleast_2d(np.asarray(coef, dtype=np.float64))
+        b = np.ascontiguousarray(intercept, dtype=np.float64).reshape(-1)
+        n_in, T = mean.shape[0], coef.shape[0]
+        nf = lib.hsr_polyfeat_count(n_in, int(degree))
+        if nf <= 0 or coef.shape[1] != nf or scale.shape[0] != n_in or b.shape[0] != T:
+            raise ValueError(f"parameters do not describe a degree-{degree} model of {n_in} inputs: coef {coef.shape}, "
+                             f"expected ({T}, {nf})")
+        m = cls(degree, alpha)
+        kpad = (nf + 1) // 2 * 2
+        W = np.zeros((kpad, T), dtype=np.float32)
+        W[:nf] = coef.T
+        dev = torch.device("cuda", torch.cuda.current_device())
+        to = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a)).to(dev, dt)
+        m.n_in, m.n_feat, m.n_targets = n_in, nf, T
+        m._fit64 = (to(mean, torch.float64), to(scale, torch.float64), to(coef.T, torch.float64), to(b, torch.float64))
+        m._dev = dict(W=to(W, torch.float32), b=to(b, torch.float32), mean=to(mean, torch.float32), inv=to(1.0 / scale, torch.float32))
+        return m
+
     # ---- predict ------------------------------------------------------------------------------------
     def _predict_dev(self, x, x_ps: int, x_cs: int, npix: int, activation: int, nan_bad: bool = False, nodata=None):
         torch = nat.require_gpu()

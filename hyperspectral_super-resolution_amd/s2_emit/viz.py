@@ -34,9 +34,12 @@ def resize_s2_rgb_to(s2_rgb: np.ndarray, target_hw: Tuple[int, int]) -> np.ndarr
 
 
 def show_side_by_side(left: np.ndarray, right: np.ndarray, left_title: str, right_title: str, figsize=(12, 5)):
+    """Two images next to each other without axes (display helper; same signature as the reference's)."""
     import matplotlib.pyplot as plt
-    plt.figure(figsize=figsize)
-    plt.subplot(1, 2, 1); plt.imshow(left); plt.title(left_title); plt.axis("off")
-    plt.subplot(1, 2, 2); plt.imshow(right); plt.title(right_title); plt.axis("off")
-    plt.tight_layout()
+    fig, axes = plt.subplots(1, 2, figsize=figsize)
+    for ax, image, title in zip(axes, (left, right), (left_title, right_title)):
+        ax.imshow(image)
+        ax.set_title(title)
+        ax.set_axis_off()
+    fig.tight_layout()
     plt.show()

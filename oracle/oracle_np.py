@@ -416,12 +416,20 @@ def ridge_poly_predict(model, X):
     return poly_features(Z, int(model["degree"])) @ model["coef"].T + model["intercept"]
 
 
-def predict_cube_logit(model, s2_cube):
-    """Spectral_matching.ipynb raw lines 192-213: (C,H,W) -> sigmoid(model(px)) as (T,H,W) f32."""
-    C, H, W = s2_cube.shape
-    X = s2_cube.reshape(C, -1).T.astype(np.float32)
-    pred = sigmoid(ridge_poly_predict(model, X)).astype(np.float32)
-    return pred.T.reshape(-1, H, W)
+def predict_cube_logit(model, X_bhw, nodata=None):
+    """Spectral_matching.ipynb raw lines 192-213: (C,H,W) -> (T,H,W) float32 = sigmoid(float32(model(px))); pixels with a
+    non-finite input, or an input np.isclose to ``nodata``, stay NaN in every target.  (The notebook hard-codes 32 targets
+    and predicts in batches of 200 000 pixels; neither changes a value.)"""
+    C, H, W = X_bhw.shape
+    X = X_bhw.reshape(C, -1).T
+    valid = np.isfinite(X).all(axis=1)
+    if nodata is not None:
+        valid &= ~(np.isclose(X, nodata).any(axis=1))
+    T = model["coef"].shape[0]
+    Y = np.full((X.shape[0], T), np.nan, dtype=np.float32)
+    y_logit = ridge_poly_predict(model, X[valid]).astype(np.float32)
+    Y[valid] = sigmoid(y_logit).astype(np.float32)
+    return Y.T.reshape(T, H, W)
 
 
 # ---------------------------------------------------------------------------------------------

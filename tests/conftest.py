@@ -37,3 +37,17 @@ def unpack_srf(g):
 @pytest.fixture(scope="session")
 def golden():
     return load_golden
+
+
+def g11_cube(g):
+    """The 10 x 600 x 600 input cube of fixture g11 (stored as its 100 x 100 coarse cube; gen_golden.py builds it with the
+    same two statements): repeat 6 x 6, add the fixed dither, NaN / nodata at the listed positions."""
+    coarse = g["cube_coarse"]
+    C = coarse.shape[0]
+    ci, ii, jj = np.meshgrid(np.arange(C), np.arange(600), np.arange(600), indexing="ij")
+    cube = np.repeat(np.repeat(coarse, 6, axis=1), 6, axis=2).astype(np.float32) + ((7 * ii + 13 * jj + 5 * ci) % 17 - 8).astype(np.float32)
+    for c_, i_, j_ in g["cube_nan"]:
+        cube[c_, i_, j_] = np.nan
+    for c_, i_, j_ in g["cube_nd"]:
+        cube[c_, i_, j_] = g["nodata"]
+    return cube

@@ -210,6 +210,71 @@ def main():
          logit_probe=smf["logit"](np.array([-0.01, 0.0, 1e-4, 0.3, 0.9999, 1.0, 1.2])),
          subsample_285_32=smf["subsample_bands_evenly"](285, 32))
 
+    # ---- G11: the ridge pipeline at the notebook's own shapes (Spectral_matching.ipynb raw :426 "Train pixels: (10000, 10)
+    #      Targets: (10000, 32)", :634 "Pred EMIT @10m: (32, 600, 600)"), predict_cube_logit run FROM THE NOTEBOOK on the
+    #      600 x 600 cube - stored as a strided sample plus per-band checksums (the full output is 46 MB) - and a second
+    #      sklearn model with 97 targets (the many-target predict kernels, T 97-512, against sklearn itself) --------------
+    rng = np.random.default_rng(11)
+    N, C, T = 10000, 10, 32
+    base = rng.random((N, 3))
+    mix = rng.random((3, C))
+    Xdn = np.round(600 + 4600 * np.clip(base @ mix / 1.5 + 0.02 * rng.standard_normal((N, C)), 0, 1)).astype(np.uint16)
+    Wt = rng.random((3, T))
+    Yu = np.round(1e4 * np.clip(base @ Wt / 2.0 + 0.01 * rng.standard_normal((N, T)), 0.0, 0.6)).astype(np.uint16)
+    Y = Yu.astype(np.float32) * np.float32(1e-4)              # the targets in the tile format's precision (u16 x 1e-4)
+    # The notebook feeds float32 arrays, so scikit-learn runs its whole pipeline in float32 there; on this (cond ~ 1e9)
+    # system that run deviates from the float64 evaluation of the SAME pipeline by ~7e-3 in logit / 1e-3 in reflectance
+    # (stored below as f32_pipeline_dev_*).  The fixture pins the float64 evaluation, as g7 does.
+    Yl = smf["logit"](Y.astype(np.float64), eps=1e-4)
+    model = Pipeline([("scaler", StandardScaler()),
+                      ("poly", PolynomialFeatures(degree=3, include_bias=False)),
+                      ("ridge", Ridge(alpha=1.0))])
+    model.fit(Xdn.astype(np.float64), Yl)
+    model32 = Pipeline([("scaler", StandardScaler()),
+                        ("poly", PolynomialFeatures(degree=3, include_bias=False)),
+                        ("ridge", Ridge(alpha=1.0))])
+    model32.fit(Xdn.astype(np.float32), smf["logit"](Y, eps=1e-4))
+    p64_, p32_ = model.predict(Xdn[:2000].astype(np.float64)), model32.predict(Xdn[:2000].astype(np.float32)).astype(np.float64)
+    dev_logit, dev_refl = np.abs(p64_ - p32_).max(), np.abs(smf["sigmoid"](p64_) - smf["sigmoid"](p32_)).max()
+    # the 10 m cube: a 100 x 100 coarse cube repeated 6 x 6 plus a fixed dither (the test rebuilds it from `cube_coarse`
+    # with the two statements below), NaN at `cube_nan` (c, i, j) and the nodata value at `cube_nd`
+    coarse = np.round(600 + 4600 * np.clip(rng.random((100, 100, 3)) @ mix / 1.5, 0, 1)).astype(np.uint16)
+    coarse = np.ascontiguousarray(np.moveaxis(coarse, -1, 0))                       # (10, 100, 100)
+    ci, ii, jj = np.meshgrid(np.arange(C), np.arange(600), np.arange(600), indexing="ij")
+    cube = np.repeat(np.repeat(coarse, 6, axis=1), 6, axis=2).astype(np.float32) + ((7 * ii + 13 * jj + 5 * ci) % 17 - 8).astype(np.float32)
+    cube_nan = np.array([[0, 0, 0], [3, 17, 500], [9, 599, 599], [5, 300, 301]])
+    cube_nd = np.array([[1, 2, 3], [8, 400, 77], [2, 599, 0]])
+    for c_, i_, j_ in cube_nan:
+        cube[c_, i_, j_] = np.nan
+    for c_, i_, j_ in cube_nd:
+        cube[c_, i_, j_] = -9999.0
+    pred = smf["predict_cube_logit"](model, cube, nodata=-9999.0)                   # the notebook's function, (32, 600, 600) float32
+    assert pred.shape == (32, 600, 600) and pred.dtype == np.float32
+    fin = np.isfinite(pred)
+    Xtr = Xdn[:512].astype(np.float32)
+    # second model: 97 targets on 2000 of the pixels (the sliced predict kernel's range), checked on an odd pixel count
+    T2 = 97
+    Wt2 = rng.random((3, T2))
+    Y2u = np.round(1e4 * np.clip(base[:2000] @ Wt2 / 2.0 + 0.01 * rng.standard_normal((2000, T2)), 1e-3, 0.6)).astype(np.uint16)
+    Yl2 = smf["logit"]((Y2u.astype(np.float32) * np.float32(1e-4)).astype(np.float64))
+    model2 = Pipeline([("scaler", StandardScaler()),
+                       ("poly", PolynomialFeatures(degree=3, include_bias=False)),
+                       ("ridge", Ridge(alpha=1.0))])
+    model2.fit(Xdn[:2000].astype(np.float64), Yl2)
+    Xte2 = np.round(600 + 4600 * np.clip(rng.random((257, 3)) @ mix / 1.5, 0, 1)).astype(np.uint16)
+    save("g11_ridge_notebook_shapes", X=Xdn, Yu16=Yu,
+         mean=model.named_steps["scaler"].mean_, scale=model.named_steps["scaler"].scale_,
+         coef=model.named_steps["ridge"].coef_, intercept=model.named_steps["ridge"].intercept_,
+         train_pred_logit=model.predict(Xtr.astype(np.float64)[:512]),
+         cube_coarse=coarse, cube_nan=cube_nan, cube_nd=cube_nd, nodata=np.float32(-9999.0),
+         pred_sample=pred[:, ::7, ::11], pred_nan_count=np.int64((~fin).sum()),
+         pred_band_sum=np.where(fin, pred, 0).sum(axis=(1, 2), dtype=np.float64),
+         pred_band_sumsq=(np.where(fin, pred, 0).astype(np.float64) ** 2).sum(axis=(1, 2)),
+         pred_rows_299=pred[:, 299, :], f32_pipeline_dev_logit=dev_logit, f32_pipeline_dev_refl=dev_refl,
+         Y2u16=Y2u, coef2=model2.named_steps["ridge"].coef_.astype(np.float32),
+         intercept2=model2.named_steps["ridge"].intercept_, Xtest2=Xte2,
+         pred2_logit=model2.predict(Xte2.astype(np.float64)).astype(np.float32))
+
     # ---- G8: histogram matching ------------------------------------------------------------------------
     rng = np.random.default_rng(8)
     src = np.round(rng.random((16, 14, 3)) * 40) / 40

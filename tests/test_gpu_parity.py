@@ -600,6 +600,95 @@ def test_poly_ridge_many_targets_vs_oracle(torch_gpu):
                                rtol=0, atol=1e-4)
 
 
+def _a9_problem(rng, N, Cin, T):
+    base = rng.random((N, 4))
+    X = (600 + 4000 * np.clip(base @ rng.random((4, Cin)) / 2 + 0.02 * rng.standard_normal((N, Cin)), 0, 1)).astype(np.float32)
+    Y = onp.logit(np.clip(base @ rng.random((4, T)) / 3 + 0.01 * rng.standard_normal((N, T)), 0.001, 0.6))
+    return X, Y
+
+
+@pytest.mark.parametrize("T", [33, 64, 96, 97, 192, 285])
+def test_predict103_kernel_families_vs_oracle(torch_gpu, T):
+    """Every many-target predict kernel of the notebook's shape (10 inputs, degree 3; Spectral_matching.ipynb raw :192-213,
+    :475-490 generalised to T targets) against the float64 oracle, NOT against itself: T 33-96 runs the chunked
+    predict103_kernel<2/3, false>, T 97-512 the sliced predict103_slice_kernel (hsr_ridge.hip).  Two views:
+      (a) the kernels alone - the ORACLE'S model loaded with from_params, so a wrong W-slice offset or target-tile epilogue
+          cannot hide behind a consistent fit;
+      (b) fit + predict end to end.
+    Odd pixel counts (ragged last 128-pixel tile), pixel-major rows and the band-major cube.  Bars: logit 2e-4, reflectance
+    1e-4 (float32 features and f32 MFMA accumulation against float64)."""
+    import s2_emit
+    rng = np.random.default_rng(100 + T)
+    X, Y = _a9_problem(rng, 2501, 10, T)
+    ref = onp.ridge_poly_fit(X.astype(np.float64), Y, 3, 1.0)
+    loaded = s2_emit.PolyRidge.from_params(ref["mean"], ref["scale"], ref["coef"], ref["intercept"], degree=3)
+    fitted = s2_emit.PolyRidge(degree=3, alpha=1.0).fit(X, Y)
+    assert fitted.n_feat == 285 and fitted.coef_.shape == (T, 285)
+    for npx in (1, 127, 777, 1517):
+        Xt = (600 + 4000 * np.clip(rng.random((npx, 4)) @ rng.random((4, 10)) / 2, 0, 1)).astype(np.float32)
+        want = onp.ridge_poly_predict(ref, Xt.astype(np.float64))
+        for tag, model in (("loaded", loaded), ("fitted", fitted)):
+            got = model.predict(Xt)
+            assert got.shape == (npx, T) and got.dtype == np.float32
+            np.testing.assert_allclose(got, want, rtol=0, atol=2e-4, err_msg=f"{tag} T={T} npx={npx}")
+    H, W = 37, 41
+    cube = (600 + 4000 * np.clip(rng.random((H * W, 4)) @ rng.random((4, 10)) / 2, 0, 1)).astype(np.float32).T.reshape(10, H, W).copy()
+    cube[2, 5, 6] = np.nan
+    cube[7, 36, 40] = -9999.0
+    want = onp.predict_cube_logit(ref, cube, nodata=-9999.0)
+    for tag, model in (("loaded", loaded), ("fitted", fitted)):
+        got = s2_emit.predict_cube_logit(model, cube, nodata=-9999.0)
+        assert got.shape == (T, H, W)
+        np.testing.assert_array_equal(np.isnan(got), np.isnan(want))
+        np.testing.assert_allclose(got, want, rtol=0, atol=1e-4, equal_nan=True, err_msg=f"{tag} T={T}")
+    # every target really is its own row of W: permuting the targets of the model permutes the outputs, bit for bit
+    perm = rng.permutation(T)
+    shuffled = s2_emit.PolyRidge.from_params(ref["mean"], ref["scale"], ref["coef"][perm], ref["intercept"][perm], degree=3)
+    Xt = (600 + 4000 * rng.random((300, 10))).astype(np.float32)
+    np.testing.assert_array_equal(shuffled.predict(Xt), loaded.predict(Xt)[:, perm])
+
+
+def test_poly_ridge_golden_g11_notebook_shapes(torch_gpu):
+    """a9 at the notebook's own shapes, against scikit-learn and the notebook's predict_cube_logit frozen in g11:
+    train (10000, 10) -> 32 targets (raw :426), predict_cube_logit on (10, 600, 600) -> (32, 600, 600) (raw :634) checked on
+    the stored strided sample, one full row, the NaN count and per-band checksums; and the 97-target sklearn model (the
+    sliced predict kernel against scikit-learn itself) on 257 pixels."""
+    import s2_emit
+    from conftest import g11_cube
+    g = load_golden("g11_ridge_notebook_shapes")
+    X = g["X"].astype(np.float32)
+    Yl = onp.logit((g["Yu16"].astype(np.float32) * np.float32(1e-4)).astype(np.float64))
+    model = s2_emit.PolyRidge(degree=3, alpha=1.0).fit(X, Yl)
+    assert model.n_feat == 285 and model.coef_.shape == (32, 285)
+    np.testing.assert_allclose(model.mean_, g["mean"], rtol=1e-12)
+    np.testing.assert_allclose(model.scale_, g["scale"], rtol=1e-12)
+    np.testing.assert_allclose(model.intercept_, g["intercept"], rtol=1e-6, atol=1e-7)
+    np.testing.assert_allclose(model.predict(X[:512]), g["train_pred_logit"], rtol=0, atol=2e-4)
+    cube = g11_cube(g)
+    nodata = float(g["nodata"])
+    for tag, m in (("fitted", model),
+                   ("sklearn's parameters", s2_emit.PolyRidge.from_params(g["mean"], g["scale"], g["coef"], g["intercept"]))):
+        pred = s2_emit.predict_cube_logit(m, cube, nodata=nodata)
+        assert pred.shape == (32, 600, 600) and pred.dtype == np.float32
+        fin = np.isfinite(pred)
+        assert int((~fin).sum()) == int(g["pred_nan_count"]) == 32 * 7, tag
+        for c_, i_, j_ in list(g["cube_nan"]) + list(g["cube_nd"]):
+            assert np.isnan(pred[:, i_, j_]).all(), tag
+        np.testing.assert_allclose(pred[:, ::7, ::11], g["pred_sample"], rtol=0, atol=1e-4, equal_nan=True, err_msg=tag)
+        np.testing.assert_allclose(pred[:, 299, :], g["pred_rows_299"], rtol=0, atol=1e-4, equal_nan=True, err_msg=tag)
+        zs = np.where(fin, pred, 0).astype(np.float64)
+        np.testing.assert_allclose(zs.sum(axis=(1, 2)), g["pred_band_sum"], rtol=2e-6, err_msg=tag)        # 360 000 pixels per band
+        np.testing.assert_allclose((zs ** 2).sum(axis=(1, 2)), g["pred_band_sumsq"], rtol=4e-6, err_msg=tag)
+    # 97 targets: fit on 2000 pixels, predict 257
+    Yl2 = onp.logit((g["Y2u16"].astype(np.float32) * np.float32(1e-4)).astype(np.float64))
+    m2 = s2_emit.PolyRidge(degree=3, alpha=1.0).fit(X[:2000], Yl2)
+    np.testing.assert_allclose(m2.intercept_, g["intercept2"], rtol=1e-6, atol=1e-7)
+    Xt2 = g["Xtest2"].astype(np.float32)
+    np.testing.assert_allclose(m2.predict(Xt2), g["pred2_logit"], rtol=0, atol=2e-4)
+    m2s = s2_emit.PolyRidge.from_params(m2.mean_, m2.scale_, g["coef2"], g["intercept2"])
+    np.testing.assert_allclose(m2s.predict(Xt2), g["pred2_logit"], rtol=0, atol=2e-4)
+
+
 # ---------------------------------------------------------------------------------------------
 # f1 resamplers and the reference-ordered driver (a7)
 # ---------------------------------------------------------------------------------------------
@@ -1458,6 +1547,67 @@ def test_step_batch_ragged_tile_sizes_and_masks(torch_gpu):
     out = plan.step_batch(st_c, st_r)
     o = plan.step(st_c[1], st_r[1], reuse_buffers=False)
     assert torch.equal(o.matched.view(torch.int32), out.tile(1).matched.view(torch.int32))
+
+
+def test_fit_targets_and_mask_reach_every_kernel_variant_repeatably(torch_gpu):
+    """The fit's operands (two target values and the mask byte per thread) are staged through LDS by per-lane LDS-DMA in
+    srf_kernel / srf_u16_kernel and by ordinary prefetch loads in srf_u16_ring_kernel (rounds 1-2 used inline-asm loads
+    whose results the compiler could copy before they had landed: a masked tile's moments changed from launch to launch).
+    For every degree x {float32 fast loader, float32 generic loader (unaligned cube), uint16 ring, uint16 single buffer}
+    x {mask, no mask} x {single launch, batch launch}: two launches give identical bits, and the moments are the ones an
+    independent torch evaluation of the same pixels gives (count exact, sums to 1e-12) - so a target or mask value that
+    arrived late, or in the wrong lane, cannot pass."""
+    torch = torch_gpu
+    from s2_emit import _engine as eng, _native as nat
+    w, good = onp.synthetic_wavelengths()
+    table = eng.build_srf_table(w, onp.synthetic_srf(), good)
+    nb = table.nb
+    g = torch.Generator(device="cuda")
+    g.manual_seed(77)
+    npix = 64 * 37 + 29                                  # ragged last group
+    base = torch.rand((npix * 285 + 4,), generator=g, device="cuda") * 0.6
+    cube_al = base[:npix * 285].view(npix, 285)
+    cube_un = base[1:npix * 285 + 1].view(npix, 285)     # 4-byte aligned only: the generic loader
+    real = torch.rand((npix, eng.padded_row(nb)), generator=g, device="cuda")
+    real[5, 2] = float("nan")
+    mask = (torch.rand(npix, generator=g, device="cuda") > 0.3).to(torch.uint8)
+    variants = [("f32 fast", cube_al, None), ("f32 generic", cube_un, None),
+                ("u16 ring", eng.tile_encode_u16(cube_al.contiguous()), eng.srf_options()),
+                ("u16 single", eng.tile_encode_u16(cube_al.contiguous()), eng.srf_options(u16_single_buffer=True))]
+    for deg in (1, 2, 3, 4):
+        M = 3 * deg + 2
+        for tag, cube, opts in variants:
+            cube = cube if cube.is_contiguous() else cube
+            for m in (None, mask):
+                ws = eng.MomentWorkspace(cube.device, nb, deg)
+                runs = []
+                for _ in range(2):
+                    img, mom = eng.srf_integrate_moments(cube, table, real, deg, ws, m, 0.0625, 0.0625, layout=nat.PIXMAJOR, opts=opts)
+                    runs.append((img.clone(), mom.clone()))
+                assert torch.equal(runs[0][0].view(torch.int32), runs[1][0].view(torch.int32)), (deg, tag, m is not None)
+                assert torch.equal(runs[0][1].view(torch.int64), runs[1][1].view(torch.int64)), (deg, tag, m is not None)
+                x = runs[0][0][:, :nb].double()
+                y = real[:, :nb].double()
+                ok = torch.isfinite(x) & torch.isfinite(y) & (x > 0.0625) & (y > 0.0625)
+                if m is not None:
+                    ok &= m.bool()[:, None]
+                xs, ys = torch.where(ok, x, torch.zeros_like(x)), torch.where(ok, y, torch.zeros_like(y))
+                want = torch.stack([(xs ** k * ok).sum(0) for k in range(2 * deg + 1)] +
+                                   [(xs ** k * ys).sum(0) for k in range(deg + 1)], dim=1)          # (nb, 3 deg + 2)
+                got = runs[0][1]
+                assert got.shape == (nb, M)
+                assert torch.equal(got[:, 0], ok.sum(0).double()), (deg, tag, m is not None)       # the count is exact
+                assert torch.allclose(got, want, rtol=1e-12, atol=0), (deg, tag, m is not None)
+                # the same tile as a batch of two (second tile: the first 640 pixels, mask only on one of them)
+                tb = eng.TileBatch([cube, cube[:640]], [real, real[:640]], [m, None if m is not None else mask[:640]], table, deg, opts)
+                for rep in range(2):
+                    eng.batch_srf_integrate_moments(tb, 0.0625, 0.0625)
+                    eng.batch_reduce_solve(tb, 5)
+                    if rep == 0:
+                        first = (tb.pseudo.clone(), tb.moments.clone())
+                assert torch.equal(first[0].view(torch.int32), tb.pseudo.view(torch.int32)), (deg, tag, "batch")
+                assert torch.equal(first[1].view(torch.int64), tb.moments.view(torch.int64)), (deg, tag, "batch")
+                assert torch.equal(tb.moments[0].view(torch.int64), got.view(torch.int64)), (deg, tag, "batch tile 0 == single launch")
 
 
 def test_padded_rows_are_owned_and_zeroed(torch_gpu):

@@ -106,3 +106,55 @@ def test_two_ranks_fit_the_union_of_their_tiles(mode):
         np.testing.assert_array_equal(matched_c, matched)
     # and both ranks hold bit-identical coefficients
     np.testing.assert_array_equal(res[0][0][0], res[1][0][0])
+
+
+def _bench(*argv, timeout=600):
+    import subprocess
+    return subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *argv], capture_output=True, text=True, timeout=timeout)
+
+
+@pytest.mark.parametrize("scaling", ["weak", "strong"])
+def test_bench_starts_its_own_ranks(scaling):
+    """`python bench.py --gpus 2 ...` UN-WRAPPED (no torch.distributed.run around it): the parent starts the two ranks
+    before touching the GPU and relays rank 0's single JSON line.  gloo + --same-device because the box has one GPU;
+    the line says so (degraded).  strong: ONE 256-row cube split into two 128-row blocks, one global fit."""
+    import json
+    r = _bench("--gpus", "2", "--backend", "gloo", "--same-device", "--height", "256", "--width", "256", "--steps", "3",
+               "--warmup", "1", "--settle-ms", "5", "--scaling", scaling, "--no-probe")
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["world_size"] == 2 and line["degraded"] is True and line["scaling"] == scaling
+    assert line["exchange_ranks"] == 2 and line["rccl_ranks"] is None            # gloo counted the ranks, RCCL did not run
+    rows = 128 if scaling == "strong" else 256
+    assert line["config"]["rows_per_gpu"] == rows and line["steps"] == 3 and line["value"] > 0
+    # value counts the pixels all ranks processed: N tiles (weak) or the one cube (strong)
+    npb = 2 * rows * 256 * 285
+    assert abs(line["value"] - npb * 3 / (line["ms_per_step"] * 3e-3) / 1e6) / line["value"] < 1e-3
+    assert "cold" in line and line["cold"]["steps"] == 20 and line["cold"]["ms_per_step"] > 0
+
+
+def test_bench_rccl_on_too_few_gpus_fails_fast():
+    """--gpus 2 over RCCL on a one-GPU box: one clear line, non-zero, no rank started, no hang."""
+    import time
+    t0 = time.time()
+    r = _bench("--gpus", "2", "--steps", "2", timeout=300)
+    assert r.returncode != 0 and "needs 2 visible GPUs" in r.stderr and r.stdout.strip() == ""
+    assert time.time() - t0 < 120          # dominated by `import torch` on a fresh box
+
+
+def test_bench_n1_reports_cold_beside_placed():
+    """The driver's N = 1 command: cold (first allocations, no trials, no settle) and placed numbers in one line, the
+    traffic figure labelled with its source."""
+    import json
+    r = _bench("--gpus", "1", "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-probe", "--placement-trials", "3")
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["scaling"] == "weak" and line["rccl_ranks"] is None
+    assert line["cold"]["ms_per_step"] > 0.15 and line["cold"]["kernel_ms"] > 0.15
+    assert line["ms_per_step"] < line["cold"]["ms_per_step"] * 1.05
+    roof = line["roofline"]
+    assert roof["traffic"] and "traffic.json" in roof["traffic_source"] and "not measured in this run" in roof["traffic_source"]
+    assert line["config"]["placement"]["pitch_gb"] == 16.0 and "16 GB" in line["config"]["placement"]["note"]
+    assert "resource_tracker" not in r.stderr

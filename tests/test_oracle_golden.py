@@ -134,6 +134,38 @@ def test_g7_ridge_pipeline():
     np.testing.assert_array_equal(onp.logit(np.array([-0.01, 0.0, 1e-4, 0.3, 0.9999, 1.0, 1.2])), g["logit_probe"])
 
 
+def test_g11_ridge_at_notebook_shapes():
+    """The restated pipeline against scikit-learn at the notebook's own shapes (10000 x 10 -> 32 targets) and against the
+    NOTEBOOK'S predict_cube_logit on the 10 x 600 x 600 cube (strided sample, one full row, NaN count, per-band checksums);
+    plus the 97-target model (the many-target predict kernels' reference)."""
+    from conftest import g11_cube
+    g = load_golden("g11_ridge_notebook_shapes")
+    X = g["X"].astype(np.float32)
+    Y = g["Yu16"].astype(np.float32) * np.float32(1e-4)
+    m = onp.ridge_poly_fit(X.astype(np.float64), onp.logit(Y.astype(np.float64)), 3, 1.0)
+    np.testing.assert_allclose(m["mean"], g["mean"], rtol=1e-13)
+    np.testing.assert_allclose(m["scale"], g["scale"], rtol=1e-13)
+    np.testing.assert_allclose(m["intercept"], g["intercept"], rtol=1e-6, atol=1e-8)
+    np.testing.assert_allclose(onp.ridge_poly_predict(m, X[:512].astype(np.float64)), g["train_pred_logit"], rtol=0, atol=2e-6)
+    cube = g11_cube(g)
+    assert cube.shape == (10, 600, 600)
+    # full-size prediction on a slab of rows (the whole cube would take ~1 min of pure-NumPy feature expansion): the rows
+    # the strided sample and the stored full row fall into
+    rows = sorted(set(range(0, 600, 7)) | {299})[::6] + [299, 595]
+    sub = cube[:, rows, :]
+    pred = onp.predict_cube_logit(m, sub, nodata=float(g["nodata"]))
+    for k, r in enumerate(rows):
+        if r % 7 == 0:
+            np.testing.assert_allclose(pred[:, k, ::11], g["pred_sample"][:, r // 7, :], rtol=0, atol=2e-6, equal_nan=True)
+        if r == 299:
+            np.testing.assert_allclose(pred[:, k, :], g["pred_rows_299"], rtol=0, atol=2e-6, equal_nan=True)
+    assert np.isnan(pred[:, rows.index(0), 0]).all()                  # cube_nan[0] = (0, 0, 0)
+    assert int(g["pred_nan_count"]) == 32 * 7
+    m2 = onp.ridge_poly_fit(X[:2000].astype(np.float64), onp.logit((g["Y2u16"].astype(np.float32) * np.float32(1e-4)).astype(np.float64)), 3, 1.0)
+    np.testing.assert_allclose(onp.ridge_poly_predict(m2, g["Xtest2"].astype(np.float64)), g["pred2_logit"], rtol=0, atol=5e-6)
+    np.testing.assert_allclose(m2["intercept"], g["intercept2"], rtol=1e-6, atol=1e-8)
+
+
 def test_g8_histogram_match():
     g = load_golden("g8_histmatch")
     np.testing.assert_array_equal(onp.histogram_match_rgb(g["src"], g["ref"], g["mask"]), g["out"])

@@ -717,7 +717,13 @@ extern "C" int hsr_poly_apply(const float* x_dev, int64_t x_bs, int64_t x_ps, co
     if (aligned && (x_ps & 3) == 0 && q >= 1 && q <= 4 && npix * q < ((int64_t)1 << 31)) {
       // one pass when it fits (4 x 16 B per thread): no grid-stride tail imbalance on a ~20 us kernel.  The
       // grid is a multiple of 3 workgroups so that the stride is a multiple of every Q (lane <-> channel group fixed).
-      int64_t gb = (npix * q + 256 * HSR_K3_U - 1) / (256 * HSR_K3_U);
+      // Small images (a 128 x 1024 row block of a strong-scaling run: 393 216 float4) got 96 workgroups of 16 loads per
+      // thread - 10.6 us for 12.6 MB (rocprofv3, r03): latency bound on a third of the CUs.  The kernel skips loads past the
+      // image, so a larger grid simply means fewer loads per thread: aim for 3 workgroups per CU (768) and 1 .. U loads.
+      const int64_t nv4 = npix * q;
+      int64_t per_thread = (nv4 + 768 * 256 - 1) / (768 * 256);
+      per_thread = per_thread < 1 ? 1 : (per_thread > HSR_K3_U ? HSR_K3_U : per_thread);
+      int64_t gb = (nv4 + 256 * per_thread - 1) / (256 * per_thread);
       if (gb > 8190) gb = 2046;
       gb = (gb + 2) / 3 * 3;
       const dim3 grid((unsigned)gb);

@@ -83,6 +83,7 @@ struct SrfArgs {
 #ifdef HSR_PHASE_STAMPS
   unsigned long long* stamps;
   unsigned long long* stamps2;   // [grid][4]: REFCLK (100 MHz) at workgroup entry and exit, XCC id, HW_ID
+  uint32_t* stamps3;             // [grid][64]: REFCLK ticks of each of the workgroup's first 64 group iterations
 #endif
 };
 
@@ -91,6 +92,7 @@ struct SrfArgs {
 // reads.  Never compiled into libhsr_mi355x.so.
 unsigned long long* g_stamp_buffer = nullptr;
 unsigned long long* g_stamp_buffer2 = nullptr;
+uint32_t* g_stamp_buffer3 = nullptr;
 __device__ __forceinline__ unsigned long long real_time() {   // constant 100 MHz counter, the same on every XCD
   unsigned long long t;
   asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
@@ -179,14 +181,20 @@ __device__ __forceinline__ void lds_barrier() {
 // global_load_dword / _ubyte (invisible to hipcc's waitcnt pass, which otherwise drains vmcnt(0) between ordinary loads
 // and LDS-DMA: +20 us on the kernel) and retired them with a hand-written s_waitcnt - correct only as long as the
 // compiler placed no copy or spill of the "=v" result between the load and the wait (one such copy was seen: a masked
-// tile's moments changed from launch to launch).  An LDS-DMA has no destination register, the compiler itself orders the
-// ds_reads behind it, and there is nothing left to inspect per compiler version.  Lane i's dword lands at stage + 4 i;
-// a byte load lands zero-extended in the same dword slot.
+// tile's moments changed from launch to launch).  An LDS-DMA has no destination register, so there is no value the
+// compiler could move: the reads are ordinary ds_reads placed behind the group barrier (whose __syncthreads() carries
+// s_waitcnt vmcnt(0)) and an explicit wait.  Lane i's dword lands at stage + 4 i.
+// The mask byte travels as the aligned dword that holds it (a byte-sized LDS-DMA packs its 64 bytes instead of using
+// dword slots - measured: the first version read 97 % of a 79 % mask as set); staged_u8 picks the byte out again.
 __device__ __forceinline__ void stage_f32(const float* p, float* stage_wave_uniform) {
   __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)stage_wave_uniform, 4, 0, 0);
 }
 __device__ __forceinline__ void stage_u8(const uint8_t* p, uint32_t* stage_wave_uniform) {
-  __builtin_amdgcn_global_load_lds((gptr_t)p, (lptr_t)stage_wave_uniform, 1, 0, 0);
+  const uintptr_t a = reinterpret_cast<uintptr_t>(p);
+  __builtin_amdgcn_global_load_lds((gptr_t)(a & ~(uintptr_t)3), (lptr_t)stage_wave_uniform, 4, 0, 0);   // same dword: never leaves the buffer's page
+}
+__device__ __forceinline__ uint32_t staged_u8(const uint8_t* p, const uint32_t* stage, int lane) {
+  return (stage[lane] >> ((reinterpret_cast<uintptr_t>(p) & 3) * 8)) & 0xffu;
 }
 constexpr int kTargetStageBytesPerBand = 64 * 4;   // ystage[band][64 lanes]; + 64 dwords for the mask bytes
 __host__ __device__ constexpr size_t target_stage_bytes(int nb) { return (size_t)nb * kTargetStageBytesPerBand + 64 * 4; }
@@ -484,17 +492,31 @@ __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
     bwo[j] = a.bands.woff[bb];
   }
 
-  if (WLDS) {  // compact weight taps -> LDS, once per workgroup (visible after the first barrier below)
-    float* wlw = const_cast<float*>(wl);
-    for (int b = 0; b < a.nb; ++b) {
-      const int kl = a.bands.klen[b];  // whole 16-tap chunks inside [0, B) (srf_common)
-      for (int i = t; i < kl; i += T) wlw[a.bands.woff[b] + i] = a.wn[(size_t)b * B + a.bands.k0[b] + i];
+  // Once per workgroup: compact weight taps -> LDS, pad columns of the output slab zeroed.  Issued BEHIND the first group's
+  // DMA (behind_the_dma below), not in front of it: anything ahead of the first DMA is dead time for the whole workgroup
+  // (r03 per-round stamps: round 0 costs ~6 us more than a steady round - 3 % of a 1024 x 1024 launch, 20 % of the
+  // 128-row block of an 8-way strong-scaling run).  Both are first read after the first group barrier.
+  bool constants_staged = false;
+  auto stage_constants = [&]() {
+    if (WLDS) {
+      float* wlw = const_cast<float*>(wl);
+      for (int b = 0; b < a.nb; ++b) {
+        const int kl = a.bands.klen[b];  // whole 16-tap chunks inside [0, B) (srf_common)
+        for (int i = t; i < kl; i += T) wlw[a.bands.woff[b] + i] = a.wn[(size_t)b * B + a.bands.k0[b] + i];
+      }
     }
-  }
-  if (OUTV) zero_stage_pad<T>(ostage, P, a.nb, ops, t);
+    if (OUTV) zero_stage_pad<T>(ostage, P, a.nb, ops, t);
+  };
+
+#ifdef HSR_CONSTANTS_FIRST      // diagnostic variant (tools/dbg/build_variants.sh): round 2's order, for A/B runs
+  stage_constants();
+  constants_staged = true;
+#endif
 
 #ifdef HSR_PHASE_STAMPS
   unsigned long long stamp_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  unsigned long long round_t0 = rt_begin;
+  int round_no = 0;
 #endif
   constexpr int M = DEG > 0 ? moment_count(DEG) : 1;
   double acc_m[kBandSlots][M];
@@ -542,9 +564,12 @@ __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
     };
     auto wait_targets = [&]() {      // behind the group barrier: every wave's DMA has landed
       if (DEG > 0) {
+        // hipcc's own ordering of ds_reads behind a pending LDS-DMA is not to be relied on (seen in the .s: a ds_read of the
+        // stage with no vmcnt wait on the path that skips the slab flush); the barrier's vmcnt(0) covers it, this makes it local
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int j = 0; j < kBandSlots; ++j) yv[j] = bval[j] ? ystage[bidx[j] * 64 + lane] : 0.0f;
-        mraw = cu.mask_dev != nullptr ? (mstage[lane] & 0xffu) : 1u;
+        mraw = cu.mask_dev != nullptr ? staged_u8(cu.mask_dev + (pvalid ? pix0 + pl : cu.npix - 1), mstage, lane) : 1u;
       }
     };
     // everything that fills the wait for the DMA: targets, the next unit record, the previous group's output slab,
@@ -553,6 +578,10 @@ __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
       load_targets();
       if (BATCH && wave == 0 && lane < 16)
         __builtin_amdgcn_global_load_lds((gptr_t)unit_record_addr(a.units, nidx, a.nunits, lane), (lptr_t)ustage, 4, 0, 0);
+      if (!constants_staged) {       // first group of the workgroup only
+        stage_constants();
+        constants_staged = true;
+      }
       if (OUTV) flush_stage<8 * P>(ostage, prev_out, prev_pix0, prev_npx, ops, t);   // no-op before the first group
       if (BATCH && DEG > 0 && pend) {
         flush_moments<M, P, true, !BATCH>(acc_m, bval, bidx, pend_part, lane);
@@ -726,6 +755,12 @@ __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
     {
       HSR_STAMP(st6);
       if (a.stamps) { stamp_acc[3] += st5 - st4; stamp_acc[4] += st6 - st5; stamp_acc[5] += st6 - st0; stamp_acc[6] += 1; }
+      if (a.stamps3 && t == 0) {
+        const unsigned long long now = real_time();
+        if (round_no < 64) a.stamps3[(size_t)blockIdx.x * 64 + round_no] = (uint32_t)(now - round_t0);
+        round_t0 = now;
+        ++round_no;
+      }
     }
 #endif
   }
@@ -963,11 +998,12 @@ __global__ __launch_bounds__(512, 4) void srf_u16_kernel(const SrfArgs a) {
         if (cu.mask_dev != nullptr && wave == 7) stage_u8(cu.mask_dev + pc, mstage);   // every wave maps lanes to pixels alike
       }
     };
-    auto wait_targets = [&]() {
+    auto wait_targets = [&]() {      // call behind the group barrier only (see srf_kernel)
       if (DEG > 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
         for (int j = 0; j < kBandSlots; ++j) yv[j] = bval[j] ? ystage[bidx[j] * 64 + lane] : 0.0f;
-        mraw = cu.mask_dev != nullptr ? (mstage[lane] & 0xffu) : 1u;
+        mraw = cu.mask_dev != nullptr ? staged_u8(cu.mask_dev + (pvalid ? pix0 + pl : cu.npix - 1), mstage, lane) : 1u;
       }
     };
     auto behind_the_dma = [&]() {
@@ -993,16 +1029,13 @@ __global__ __launch_bounds__(512, 4) void srf_u16_kernel(const SrfArgs a) {
       }
     }
     behind_the_dma();   // one call site (see srf_kernel)
-    if (fast_group) {
-      __syncthreads();
-      wait_targets();
-    } else {
+    if (!fast_group) {
       // generic loader: any 2-byte alignment, ragged last group; the tail of the last chunk is zeroed
-      wait_targets();
       const int n = npx * B;
       for (int i = t; i < nchunk * 8; i += T) tile[i] = i < n ? ld_stream(src + i) : (uint16_t)0;
-      __syncthreads();
     }
+    __syncthreads();     // vmcnt(0) + barrier: the group and every wave's staged targets have landed
+    wait_targets();
     if (has_nodata) {
       u16_nodata_sweep(reinterpret_cast<const uint4*>(smem), nchunk, npx * B, B, nd2, a.nodata, flags, t);
       __syncthreads();
@@ -1119,17 +1152,19 @@ __global__ __launch_bounds__(512, 4) void srf_u16_ring_kernel(const SrfArgs a) {
     bkl[j] = bval[j] ? a.bands.klen[bidx[j]] : 0;
     bwo[j] = a.bands.woff[bidx[j]];
   }
-  if (wlds) {
-    float* wlw = const_cast<float*>(wl);
-    for (int b = 0; b < a.nb; ++b) {
-      const int kl = a.bands.klen[b];
-      for (int i = t; i < kl; i += T) {
-        const float wv = a.wn[(size_t)b * B + a.bands.k0[b] + i];
-        wlw[a.bands.woff[b] + i] = FASTU ? wv * scale : wv;     // fast arithmetic: decode scale folded into the taps
+  auto stage_constants = [&]() {      // called right BEHIND the first group's prefetch (see srf_kernel)
+    if (wlds) {
+      float* wlw = const_cast<float*>(wl);
+      for (int b = 0; b < a.nb; ++b) {
+        const int kl = a.bands.klen[b];
+        for (int i = t; i < kl; i += T) {
+          const float wv = a.wn[(size_t)b * B + a.bands.k0[b] + i];
+          wlw[a.bands.woff[b] + i] = FASTU ? wv * scale : wv;     // fast arithmetic: decode scale folded into the taps
+        }
       }
     }
-  }
-  if (OUTV) zero_stage_pad<T>(ostage, P, a.nb, ops, t);
+    if (OUTV) zero_stage_pad<T>(ostage, P, a.nb, ops, t);
+  };
   constexpr int M = DEG > 0 ? moment_count(DEG) : 1;
   double acc_m[kBandSlots][M];
   if (DEG > 0) {
@@ -1178,6 +1213,7 @@ __global__ __launch_bounds__(512, 4) void srf_u16_ring_kernel(const SrfArgs a) {
   }
   int g = cu.slot;
   prefetch(cu, g, 0);
+  stage_constants();
   int64_t nidx = (int64_t)blockIdx.x + gridDim.x;   // index of the unit after cu
   // the record of unit nidx is in ustage[cur] at the top barrier of every iteration: an LDS-DMA like the samples,
   // issued one iteration earlier into the other half (srf_kernel explains why not through registers)
@@ -1393,6 +1429,7 @@ static int launch_srf(const SrfArgs& a, int grid, hipStream_t stream) {
 #ifdef HSR_PHASE_STAMPS
   const_cast<SrfArgs&>(a).stamps = g_stamp_buffer;
   const_cast<SrfArgs&>(a).stamps2 = g_stamp_buffer2;
+  const_cast<SrfArgs&>(a).stamps3 = g_stamp_buffer3;
 #endif
   hipLaunchKernelGGL(kern, dim3(grid), dim3(8 * P), lds, stream, a);
   HSR_LAUNCH_CHECK("srf_kernel");

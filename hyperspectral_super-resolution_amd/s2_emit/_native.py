@@ -61,6 +61,16 @@ class FusedFit(C.Structure):
                 ("min_count", _i64)]
 
 
+class StepDesc(C.Structure):
+    """hsr_step_desc: every argument of one tile's step for fixed output / workspace buffers (include/hsr.h, ABI 4)."""
+    _fields_ = [("cube_dtype", _i32), ("B", _i32), ("npix", _i64), ("scale", _f32), ("nodata", _i32),
+                ("wn_dev", _vp), ("k0", _pi32), ("klen", _pi32), ("nb", _i32), ("deg", _i32),
+                ("pseudo_dev", _vp), ("out_bs", _i64), ("out_ps", _i64), ("real_bs", _i64), ("real_ps", _i64),
+                ("min_x", _f32), ("min_y", _f32), ("partials_dev", _vp), ("moments_dev", _vp), ("coeffs_dev", _vp),
+                ("min_count", _i64), ("matched_dev", _vp), ("matched_bs", _i64), ("matched_ps", _i64),
+                ("apply_mask", _i32), ("clip", _i32), ("opts", SrfOptions)]
+
+
 BATCH_RECORD_BYTES = 64          # sizeof(hsr_batch_tile) == sizeof(hsr_batch_unit)
 assert C.sizeof(BatchTile) == BATCH_RECORD_BYTES
 _popt = C.POINTER(SrfOptions)
@@ -132,6 +142,20 @@ SIGNATURES = {
     "hsr_block_mean": (C.c_int, [_vp, _i32, _i64, _i64, _i32, _i32, _i32, _i32, _f32, _vp, _i64, _i64, _vp]),
     "hsr_bilinear_upsample": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _i64, _vp]),
     "hsr_probe_read": (C.c_int, [_vp, _i64, _i32, _vp, _vp]),
+    "hsr_step_plan_create": (C.c_int, [C.POINTER(StepDesc), C.POINTER(_vp)]),
+    "hsr_step_plan_destroy": (None, [_vp]),
+    "hsr_step_plan_slots": (C.c_int, [_vp]),
+    "hsr_step_run": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "hsr_step_run_k1": (C.c_int, [_vp, _vp, _vp, _vp, _vp]),
+    "hsr_step_run_reduce": (C.c_int, [_vp, _vp]),
+    "hsr_step_run_solve": (C.c_int, [_vp, _vp]),
+    "hsr_step_run_apply": (C.c_int, [_vp, _vp, _vp]),
+    "hsr_pipeline_create": (C.c_int, [_vp, _vp, _vp, _i32, C.POINTER(_vp)]),
+    "hsr_pipeline_destroy": (None, [_vp]),
+    "hsr_pipeline_submit": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _pi32, _vp, _vp]),
+    "hsr_pipeline_fit_done": (C.c_int, [_vp]),
+    "hsr_pipeline_flush": (C.c_int, [_vp, _vp, _vp, _pi32]),
+    "hsr_pipeline_count": (_i64, [_vp]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -108,7 +108,8 @@ class SpectralFusion:
                  force_exchange: bool = False, tile_scale=None, tile_nodata: Optional[int] = eng.TILE_NODATA,
                  reserved_cus: Optional[int] = None, tile_pixels: int = 0, u16_single_buffer: bool = False,
                  u16_fast: bool = False, placement_trials: int = 0, fused_fit: bool = False,
-                 placement_pitch_gb: float = eng.PLACEMENT_PITCH_GB, placement_budget_gb: Optional[float] = None):
+                 placement_pitch_gb: float = eng.PLACEMENT_PITCH_GB, placement_budget_gb: Optional[float] = None,
+                 side_stream=None):
         """``placement_trials`` (default 0 = OFF: the plan allocates once and never synchronises with the host): opt in to
         the placement search of eng.placement_search for tiles of >= 65 536 pixels - up to min(4, trials) candidate output
         images on the first step()/submit()/step_batch() over a tile size, up to ``trials`` candidate (cube, target, image)
@@ -166,6 +167,11 @@ class SpectralFusion:
         # against 8.5 us + one launch gap for the separate hsr_moments_reduce_solve - 3 us per step slower.
         self.fused_fit = bool(fused_fit)
         self._pipe = None                            # state of submit()/flush(), created on first use
+        # the stream the fits of submit() run on: None = chosen by measurement on the first submit (_pick_side_stream)
+        self.side_stream = side_stream
+        self.side_stream_log = None                  # us per pipelined step of each candidate stream, if measured
+        self._native: Dict[tuple, object] = {}       # prepared launches of step(), by _native_key
+        self._native_handles: list = []              # ("plan" | "pipe", handle) to destroy with the plan
         self._pipe_images: Dict[int, list] = {}      # output images placed by place_inputs() for the pipeline's two slots
         self.ws = eng.MomentWorkspace(self.device, self.table.nb, deg)
         self.table.device_weights(self.device)
@@ -273,12 +279,90 @@ class SpectralFusion:
                 return real, nat.PLANAR
         raise ValueError(f"real S2 target of shape {tuple(real.shape)} matches neither (npix,{nb}+) nor ({nb},npix)")
 
+    # ---- prepared launches (include/hsr.h "step executor", csrc/hsr_exec.hip) -----------------------------------
+    # step() / submit() of a plan normally see the same shapes again and again.  The first call for a (cube shape and dtype,
+    # target shape and strides, mask or not) combination goes through the individual operators (which validate everything
+    # and run the opt-in placement trials); it also builds an hsr_step_plan holding every argument of the three launches.
+    # Later calls are ONE ctypes call with the three pointers that change - the same launches, hence the same bits, without
+    # ~35 us of Python per step (profiles/r03_strong_scaling.md).
+    def _native_key(self, cube, real, mask):
+        return (tuple(cube.shape), cube.dtype, tuple(real.shape), tuple(real.stride()), real.dtype, mask is not None)
+
+    def _native_desc(self, cube, real2, real_layout, pseudo, matched, ws):
+        """hsr_step_desc for tiles shaped like ``cube`` / ``real2`` writing into the given images and workspace."""
+        torch = nat.require_gpu()
+        import ctypes as C
+        c2 = eng._as_cube2d(cube)
+        npix, B = c2.shape
+        nb = self.table.nb
+        rbs, rps, _, _ = eng._img(real2, real_layout, nb)
+        obs, ops_, _, _ = eng._img(pseudo, self.layout, nb)
+        mbs, mps, _, _ = eng._img(matched, self.layout, nb)
+        k0 = (C.c_int32 * nb)(*[int(v) for v in self.table.k0])
+        kl = (C.c_int32 * nb)(*[int(v) for v in self.table.klen])
+        wn = self.table.device_weights(self.device)
+        d = nat.StepDesc()
+        d.cube_dtype = 2 if c2.dtype == torch.uint16 else 0
+        d.B, d.npix = int(B), int(npix)
+        d.scale = eng._decode_scale(self.tile_scale)
+        d.nodata = -1 if self.tile_nodata is None else int(self.tile_nodata)
+        d.wn_dev = wn.data_ptr()
+        d.k0, d.klen = C.cast(k0, C.POINTER(C.c_int32)), C.cast(kl, C.POINTER(C.c_int32))
+        d.nb, d.deg = nb, self.deg
+        d.pseudo_dev, d.out_bs, d.out_ps = pseudo.data_ptr(), obs, ops_
+        d.real_bs, d.real_ps = rbs, rps
+        d.min_x = d.min_y = self.min_valid
+        d.partials_dev, d.moments_dev, d.coeffs_dev = ws.partials.data_ptr(), ws.moments.data_ptr(), ws.coeffs.data_ptr()
+        d.min_count = self.min_count
+        d.matched_dev, d.matched_bs, d.matched_ps = matched.data_ptr(), mbs, mps
+        d.apply_mask, d.clip = int(self.apply_mask), int(self.clip)
+        d.opts = self.opts
+        return d, (k0, kl, wn)
+
+    def _native_plan(self, cube, real2, real_layout, pseudo, matched, ws):
+        import ctypes as C
+        lib = nat.load()
+        d, keep = self._native_desc(cube, real2, real_layout, pseudo, matched, ws)
+        h = C.c_void_p()
+        nat.check(lib.hsr_step_plan_create(C.byref(d), C.byref(h)), "hsr_step_plan_create")
+        self._native_handles.append(("plan", h))
+        return h, (keep, pseudo, matched, ws)         # the plan stores raw pointers: keep the tensors alive with it
+
+    def close(self):
+        """Destroy the prepared launches of this plan (also done when the plan is garbage collected)."""
+        lib = nat._lib
+        handles, self._native_handles = getattr(self, "_native_handles", []), []
+        self._native = {}
+        self._pipe = None
+        if lib is None:
+            return
+        for kind, h in reversed(handles):                       # pipelines before the plans they point to
+            (lib.hsr_pipeline_destroy if kind == "pipe" else lib.hsr_step_plan_destroy)(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
     def step(self, cube, real, mask=None, reuse_buffers: bool = True, k1_events=None) -> FusionOutput:
         """One pass of the hot path over one tile.
         cube (H,W,B) or (npix,B) float32 GPU tensor; real: real-S2 target, band-last (H,W,C>=nb) /
         (npix,C) [fast] or band-major (nb,H,W) / (nb,npix); mask optional uint8 (npix), 1 = use."""
         torch = nat.require_gpu()
+        exchanges = self._exchanges()
+        fast = reuse_buffers and k1_events is None and not exchanges and not self.fused_fit
+        if fast:
+            ent = self._native.get(self._native_key(cube, real, mask))
+            if ent is not None and cube.is_contiguous() and cube.device == self.device and real.device == self.device and \
+                    (mask is None or (mask.dtype == torch.uint8 and mask.is_contiguous() and mask.numel() == ent[2] and mask.device == self.device)):
+                with eng._launch(cube) as st:
+                    nat.check(nat._lib.hsr_step_run(ent[0], cube.data_ptr(), real.data_ptr(), None if mask is None else mask.data_ptr(), st),
+                              "hsr_step_run")
+                ent[3].slots = nat._lib.hsr_step_plan_slots(ent[0])
+                return ent[1]
         npix = cube.numel() // cube.shape[-1]
+        real_in = real
         real, real_layout = self._real_image(real, npix)
         if reuse_buffers:
             def probe(img):
@@ -288,7 +372,6 @@ class SpectralFusion:
             pseudo, matched = self._buffers(npix, probe if npix not in self._buf else None)
         else:
             pseudo = matched = None
-        exchanges = self._exchanges()
         fit = self.min_count if (self.fused_fit and not exchanges) else None
         pseudo, fitted = eng.srf_integrate_moments(cube, self.table, real, self.deg, self.ws, mask,
                                                    self.min_valid, self.min_valid, out=pseudo, events=k1_events,
@@ -304,8 +387,12 @@ class SpectralFusion:
             moments, coeffs = eng.moments_reduce_solve(self.ws, self.min_count)
         matched = eng.poly_apply(pseudo, coeffs, mask if self.apply_mask else None, None, self.clip,
                                  self.layout, out=matched, nb=self.table.nb)
-        return FusionOutput(self.names, pseudo, moments, coeffs, matched, self.layout)
-
+        out = FusionOutput(self.names, pseudo, moments, coeffs, matched, self.layout)
+        if fast and real.is_contiguous() and self.table.nb <= nat.HSR_MAX_BANDS:
+            # everything was validated by the operators above: prepare the launches for the next tile of this shape
+            h, keep = self._native_plan(cube, real, real_layout, pseudo, matched, self.ws)
+            self._native[self._native_key(cube, real_in, mask)] = (h, out, npix, self.ws, keep)
+        return out
 
 
     # ---- a batch of independent tiles in three launches ---------------------------------------------------
@@ -599,78 +686,158 @@ class SpectralFusion:
     # 0.265 ms against 0.256 ms sequential.  Two alternating buffer sets; ordering between tiles i and i+2 needs no
     # extra events: K3(i) waits for fit(i) and precedes K1(i+2) on the caller's stream.  The FusionOutput returned
     # for tile i is valid until the second submit() after it.
-    def _pipe_state(self, npix: int, probe=None):
+    def _pick_side_stream(self, slots, cube, real2, mask, steps: int = 10):
+        """The stream the fits of submit() run on, chosen by MEASUREMENT.  Which hardware queue a HIP stream is served by is
+        the runtime's business (a few queues shared round-robin by all streams of the process), and it decides everything
+        here (profiles/r03_strong_scaling.md): a default-priority stream may share the caller's queue (the fit then simply
+        serialises with K1), and some high-priority streams of torch's pool make every pipelined step of a small tile take
+        ~200 us instead of ~55 us (the 4th and 5th stream of the pool, reproducibly, in every process tried).  So a few
+        candidates - high-priority streams first, one of default priority last - each run a short local pipeline over the
+        caller's tile (results are overwritten by the first real submit) and the fastest is kept; ties go to the earlier
+        candidate.  ~4 x 10 steps, once per tile shape; pass ``side_stream=`` to the constructor to skip it."""
         torch = nat.require_gpu()
-        if self._pipe is None or self._pipe["npix"] != npix:
-            nb = self.table.nb
-            slots = []
-            placed = self._pipe_images.pop(npix, [])         # placed together with the resident inputs (place_inputs)
-            if len(placed) < 2:
-                placed = [eng.alloc_image(torch, nb, npix, self.layout, self.device) for _ in range(2)]
-                if probe is not None and self.placement_trials > 1 and npix >= (1 << 16):
-                    placed = self._place(npix, placed, probe, count=2)     # ONE search for both slots' images
-            for k in range(2):
-                pseudo = placed[k]
-                slots.append(dict(pseudo=pseudo,
-                                  matched=eng.alloc_image(torch, nb, npix, self.layout, self.device),
-                                  ws=eng.MomentWorkspace(self.device, nb, self.deg), mask=None,
-                                  ev_k1=torch.cuda.Event(), ev_fit=torch.cuda.Event()))
-            self._pipe = dict(npix=npix, slots=slots, n=0, pending=None, side=torch.cuda.Stream(device=self.device, priority=-1))
-        return self._pipe
+        import ctypes as C
+        import time
+        lib = nat.load()
+        cands = [torch.cuda.Stream(device=self.device, priority=-1) for _ in range(3)] + [torch.cuda.Stream(device=self.device, priority=0)]
+        fin = C.c_int32(-1)
+        mptr = None if mask is None else mask.data_ptr()
+        times = []
+        with eng._launch(cube) as stream:
+            for cand in cands:
+                ph = C.c_void_p()
+                nat.check(lib.hsr_pipeline_create(slots[0]["plan"], slots[1]["plan"], C.c_void_p(cand.cuda_stream), 0, C.byref(ph)),
+                          "hsr_pipeline_create")
+                try:
+                    best = float("inf")
+                    for rep in range(2):                     # first repetition warms the queue up
+                        torch.cuda.synchronize(self.device)
+                        t0 = time.perf_counter()
+                        for _ in range(steps):
+                            nat.check(lib.hsr_pipeline_submit(ph, cube.data_ptr(), real2.data_ptr(), mptr, mptr, stream, C.byref(fin), None, None),
+                                      "hsr_pipeline_submit")
+                        nat.check(lib.hsr_pipeline_flush(ph, mptr, stream, C.byref(fin)), "hsr_pipeline_flush")
+                        torch.cuda.synchronize(self.device)
+                        best = min(best, time.perf_counter() - t0)
+                    times.append(best / steps)
+                finally:
+                    lib.hsr_pipeline_destroy(ph)
+        pick = min(range(len(cands)), key=lambda i: (times[i] > 1.03 * min(times), i))     # first one within 3 % of the best
+        self.side_stream_log = [round(t * 1e6, 2) for t in times]
+        return cands[pick]
 
-    def _pipe_finish(self, slot) -> FusionOutput:
-        """K3 of a submitted tile on the caller's stream, behind its fit."""
+    def _pipe_build(self, cube, real, mask, key):
+        """Buffers (two slots), prepared launches and the native pipeline for tiles shaped like ``cube`` / ``real``."""
         torch = nat.require_gpu()
-        torch.cuda.current_stream(self.device).wait_event(slot["ev_fit"])
-        ws = slot["ws"]
-        eng.poly_apply(slot["pseudo"], ws.coeffs, slot["mask"] if self.apply_mask else None, None, self.clip,
-                       self.layout, out=slot["matched"], nb=self.table.nb)
-        slot["mask"] = None
-        return FusionOutput(self.names, slot["pseudo"], ws.moments, ws.coeffs, slot["matched"], self.layout)
-
-    def submit(self, cube, real, mask=None, k1_events=None) -> Optional[FusionOutput]:
-        """Pipelined step: start tile i, finish and return tile i-1 (None on the first call)."""
-        torch = nat.require_gpu()
+        import ctypes as C
+        lib = nat.load()
+        if self._pipe is not None:
+            self.flush()                                   # a tile of the previous shape still in flight: finish it
         npix = cube.numel() // cube.shape[-1]
-        real, real_layout = self._real_image(real, npix)
+        real2, real_layout = self._real_image(real, npix)
+        if not (real2.is_cuda and real2.dtype == torch.float32):
+            raise ValueError("real must be a float32 GPU image with one value per pixel and band")
+        eng._as_cube2d(cube)                               # dtype / contiguity / device checks of the operators
+        nb = self.table.nb
+
         def probe(img):
-            eng.srf_integrate_moments(cube, self.table, real, self.deg, self.ws, mask, self.min_valid, self.min_valid,
+            eng.srf_integrate_moments(cube, self.table, real2, self.deg, self.ws, mask, self.min_valid, self.min_valid,
                                       out=img, reduce=False, layout=self.layout, real_layout=real_layout,
                                       scale=self.tile_scale, nodata=self.tile_nodata, opts=self.opts)
-        st = self._pipe_state(npix, probe)
-        slot = st["slots"][st["n"] % 2]
-        ws = slot["ws"]
-        main = torch.cuda.current_stream(self.device)
-        eng.srf_integrate_moments(cube, self.table, real, self.deg, ws, mask, self.min_valid, self.min_valid,
-                                  out=slot["pseudo"], events=k1_events, reduce=False, layout=self.layout,
-                                  real_layout=real_layout, scale=self.tile_scale, nodata=self.tile_nodata, opts=self.opts)
-        slot["mask"] = mask
-        prev = st["pending"]
-        out = self._pipe_finish(prev) if prev is not None else None     # K3(i-1), directly behind K1(i) on this stream
-        # the event that releases fit(i) is recorded behind K3(i-1), not between K1(i) and K3(i-1): an event record
-        # in between cost a ~13 us bubble on the caller's stream; fit(i) still has all of K1(i+1) to hide under
-        slot["ev_k1"].record(main)
-        with torch.cuda.stream(st["side"]):
-            st["side"].wait_event(slot["ev_k1"])
-            if self._exchanges():
-                moments = eng.moments_reduce(ws)
-                exchange_moments(moments, lambda m, _ws=ws: eng.poly_solve(m, self.deg, self.min_count, out=_ws.coeffs),
-                                 self.group, self.coeff_sync)
-            else:
-                eng.moments_reduce_solve(ws, self.min_count)
-            slot["ev_fit"].record(st["side"])
-        st["pending"] = slot
+        placed = self._pipe_images.pop(npix, [])           # placed together with the resident inputs (place_inputs)
+        if len(placed) < 2:
+            placed = [eng.alloc_image(torch, nb, npix, self.layout, self.device) for _ in range(2)]
+            if self.placement_trials > 1 and npix >= (1 << 16):
+                placed = self._place(npix, placed, probe, count=2)       # ONE search for both slots' images
+        slots, outs = [], []
+        for k in range(2):
+            ws = eng.MomentWorkspace(self.device, nb, self.deg)
+            matched = eng.alloc_image(torch, nb, npix, self.layout, self.device)
+            h, keep = self._native_plan(cube, real2, real_layout, placed[k], matched, ws)
+            slots.append(dict(plan=h, ws=ws, keep=keep, mask=None))
+            outs.append(FusionOutput(self.names, placed[k], ws.moments, ws.coeffs, matched, self.layout))
+        exchange = self._exchanges()
+        side = self.side_stream if self.side_stream is not None else self._pick_side_stream(slots, cube, real2, mask)
+        ph = C.c_void_p()
+        nat.check(lib.hsr_pipeline_create(slots[0]["plan"], slots[1]["plan"], C.c_void_p(side.cuda_stream), 1 if exchange else 0,
+                                          C.byref(ph)), "hsr_pipeline_create")
+        self._native_handles.append(("pipe", ph))
+        self._pipe = dict(key=key, npix=npix, h=ph, slots=slots, outs=outs, side=side, side_handle=C.c_void_p(side.cuda_stream),
+                          exchange=exchange, n=0, fin=C.c_int32(-1))
+        return self._pipe
+
+    @staticmethod
+    def _event_handle(ev, stream):
+        """Raw hipEvent_t of a torch event (torch creates it lazily, on the first record)."""
+        if not ev.cuda_event:
+            ev.record(stream)
+        import ctypes as C
+        return C.c_void_p(ev.cuda_event)
+
+    def submit(self, cube, real, mask=None, k1_events=None) -> Optional[FusionOutput]:
+        """Pipelined step: start tile i, finish and return tile i-1 (None on the first call).  One call into the native
+        pipeline (csrc/hsr_exec.hip) enqueues K1(i) and K3(i-1) on the caller's stream and - without an exchange - the fit
+        of tile i on the side stream; with an exchange the fit (slot reduction -> collective -> solve) is enqueued from
+        here on the side stream."""
+        torch = nat.require_gpu()
+        import ctypes as C
+        lib = nat._lib or nat.load()
+        key = (tuple(cube.shape), cube.dtype, tuple(real.shape), tuple(real.stride()), real.dtype)
+        st = self._pipe
+        if st is None or st["key"] != key:
+            st = self._pipe_build(cube, real, mask, key)
+        if not (cube.is_contiguous() and cube.device == self.device and real.device == self.device):
+            raise ValueError("cube must be a contiguous tensor on the plan's GPU, real on the same GPU")
+        if mask is not None and not (mask.dtype == torch.uint8 and mask.numel() == st["npix"] and mask.is_contiguous()
+                                     and mask.device == self.device):
+            raise ValueError("mask must be a contiguous uint8 tensor with one byte per pixel")
+        cur = st["n"] & 1
+        prev_mask = st["slots"][cur ^ 1]["mask"]
+        fin = st["fin"]
+        with eng._launch(cube) as stream:
+            e0 = e1 = None
+            if k1_events is not None:
+                ts = torch.cuda.current_stream(self.device)
+                e0, e1 = self._event_handle(k1_events[0], ts), self._event_handle(k1_events[1], ts)
+            nat.check(lib.hsr_pipeline_submit(st["h"], cube.data_ptr(), real.data_ptr(), None if mask is None else mask.data_ptr(),
+                                              None if prev_mask is None else prev_mask.data_ptr(), stream, C.byref(fin), e0, e1),
+                      "hsr_pipeline_submit")
+            slot = st["slots"][cur]
+            slot["mask"] = mask                        # K3 of this tile reads it one submit() later
+            slot["ws"].slots = lib.hsr_step_plan_slots(slot["plan"])
+            if st["exchange"]:
+                sh = st["side_handle"]
+                with torch.cuda.stream(st["side"]):
+                    nat.check(lib.hsr_step_run_reduce(slot["plan"], sh), "hsr_step_run_reduce")
+
+                    def solve(_m, _p=slot["plan"], _ws=slot["ws"]):
+                        nat.check(lib.hsr_step_run_solve(_p, sh), "hsr_step_run_solve")
+                        return _ws.coeffs
+                    exchange_moments(slot["ws"].moments, solve, self.group, self.coeff_sync)
+                nat.check(lib.hsr_pipeline_fit_done(st["h"]), "hsr_pipeline_fit_done")
         st["n"] += 1
-        return out
+        if fin.value < 0:
+            return None
+        st["slots"][fin.value]["mask"] = None
+        return st["outs"][fin.value]
 
     def flush(self) -> Optional[FusionOutput]:
         """Finish (K3, on the caller's stream) the tile left in the pipeline by the last submit() and return it."""
         st = self._pipe
-        if st is None or st["pending"] is None:
+        if st is None or st["n"] == 0:
             return None
-        out = self._pipe_finish(st["pending"])
-        st["pending"] = None
-        return out
+        import ctypes as C
+        lib = nat._lib or nat.load()
+        last = (st["n"] - 1) & 1
+        mask = st["slots"][last]["mask"]
+        fin = st["fin"]
+        with eng._launch(st["outs"][0].pseudo) as stream:
+            nat.check(lib.hsr_pipeline_flush(st["h"], None if mask is None else mask.data_ptr(), stream, C.byref(fin)),
+                      "hsr_pipeline_flush")
+        if fin.value < 0:
+            return None
+        st["slots"][fin.value]["mask"] = None
+        return st["outs"][fin.value]
 
 
 def fuse_pair(R, emit_w, srf_dict, good_mask, real_s2: Dict[str, np.ndarray], deg: int = 3,

@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HSR_ABI_VERSION 3
+#define HSR_ABI_VERSION 4
 
 #define HSR_OK 0
 #define HSR_ERR_INVALID 1      /* bad argument (shape, alignment, NULL)            */
@@ -435,6 +435,71 @@ int hsr_block_mean(const void* in_dev, int32_t in_dtype, int64_t in_bs, int64_t 
                    float* out_dev, int64_t out_bs, int64_t out_ps, hsr_stream_t stream);
 int hsr_bilinear_upsample(const float* in_dev, int64_t in_bs, int64_t in_ps, int32_t nb, int32_t Hc, int32_t Wc,
                           int32_t factor, float* out_dev, int64_t out_bs, int64_t out_ps, hsr_stream_t stream);
+
+/* ---- step executor (ABI 4): the hot path of one tile as PREPARED launches, and the one-tile-deep pipeline -------------
+ * A plan stores every argument of K1+K2 (hsr_srf_integrate_moments[_u16]), of the slot reduction + solve
+ * (hsr_moments_reduce[_solve], hsr_poly_solve) and of K3 (hsr_poly_apply) for fixed output / workspace buffers; running a
+ * step is ONE call that takes only the pointers that change from tile to tile (cube, target, mask: same shapes and strides
+ * as described).  Same launches as the individual entry points, same bits - what it removes is the host-side marshalling
+ * (a 128 x 1024 row block of an 8-way strong-scaling run is 36 us of GPU work; three ctypes calls with 15-25 arguments,
+ * two stream contexts and four event operations from Python are ~60 us).  Plans are host objects: create / destroy are not
+ * launch-path calls; run calls are stream ordered and capturable like everything else.  A plan may be used by one host
+ * thread at a time. */
+typedef struct hsr_step_desc {
+  int32_t cube_dtype;            /* 0: float32 cube, 2: uint16 tile (scale / nodata below)                          */
+  int32_t B;
+  int64_t npix;
+  float scale;                   /* uint16 decode factor (1e-4)                                                     */
+  int32_t nodata;                /* uint16 nodata code, -1: none                                                    */
+  const float* wn_dev;           /* (nb, B) weights                                                                 */
+  const int32_t* k0;             /* host tables, copied by hsr_step_plan_create                                     */
+  const int32_t* klen;
+  int32_t nb, deg;
+  float* pseudo_dev;             /* K1 output image, strides out_bs / out_ps                                        */
+  int64_t out_bs, out_ps;
+  int64_t real_bs, real_ps;      /* strides of the target image passed to the run calls                             */
+  float min_x, min_y;
+  double* partials_dev;          /* hsr_partials_bytes(nb, deg)                                                     */
+  double* moments_dev;           /* (nb, 3deg+2)                                                                    */
+  double* coeffs_dev;            /* (nb, deg+1)                                                                     */
+  int64_t min_count;
+  float* matched_dev;            /* K3 output image                                                                 */
+  int64_t matched_bs, matched_ps;
+  int32_t apply_mask;            /* K3 applies the polynomial only where mask != 0                                  */
+  int32_t clip;
+  hsr_srf_options opts;
+} hsr_step_desc;
+typedef struct hsr_step_plan hsr_step_plan;
+typedef struct hsr_pipeline hsr_pipeline;
+
+int hsr_step_plan_create(const hsr_step_desc* desc, hsr_step_plan** plan_out);
+void hsr_step_plan_destroy(hsr_step_plan* plan);
+int hsr_step_plan_slots(const hsr_step_plan* plan);      /* partial slots of the last K1 launch of this plan          */
+/* K1+K2 -> slot reduction + solve -> K3 on one stream (== SpectralFusion.step without an exchange) */
+int hsr_step_run(hsr_step_plan* plan, const void* cube_dev, const float* real_dev, const uint8_t* mask_dev,
+                 hsr_stream_t stream);
+/* the pieces, for callers that put a collective between reduce and solve */
+int hsr_step_run_k1(hsr_step_plan* plan, const void* cube_dev, const float* real_dev, const uint8_t* mask_dev,
+                    hsr_stream_t stream);
+int hsr_step_run_reduce(hsr_step_plan* plan, hsr_stream_t stream);       /* partials -> moments_dev                   */
+int hsr_step_run_solve(hsr_step_plan* plan, hsr_stream_t stream);        /* moments_dev -> coeffs_dev                */
+int hsr_step_run_apply(hsr_step_plan* plan, const uint8_t* mask_dev, hsr_stream_t stream);
+/* One-tile-deep pipeline over two plans (two buffer sets): submit(i) enqueues K1(i) and K3(i-1) on the caller's stream and
+ * the fit of tile i on `side_stream`, which waits for K1(i) through an event recorded behind K3(i-1):
+ *     caller's stream :  K1(0)  K1(1)  K3(0)  K1(2)  K3(1) ...        side stream :  fit(0)  fit(1) ...  (fit(i) under K1(i+1))
+ * exchange = 0: the fit is hsr_moments_reduce_solve, enqueued by submit.  exchange = 1: when submit returns the side stream
+ * already waits for K1(i); the caller enqueues reduce -> collective -> solve on it (hsr_step_run_reduce / _solve) and then
+ * calls hsr_pipeline_fit_done.  *finished_slot: 0 / 1 = the slot whose tile was finished (its matched image is enqueued),
+ * -1 = none.  side_stream must be a real stream (not NULL); a high-priority one gets its own hardware queue. */
+int hsr_pipeline_create(hsr_step_plan* slot0, hsr_step_plan* slot1, hsr_stream_t side_stream, int32_t exchange,
+                        hsr_pipeline** pipeline_out);
+void hsr_pipeline_destroy(hsr_pipeline* pipeline);
+int hsr_pipeline_submit(hsr_pipeline* pipeline, const void* cube_dev, const float* real_dev, const uint8_t* mask_dev,
+                        const uint8_t* prev_mask_dev, hsr_stream_t main_stream, int32_t* finished_slot,
+                        void* k1_begin_event, void* k1_end_event);   /* optional hipEvent_t pair recorded around K1 (or NULL) */
+int hsr_pipeline_fit_done(hsr_pipeline* pipeline);
+int hsr_pipeline_flush(hsr_pipeline* pipeline, const uint8_t* mask_dev, hsr_stream_t main_stream, int32_t* finished_slot);
+int64_t hsr_pipeline_count(const hsr_pipeline* pipeline);
 
 /* ---- diagnostics -------------------------------------------------------------------------------
  * Pure streaming read of `bytes` bytes (a multiple of 16, 16-byte aligned base): the measured HBM read ceiling of

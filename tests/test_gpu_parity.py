@@ -1610,6 +1610,69 @@ def test_fit_targets_and_mask_reach_every_kernel_variant_repeatably(torch_gpu):
                 assert torch.equal(tb.moments[0].view(torch.int64), got.view(torch.int64)), (deg, tag, "batch tile 0 == single launch")
 
 
+def test_prepared_launches_match_the_operator_path_bit_for_bit(torch_gpu):
+    """The step executor (include/hsr.h ABI 4, csrc/hsr_exec.hip): step() builds an hsr_step_plan on the first call for a
+    shape and runs later calls as ONE hsr_step_run; submit() / flush() run on the native pipeline (K1 and K3 on the caller's
+    stream, the fit on a side stream, events and stream waits issued from C).  Same launches -> identical bits to the
+    operator-by-operator path (reuse_buffers=False never takes the prepared path), for float32 and uint16 cubes, masks that
+    come and go from tile to tile, a changing tile shape, and through the C ABI directly."""
+    torch = torch_gpu
+    import ctypes as C
+    from s2_emit import SpectralFusion, _engine as eng, _native as nat
+    from s2_emit.synthetic import device_problem
+    p = device_problem(96, 80, 285, deg=3, seed=21)
+    q = device_problem(64, 100, 285, deg=3, seed=22)
+    g = torch.Generator(device="cuda")
+    g.manual_seed(3)
+    mask = (torch.rand(96 * 80, generator=g, device="cuda") > 0.25).to(torch.uint8)
+    for kind in ("f32", "u16"):
+        cube_p = p.cube if kind == "f32" else eng.tile_encode_u16(p.cube)
+        cube_q = q.cube if kind == "f32" else eng.tile_encode_u16(q.cube)
+        plan = SpectralFusion(p.emit_w, p.srf, p.good_mask, deg=3, min_valid=0.0, min_count=5, apply_mask=True)
+        ref = SpectralFusion(p.emit_w, p.srf, p.good_mask, deg=3, min_valid=0.0, min_count=5, apply_mask=True)
+
+        def same(a, b, tag):
+            for f in ("pseudo", "matched"):
+                assert torch.equal(getattr(a, f).view(torch.int32), getattr(b, f).view(torch.int32)), (kind, tag, f)
+            for f in ("moments", "coeffs"):
+                assert torch.equal(getattr(a, f).view(torch.int64), getattr(b, f).view(torch.int64)), (kind, tag, f)
+        for rep in range(3):                                   # call 0 builds the plan, calls 1-2 run it
+            for tag, (c, r, m) in {"p": (cube_p, p.real, None), "p+mask": (cube_p, p.real, mask), "q": (cube_q, q.real, None)}.items():
+                got = plan.step(c, r, m)
+                want = ref.step(c, r, m, reuse_buffers=False)
+                same(got, want, (tag, rep))
+        assert len(plan._native) == 3 and len(ref._native) == 0
+        # pipeline: tiles alternate shape-compatible inputs and masks; every finished tile equals its own step()
+        pipe = SpectralFusion(p.emit_w, p.srf, p.good_mask, deg=3, min_valid=0.0, min_count=5, apply_mask=True)
+        seq = [(cube_p, p.real, None), (cube_p, p.real, mask), (cube_p.clone(), p.real.clone(), None), (cube_p, p.real, mask)]
+        outs = []
+        for c, r, m in seq:
+            o = pipe.submit(c, r, m)
+            if o is not None:
+                outs.append((o.pseudo.clone(), o.matched.clone(), o.moments.clone(), o.coeffs.clone()))
+        o = pipe.flush()
+        outs.append((o.pseudo.clone(), o.matched.clone(), o.moments.clone(), o.coeffs.clone()))
+        assert pipe.flush() is None and len(outs) == len(seq)
+        for (c, r, m), got in zip(seq, outs):
+            want = ref.step(c, r, m, reuse_buffers=False)
+            assert torch.equal(got[0].view(torch.int32), want.pseudo.view(torch.int32)), kind
+            assert torch.equal(got[1].view(torch.int32), want.matched.view(torch.int32)), kind
+            assert torch.equal(got[2].view(torch.int64), want.moments.view(torch.int64)), kind
+            assert torch.equal(got[3].view(torch.int64), want.coeffs.view(torch.int64)), kind
+        # a new tile shape rebuilds the pipeline (the tile in flight is finished first)
+        assert pipe.submit(cube_q, q.real) is None
+        same(pipe.flush(), ref.step(cube_q, q.real, reuse_buffers=False), "pipeline, new shape")
+        plan.close(); pipe.close()
+        assert plan._native == {} and plan._native_handles == []
+    # the C ABI's own argument checks
+    lib = nat.load()
+    h = C.c_void_p()
+    d = nat.StepDesc()
+    assert lib.hsr_step_plan_create(C.byref(d), C.byref(h)) == 1 and b"hsr_step_plan_create" in lib.hsr_last_error()
+    assert lib.hsr_step_run(None, None, None, None, None) == 1
+    assert lib.hsr_pipeline_flush(None, None, None, None) == 1 and lib.hsr_pipeline_count(None) == -1
+
+
 def test_padded_rows_are_owned_and_zeroed(torch_gpu):
     """Pixel-major outputs with padded rows (nb = 3 -> 4, nb = 13 -> 16): the pad columns come back as zeros, never as
     whatever the LDS staging area held - in K1, through K3 ('channels >= nb pass through'), float32 and uint16."""

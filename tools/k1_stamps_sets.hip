@@ -11,7 +11,7 @@
 #include <vector>
 #include <algorithm>
 #include "../include/hsr.h"
-namespace hsr { extern unsigned long long* g_stamp_buffer; extern unsigned long long* g_stamp_buffer2; }
+namespace hsr { extern unsigned long long* g_stamp_buffer; extern unsigned long long* g_stamp_buffer2; extern uint32_t* g_stamp_buffer3; }
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
 
 int main(int argc, char** argv) {
@@ -51,6 +51,7 @@ int main(int argc, char** argv) {
   }
   hsr::g_stamp_buffer = d_st;
   unsigned long long* d_st2; CK(hipMalloc(&d_st2, (size_t)G * 4 * 8)); hsr::g_stamp_buffer2 = d_st2;
+  uint32_t* d_st3; CK(hipMalloc(&d_st3, (size_t)G * 64 * 4)); CK(hipMemset(d_st3, 0, (size_t)G * 64 * 4)); hsr::g_stamp_buffer3 = d_st3;
   const char* nm[6] = {"issue glds", "wait tile", "scan", "compute+store+mom", "end barrier", "iteration"};
   hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
   int slots = 0;
@@ -96,6 +97,13 @@ int main(int argc, char** argv) {
       for (int x = 0; x < 8; ++x) printf("  %d:%d %.1f %.1f", x, xn[x], xn[x] ? xsum[x] / xn[x] : 0.0, xmax[x]);
       printf("\n");
       CK(hipMemset(d_st2, 0, (size_t)G * 4 * 8));
+      // per round (= one contiguous 37 MB stretch of the cube: groups k*512 .. k*512+511): mean iteration time over the workgroups
+      std::vector<uint32_t> h3((size_t)G * 64);
+      CK(hipMemcpy(h3.data(), d_st3, h3.size() * 4, hipMemcpyDeviceToHost));
+      printf("      us per round:");
+      for (int k = 0; k < 32; ++k) { double sm = 0; int n = 0; for (int b = 0; b < 512; ++b) if (h3[(size_t)b * 64 + k]) { sm += h3[(size_t)b * 64 + k]; ++n; } printf(" %.2f", n ? sm / n * 0.01 : 0.0); }
+      printf("\n");
+      CK(hipMemset(d_st3, 0, (size_t)G * 64 * 4));
     }
   }
   return 0;

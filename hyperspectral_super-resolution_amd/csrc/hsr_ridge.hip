@@ -341,6 +341,20 @@ struct PredArgs {
 
 // predict_cube_logit's rule for unusable pixels (Spectral_matching.ipynb raw lines 197-203): any input non-finite, or
 // close to the nodata value in torch.isclose's sense (|x - nd| <= 1e-8 + 1e-5 |nd|, equal infinities close, NaN never).
+// Epilogue of the predict103 kernels.  r03 (rocprofv3 PMC: matrix pipe busy 57 % of the SIMD cycles, 88 k wave-cycles per
+// tile of which 55 k are MFMA): the first version loaded the bias of each of a lane's 16 x TT targets inside the tile loop,
+// every load in its own exec-masked block behind `trg < T` with its own s_waitcnt - ~0.5 k cycles of exposed latency each,
+// 24 k per tile - and evaluated 1 / (1 + e) as an IEEE division (10 instructions).  The targets of a lane do not depend on
+// the tile, so the bias values are loaded ONCE before the tile loop and the accumulators start from them; the sigmoid uses
+// v_rcp_f32 (1 ulp; the bar is 1e-4 in reflectance); only the store stays behind `trg < T`.
+__device__ __forceinline__ float predict_activation(float v, int act) {
+  if (act) {
+    v = v < -50.0f ? -50.0f : (v > 50.0f ? 50.0f : v);   // NaN falls through, like np.clip
+    v = __builtin_amdgcn_rcpf(1.0f + __expf(-v));
+  }
+  return v;
+}
+
 __device__ __forceinline__ bool pred_bad_input(float x, int use_nodata, float nd) {
   const bool nonfinite = (__float_as_uint(x) & 0x7f800000u) == 0x7f800000u;
   const bool close = use_nodata && (x == nd || fabsf(x - nd) <= 1e-8f + 1e-5f * fabsf(nd));
@@ -415,11 +429,7 @@ __global__ __launch_bounds__(kPredThreads) void predict_kernel(const PredArgs a)
           const int trg = tt * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
           const int64_t p = p0 + ph + j;
           if (trg < a.T && p < a.npix) {
-            float v = acc[q][r] + a.bias[trg];
-            if (a.act) {
-              v = v < -50.0f ? -50.0f : (v > 50.0f ? 50.0f : v);   // NaN falls through, like np.clip
-              v = 1.0f / (1.0f + __expf(-v));
-            }
+            float v = predict_activation(acc[q][r] + a.bias[trg], a.act);
             if (badl[ph + j]) v = __uint_as_float(0x7fc00000u);
             a.out[(size_t)trg * a.out_stride + p] = v;
           }
@@ -496,6 +506,7 @@ __device__ __forceinline__ void mfma_steps103(const float (&z)[11], int kh, cons
   }
 }
 
+
 template <int TT, bool WHOLE>
 __global__ __launch_bounds__(256, 2) void predict103_kernel(const PredArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -510,24 +521,42 @@ __global__ __launch_bounds__(256, 2) void predict103_kernel(const PredArgs a) {
     }
     __syncthreads();
   }
+  float bv[TT][16];                                 // bias of this lane's targets: tile-invariant
+#pragma unroll
+  for (int q = 0; q < TT; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int trg = q * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+      bv[q][r] = trg < a.T ? a.bias[trg] : 0.0f;
+    }
+  // the 10 inputs of the NEXT tile are loaded while this tile's MFMA chain runs (a fresh load at the top of every tile left
+  // the matrix pipe idle for one HBM latency per tile: ~2 us of a 9-27 us tile)
+  float xn[10];
+  auto load_inputs = [&](int64_t tile_) {
+    const int64_t p_ = tile_ * 128 + wave * 32 + j;
+    const int64_t pc_ = p_ < a.npix ? p_ : a.npix - 1;
+#pragma unroll
+    for (int c = 0; c < 10; ++c) xn[c] = a.x[pc_ * a.x_ps + c * a.x_cs];
+  };
+  if ((int64_t)blockIdx.x * 128 < a.npix) load_inputs(blockIdx.x);
   for (int64_t tile = blockIdx.x; tile * 128 < a.npix; tile += gridDim.x) {
     const int64_t p = tile * 128 + wave * 32 + j;
-    const int64_t pc = p < a.npix ? p : a.npix - 1;
     float z[11];
     bool bad = false;
 #pragma unroll
     for (int c = 0; c < 10; ++c) {
-      const float xr = a.x[pc * a.x_ps + c * a.x_cs];
+      const float xr = xn[c];
       bad = bad || pred_bad_input(xr, a.use_nodata, a.nodata);
       z[c] = (xr - a.mean[c]) * a.inv[c];
     }
     bad = bad && a.nan_bad != 0;
     z[10] = 1.0f;
+    if ((tile + gridDim.x) * 128 < a.npix) load_inputs(tile + gridDim.x);
     f32x16 acc[TT];
 #pragma unroll
     for (int q = 0; q < TT; ++q)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
+      for (int r = 0; r < 16; ++r) acc[q][r] = bv[q][r];
     if (WHOLE) {
       mfma_steps103<0, kSteps103, TT>(z, kh, wl, Tp, 0, j, acc);
     } else {
@@ -569,15 +598,9 @@ __global__ __launch_bounds__(256, 2) void predict103_kernel(const PredArgs a) {
         for (int r = 0; r < 16; ++r) {
           const int tu = q * 32 + (r & 3) + 8 * (r >> 2);      // wave-uniform part of the target index
           const int trg = tu + 4 * kh;
-          if (trg < tmax) {
-            float v = acc[q][r] + a.bias[trg];
-            if (a.act) {
-              v = v < -50.0f ? -50.0f : (v > 50.0f ? 50.0f : v);
-              v = 1.0f / (1.0f + __expf(-v));
-            }
-            if (bad) v = __uint_as_float(0x7fc00000u);
-            orow[(size_t)tu * ostride] = v;
-          }
+          float v = predict_activation(acc[q][r], a.act);
+          if (bad) v = __uint_as_float(0x7fc00000u);
+          if (trg < tmax) orow[(size_t)tu * ostride] = v;
         }
       }
     }
@@ -604,24 +627,40 @@ __global__ __launch_bounds__(512, 2) void predict103_slice_kernel(const PredArgs
     wl[i] = t0 + c < a.T ? a.W[(size_t)r * a.ldw + t0 + c] : 0.0f;
   }
   __syncthreads();
+  float bv[TT][16];                                    // bias of this lane's targets: tile-invariant
+#pragma unroll
+  for (int q = 0; q < TT; ++q)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int trg = t0 + q * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+      bv[q][r] = trg < a.T ? a.bias[trg] : 0.0f;
+    }
+  float xn[10];                                        // inputs of the next tile, loaded under this tile's MFMA chain
+  auto load_inputs = [&](int64_t tile_) {
+    const int64_t p_ = tile_ * 256 + wave * 32 + j;
+    const int64_t pc_ = p_ < a.npix ? p_ : a.npix - 1;
+#pragma unroll
+    for (int c = 0; c < 10; ++c) xn[c] = a.x[pc_ * a.x_ps + c * a.x_cs];
+  };
+  if ((int64_t)blockIdx.x * 256 < a.npix) load_inputs(blockIdx.x);
   for (int64_t tile = blockIdx.x; tile * 256 < a.npix; tile += gridDim.x) {
     const int64_t p = tile * 256 + wave * 32 + j;
-    const int64_t pc = p < a.npix ? p : a.npix - 1;
     float z[11];
     bool bad = false;
 #pragma unroll
     for (int c = 0; c < 10; ++c) {
-      const float xr = a.x[pc * a.x_ps + c * a.x_cs];
+      const float xr = xn[c];
       bad = bad || pred_bad_input(xr, a.use_nodata, a.nodata);
       z[c] = (xr - a.mean[c]) * a.inv[c];
     }
     bad = bad && a.nan_bad != 0;
     z[10] = 1.0f;
+    if ((tile + gridDim.x) * 256 < a.npix) load_inputs(tile + gridDim.x);
     f32x16 acc[TT];
 #pragma unroll
     for (int q = 0; q < TT; ++q)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[q][r] = 0.0f;
+      for (int r = 0; r < 16; ++r) acc[q][r] = bv[q][r];
     mfma_steps103<0, kSteps103, TT>(z, kh, wl, Tp, 0, j, acc);
     if (p < a.npix) {
       int64_t ostride = a.out_stride;
@@ -634,15 +673,9 @@ __global__ __launch_bounds__(512, 2) void predict103_slice_kernel(const PredArgs
         for (int r = 0; r < 16; ++r) {
           const int tu = q * 32 + (r & 3) + 8 * (r >> 2);
           const int trg = t0 + tu + 4 * kh;
-          if (trg < tmax) {
-            float v = acc[q][r] + a.bias[trg];
-            if (a.act) {
-              v = v < -50.0f ? -50.0f : (v > 50.0f ? 50.0f : v);
-              v = 1.0f / (1.0f + __expf(-v));
-            }
-            if (bad) v = __uint_as_float(0x7fc00000u);
-            orow[(size_t)tu * ostride] = v;
-          }
+          float v = predict_activation(acc[q][r], a.act);
+          if (bad) v = __uint_as_float(0x7fc00000u);
+          if (trg < tmax) orow[(size_t)tu * ostride] = v;
         }
       }
     }

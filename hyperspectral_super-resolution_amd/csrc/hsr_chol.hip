@@ -9,11 +9,11 @@
 //                       (block 32): diagonal block factored in LDS with one barrier per column, the panel below
 //                       staged in LDS and solved four lanes per row, the trailing matrix updated from the
 //                       LDS-resident panel in 16 x 16 tiles on v_mfma_f64_16x16x4_f64.
-//   chol_diag_inverse_kernel  inverses of the diagonal blocks, so that
-//   chol_solve_kernel   (forward and backward substitution, one wave per right-hand side) needs a 32 x 32
-//                       matrix-vector product per block instead of a serial 32-step chain; the updates below /
-//                       above are matrix-vector products read along rows of L (forward) / along columns, which is
-//                       the coalesced direction of the row-major factor (backward).
+//                       The inverse of every diagonal block rides along with its factorisation (r03) and is what the
+//                       panel is multiplied with; the inverses also go to the workspace, so that
+//   chol_solve_kernel   (forward and backward substitution, blocked: one workgroup per slab of 32 right-hand sides held
+//                       in LDS) needs a 32 x 32 product with the block inverse instead of a serial 32-step chain, and
+//                       updates the other rows with 16 x 16 tiles of L on v_mfma_f64_16x16x4_f64.
 // n must be a multiple of 32 (the caller pads with an identity block), n <= 512.
 #include <math.h>
 
@@ -21,8 +21,20 @@
 
 namespace hsr {
 
+#ifdef HSR_CHOL_STAMPS          // diagnostic build only (tools/chol_stamps.hip): s_memtime per phase of the factor kernel
+unsigned long long* g_chol_stamps = nullptr;   // [16 blocks][8 phases], device memory
+#define CHOL_STAMP_PARAM , unsigned long long* stamps
+#define CHOL_STAMP_ARG , hsr::g_chol_stamps
+#define CHOL_STAMP(k) do { if (tid == 0 && stamps) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); stamps[(kb / kCb) * 8 + (k)] = t_; } } while (0)
+#else
+#define CHOL_STAMP_PARAM
+#define CHOL_STAMP_ARG
+#define CHOL_STAMP(k)
+#endif
 constexpr int kCb = 32;        // block size
 constexpr int kCs = kCb + 1;   // LDS row stride (doubles)
+constexpr int kTrailTiles = 5; // trailing-update tiles a wave loads before its first MFMA (9 = one pass at n = 288 spilled 75 VGPRs
+                               // under the 128-register cap of a 1024-thread workgroup and was 35 % slower)
 
 typedef double chol_f64x4 __attribute__((ext_vector_type(4)));
 
@@ -53,68 +65,106 @@ __device__ __forceinline__ double quad_sum(double v) {
 // (1 byte of LDS per fma; same peak as the vector unit on CDNA4, but reachable), a wave's tiles loaded from global
 // memory up front so that their latency hides under the matrix instructions; the diagonal block multiplies by a
 // Newton-refined reciprocal instead of dividing.
-__global__ __launch_bounds__(1024) void chol_factor_kernel(double* __restrict__ A, int64_t lda, int n, int* info) {
+__global__ __launch_bounds__(1024) void chol_factor_kernel(double* __restrict__ A, int64_t lda, int n, int* info,
+                                                           double* __restrict__ dinv /* [n/32][32][32]: inverses of the diagonal blocks of L */
+                                                           CHOL_STAMP_PARAM) {
   extern __shared__ __attribute__((aligned(16))) double chol_lds[];
   double (*D)[kCs] = reinterpret_cast<double (*)[kCs]>(chol_lds);                      // diagonal block
   double (*P)[kCs] = reinterpret_cast<double (*)[kCs]>(chol_lds + kCb * kCs);           // panel below, (n - 32) rows
   __shared__ int bad_pivot;
-  __shared__ double invd[kCb];
+  // r03: the inverse of the diagonal block rides along with its factorisation.  The column steps below are Gaussian
+  // elimination with multipliers f_ij = D[i][j] / D[j][j]; applying the same row operations to the identity (E, done by the
+  // threads of the upper triangle, which were idle) gives the inverse of the unit-lower factor, and L_kk^-1 =
+  // diag(1 / L_ii) E.  With it the panel below is ONE small matrix product on the matrix cores (X = P L_kk^-T) instead of
+  // a 32-step substitution chain per row (30 % of the kernel in r02's cycle stamps), and chol_diag_inverse_kernel - which
+  // recomputed the same inverses for the substitution - is gone.
+  __shared__ double E[kCb][kCs];       // E[i][c], i > c: strictly lower part of the unit-lower inverse (diagonal = 1)
+  __shared__ double Minv[kCb][kCs];    // L_kk^-1, lower triangular, upper part zero
   const int tid = threadIdx.x, ti = tid >> 5, tj = tid & 31;
   const int lane = tid & 63, wave = tid >> 6;
   if (tid == 0) {
     *info = 0;
     bad_pivot = 0x7fffffff;
   }
+  // tile t of the trailing update's lower triangle -> its tile row (t = bi (bi + 1) / 2 + bj); the same for every block step
+  __shared__ unsigned char tile_row[480];                   // n <= 512: at most 30 tile rows = 465 tiles
+  if (tid < 480) {
+    int bi = (int)((sqrtf(8.0f * (float)tid + 1.0f) - 1.0f) * 0.5f);
+    while ((bi + 1) * (bi + 2) / 2 <= tid) ++bi;
+    while (bi * (bi + 1) / 2 > tid) --bi;
+    tile_row[tid] = (unsigned char)bi;
+  }
   for (int kb = 0; kb < n; kb += kCb) {
     const int m = n - kb - kCb;   // rows below the diagonal block
+    CHOL_STAMP(0);
     D[ti][tj] = tj <= ti ? A[(int64_t)(kb + ti) * lda + kb + tj] : 0.0;
+    E[ti][tj] = 0.0;
     for (int e = tid; e < m * kCb; e += 1024) P[e >> 5][e & 31] = A[(int64_t)(kb + kCb + (e >> 5)) * lda + kb + (e & 31)];
     __syncthreads();
+    CHOL_STAMP(1);
     // 32 x 32 block, one barrier per column: the Schur update of step j is applied with the UNSCALED column j
     // (D[i][l] -= D[i][j] D[l][j] / D[j][j]); D[j][j] is then the squared pivot and the columns are scaled once at
     // the end.  (Scaling each column first needs three barriers per step: 96 instead of 33 per block.)
+    // r03 cycle stamps: this loop is ~48 % of the kernel at ~620 cycles per column step.  Two restructurings were built to parity
+    // and measured slower, so the loop stays as it is: two columns per barrier with a rank-2 update (1 350 cycles per pair), and
+    // the next pivot's reciprocal computed one step ahead next to the update (+6 %).  The step is not bound by the reciprocal
+    // chain or by the barrier count but by the LDS round trips of the 16 waves.
     for (int j = 0; j < kCb - 1; ++j) {
-      if (ti > j && tj > j && tj <= ti) D[ti][tj] -= D[ti][j] * D[tj][j] * rcp_nr(D[j][j]);
+      if (ti > j && tj > j && tj <= ti) {
+        D[ti][tj] -= D[ti][j] * D[tj][j] * rcp_nr(D[j][j]);
+      } else if (tj > j && ti <= j) {                 // upper-triangle thread (ti, tj): element E[tj][ti], updated for ti <= j < tj
+        const double f = D[tj][j] * rcp_nr(D[j][j]);  // multiplier of row tj in step j (column j is final by now)
+        E[tj][ti] -= f * (ti == j ? 1.0 : E[j][ti]);  // row j of E is final (only steps < j touch it)
+      }
       __syncthreads();
     }
-    double piv = 1.0;
+    CHOL_STAMP(2);
+    double piv = 1.0, rpiv_row = 1.0;
     if (tj <= ti) {
       const double d = D[tj][tj];
       if (ti == tj && !(d > 0.0)) atomicMin(&bad_pivot, kb + tj + 1);   // LAPACK: index of the first non-positive pivot
       piv = sqrt(d);
+      rpiv_row = 1.0 / sqrt(D[ti][ti]);
     }
     __syncthreads();
     if (tid == 0 && *info == 0 && bad_pivot != 0x7fffffff) *info = bad_pivot;
-    if (tj <= ti) {
-      const double l = ti == tj ? piv : D[ti][tj] / piv;
-      D[ti][tj] = l;
-      A[(int64_t)(kb + ti) * lda + kb + tj] = l;
-      if (ti == tj) invd[ti] = 1.0 / piv;
+    {
+      double mi = 0.0;
+      if (tj <= ti) {
+        const double l = ti == tj ? piv : D[ti][tj] / piv;
+        A[(int64_t)(kb + ti) * lda + kb + tj] = l;
+        mi = (ti == tj ? 1.0 : E[ti][tj]) * rpiv_row;                   // L_kk^-1 = diag(1 / L_ii) E
+      }
+      Minv[ti][tj] = mi;
+      dinv[((size_t)(kb / kCb) * kCb + ti) * kCb + tj] = mi;
     }
     __syncthreads();
-    // panel below: row r solves x L^T = a.  Four lanes per row; lane q owns x[q], x[q+4], ..  D's upper triangle is zero
-    // and x starts at zero, so every partial dot product may run over all of a lane's columns below c.
-    for (int r = tid >> 2; r < m; r += 256) {
-      const int q = tid & 3;
-      double x[kCb / 4];
+    CHOL_STAMP(3);
+    // panel below: X = P L_kk^-T, i.e. X[r][c] = sum_k P[r][k] Minv[c][k], on the float64 matrix cores.  One wave per 16 rows
+    // does both 16-column halves: all of its A operands are in registers before the first result is written back to P.
+    {
+      const int col = lane & 15, kk = lane >> 4;
+      for (int I = wave; I < (m >> 4); I += 16) {
+        double av[kCb / 4];
 #pragma unroll
-      for (int k = 0; k < kCb / 4; ++k) x[k] = 0.0;
+        for (int st = 0; st < kCb / 4; ++st) av[st] = P[16 * I + col][4 * st + kk];
+        chol_f64x4 x0 = {0.0, 0.0, 0.0, 0.0}, x1 = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int c = 0; c < kCb; ++c) {
-        double part = 0.0;
+        for (int st = 0; st < kCb / 4; ++st) {
+          x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[st], Minv[col][4 * st + kk], x0, 0, 0, 0);
+          x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[st], Minv[16 + col][4 * st + kk], x1, 0, 0, 0);
+        }
 #pragma unroll
-        for (int k = 0; k < kCb / 4; ++k)
-          if (4 * k < c) part = fma(x[k], D[c][q + 4 * k], part);
-        part = quad_sum(part);
-        const double xc = (P[r][c] - part) * invd[c];
-        if (q == (c & 3)) {
-          x[c >> 2] = xc;
-          P[r][c] = xc;
+        for (int g = 0; g < 4; ++g) {
+          P[16 * I + kk + 4 * g][col] = x0[g];
+          P[16 * I + kk + 4 * g][16 + col] = x1[g];
         }
       }
     }
     __syncthreads();
+    CHOL_STAMP(4);
     for (int e = tid; e < m * kCb; e += 1024) A[(int64_t)(kb + kCb + (e >> 5)) * lda + kb + (e & 31)] = P[e >> 5][e & 31];
+    CHOL_STAMP(5);
     // trailing update, lower triangle in 16 x 16 tiles on the float64 matrix cores: C[I][J] -= P_I P_J^T.
     // Lane (col = lane & 15, kk = lane >> 4): A operand P[16 I + col][4 s + kk], B operand P[16 J + col][4 s + kk],
     // accumulator register g = element (row kk + 4 g, column col) of the tile (layout as in csrc/hsr_ridge.hip).
@@ -122,17 +172,14 @@ __global__ __launch_bounds__(1024) void chol_factor_kernel(double* __restrict__ 
       const int mt = m >> 4;                       // m is a multiple of 32
       const int ntile = mt * (mt + 1) / 2;
       const int col = lane & 15, kk = lane >> 4;
-      constexpr int kMaxTiles = 30;                // n <= 512: 30 tile rows -> 465 tiles over 16 waves
-      for (int t0 = wave; t0 < ntile; t0 += 16 * 5) {
-        double creg[5][4];
-        int bis[5], bjs[5];
+      for (int t0 = wave; t0 < ntile; t0 += 16 * kTrailTiles) {
+        double creg[kTrailTiles][4];
+        int bis[kTrailTiles], bjs[kTrailTiles];
 #pragma unroll
-        for (int u = 0; u < 5; ++u) {
+        for (int u = 0; u < kTrailTiles; ++u) {
           const int t = t0 + 16 * u;
-          int bi = (int)((sqrt(8.0 * (double)(t < ntile ? t : 0) + 1.0) - 1.0) * 0.5);
-          while ((bi + 1) * (bi + 2) / 2 <= t && bi < kMaxTiles) ++bi;
-          while (bi * (bi + 1) / 2 > t && bi > 0) --bi;
-          bis[u] = bi;
+          const int bi = tile_row[t < ntile ? t : 0];      // table built once per launch (r03: a float64 sqrt and two
+          bis[u] = bi;                                     // correction loops per tile were part of the 39 % this phase took)
           bjs[u] = (t < ntile ? t : 0) - bi * (bi + 1) / 2;
           if (t < ntile) {
             const double* src = A + (int64_t)(kb + kCb + 16 * bi + kk) * lda + kb + kCb + 16 * bjs[u] + col;
@@ -141,7 +188,7 @@ __global__ __launch_bounds__(1024) void chol_factor_kernel(double* __restrict__ 
           }
         }
 #pragma unroll
-        for (int u = 0; u < 5; ++u) {
+        for (int u = 0; u < kTrailTiles; ++u) {
           const int t = t0 + 16 * u;
           if (t < ntile) {
             chol_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
@@ -157,95 +204,113 @@ __global__ __launch_bounds__(1024) void chol_factor_kernel(double* __restrict__ 
       }
     }
     __syncthreads();
+    CHOL_STAMP(6);
   }
 }
 
-// Inverses of the 32 x 32 diagonal blocks of L (one workgroup of 128 threads per block): with them the substitution below
-// needs no serial 32-step chain per block, only a 32 x 32 matrix-vector product.  X L^T = I gives X = L^-T, solved row by
-// row exactly like a panel row of the factorisation (four lanes per row, reciprocals of the diagonal), and stored
-// transposed.  (First version: one thread per column, a division per step: 26 us.)
-__global__ __launch_bounds__(128) void chol_diag_inverse_kernel(const double* __restrict__ L, int64_t lda,
-                                                                double* __restrict__ dinv /* [n/32][32][32] */) {
-  __shared__ double D[kCb][kCs], X[kCb][kCs], invd[kCb];
-  const int kb = blockIdx.x * kCb, tid = threadIdx.x;
-  for (int e = tid; e < kCb * kCb; e += 128) {
-    const int r = e >> 5, c = e & 31;
-    D[r][c] = c <= r ? L[(int64_t)(kb + r) * lda + kb + c] : 0.0;
-    if (r == c) invd[r] = 1.0 / D[r][c];
-  }
-  __syncthreads();
-  {
-    const int r = tid >> 2, q = tid & 3;             // row r of X = row r of L^-T
-    double x[kCb / 4];
-#pragma unroll
-    for (int k = 0; k < kCb / 4; ++k) x[k] = 0.0;
-#pragma unroll
-    for (int c = 0; c < kCb; ++c) {
-      double part = 0.0;
-#pragma unroll
-      for (int k = 0; k < kCb / 4; ++k)
-        if (4 * k < c) part = fma(x[k], D[c][q + 4 * k], part);
-      part = quad_sum(part);
-      const double xc = ((r == c ? 1.0 : 0.0) - part) * invd[c];
-      if (q == (c & 3)) {
-        x[c >> 2] = xc;
-        X[r][c] = xc;
-      }
-    }
-  }
-  __syncthreads();
-  for (int e = tid; e < kCb * kCb; e += 128) {
-    const int r = e >> 5, c = e & 31;
-    dinv[((size_t)blockIdx.x * kCb + r) * kCb + c] = X[c][r];    // L^-1 = (L^-T)^T
-  }
-}
-
-// L y = b, then L^T x = y, in place in column `col` of B.  One wave per column; 4 waves per workgroup.
-__global__ __launch_bounds__(256) void chol_solve_kernel(const double* __restrict__ L, int64_t lda, int n,
-                                                         const double* __restrict__ dinv, double* __restrict__ B,
-                                                         int64_t ldb, int T) {
+// L y = b, then L^T x = y, in place in B - blocked, on the float64 matrix cores.  One workgroup of 1024 threads per slab
+// of 32 right-hand sides; the slab lives in LDS (Y, n x 32) for the whole solve.  Per 32-row block k, forward:
+//     X   = Linv_kk  Y_k                      four 16 x 16 tiles (waves 0-3), 8 MFMA steps each
+//     Y_r -= L_rk X   for the rows r below    (n - kb - 32) / 16 x 2 tiles over the 16 waves, L read from global (L2)
+// and backward the same with Linv_kk^T and L^T (whose tiles are read along the coalesced direction of the row-major
+// factor).  Round 2 ran one wave per right-hand side with matrix-VECTOR products: every wave re-read all of L and the
+// block inverses with one 8-byte load per multiply-add - 92 us for 32 right-hand sides (r03 rocprofv3), most of it load
+// latency.  Here a tile of L is read once per slab and feeds 32 right-hand sides.
+// MFMA operand layout (as in chol_factor_kernel): lane (col = lane & 15, kk = lane >> 4) supplies A[16 I + col][4 s + kk]
+// and B^T[16 J + col][4 s + kk]; accumulator register g is element (row kk + 4 g, column col) of the tile.
+constexpr int kYs = kCb + 1;   // LDS row stride of the slab
+constexpr int kSolveTiles = 2; // update tiles per wave whose L operands are prefetched: n = 288 -> 32 tiles over 16 waves
+__global__ __launch_bounds__(1024) void chol_solve_kernel(const double* __restrict__ L, int64_t lda, int n,
+                                                          const double* __restrict__ dinv, double* __restrict__ B,
+                                                          int64_t ldb, int T, int dinv_in_lds) {
   extern __shared__ __attribute__((aligned(16))) double solve_lds[];
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int col = blockIdx.x * 4 + wave;
-  double* y = solve_lds + (size_t)wave * (n + kCb);
-  double* xb = y + n;            // the block solution being formed (32 values)
-  if (col >= T) return;          // no barriers below: every wave works on its own slice of LDS
-  for (int r = lane; r < n; r += 64) y[r] = B[(int64_t)r * ldb + col];
-  const int c = lane & 31;
-  // ---- forward: blocks top to bottom
-  for (int kb = 0; kb < n; kb += kCb) {
-    const double* di = dinv + ((size_t)(kb / kCb) * kCb + c) * kCb;   // row c of the block's inverse
-    double s = 0.0;
+  double (*Y)[kYs] = reinterpret_cast<double (*)[kYs]>(solve_lds);
+  double (*X)[kYs] = reinterpret_cast<double (*)[kYs]>(solve_lds + (size_t)n * kYs);
+  double* dl = solve_lds + (size_t)(n + kCb) * kYs;        // all block inverses, when they fit (n <= 288)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 15, kk = lane >> 4;
+  const int c0 = blockIdx.x * kCb;
+  for (int e = tid; e < n * kCb; e += 1024) {
+    const int r = e >> 5, c = e & 31;
+    Y[r][c] = c0 + c < T ? B[(int64_t)r * ldb + c0 + c] : 0.0;
+  }
+  if (dinv_in_lds)
+    for (int e = tid; e < n * kCb; e += 1024) dl[e] = dinv[e];
+  __syncthreads();
+  const double* dsrc = dinv_in_lds ? dl : dinv;
+#pragma unroll 1
+  for (int pass = 0; pass < 2; ++pass) {                 // 0: forward with L, 1: backward with L^T
+    const int64_t sr = pass == 0 ? lda : 1, sc = pass == 0 ? 1 : lda;    // L (forward) or L^T (backward) element (r, c)
+    const int dr = pass == 0 ? kCb : 1, dc = pass == 0 ? 1 : kCb;        // the same for the block inverse
+#pragma unroll 1
+    for (int step = 0; step < n / kCb; ++step) {
+      const int kb = pass == 0 ? step * kCb : n - kCb - step * kCb;
+      // (1) this wave's tiles of L for the update of the other rows: they do not depend on X, so their loads go out
+      //     first and their L2 latency runs under the block solve and its barrier
+      const int r0 = pass == 0 ? kb + kCb : 0;
+      const int ntile = (pass == 0 ? (n - kb - kCb) : kb) / 16 * 2;
+      double av[kSolveTiles][kCb / 4];
 #pragma unroll
-    for (int p = 0; p < kCb; ++p) s += di[p] * y[kb + p];             // x_c = sum_{p <= c} Linv[c][p] y_p (rest is 0)
-    if (lane < kCb) xb[c] = s;
-    if (lane < kCb) y[kb + c] = xb[c];
-    // rows below: y[r] -= L[r][kb .. kb+31] . x
-    for (int r = kb + kCb + lane; r < n; r += 64) {
-      const double* lr = L + (int64_t)r * lda + kb;
-      double t = 0.0;
+      for (int u = 0; u < kSolveTiles; ++u) {
+        const int t = wave + 16 * u;
+        if (t < ntile) {
+          const int row = r0 + 16 * (t >> 1) + col;
 #pragma unroll
-      for (int p = 0; p < kCb; ++p) t += lr[p] * xb[p];
-      y[r] -= t;
+          for (int st = 0; st < kCb / 4; ++st) {
+            const int p = 4 * st + kk;
+            av[u][st] = L[(int64_t)row * sr + (int64_t)(kb + p) * sc];
+          }
+        }
+      }
+      // (2) X = Linv_kk Y_k (forward) / Linv_kk^T Y_k (backward)
+      const double* di = dsrc + (size_t)(kb / kCb) * kCb * kCb;          // Linv_kk, row-major
+      if (wave < 4) {
+        const int I = wave >> 1, J = wave & 1;
+        chol_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int st = 0; st < kCb / 4; ++st) {
+          const int p = 4 * st + kk;
+          const double a = di[(16 * I + col) * dr + p * dc];
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Y[kb + p][16 * J + col], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) X[16 * I + kk + 4 * g][16 * J + col] = acc[g];
+      }
+      __syncthreads();
+      Y[kb + (tid >> 5)][tid & 31] = X[tid >> 5][tid & 31];              // 32 x 32 = one element per thread
+      // (3) the other rows: below the block (forward) / above it (backward)
+#pragma unroll
+      for (int u = 0; u < kSolveTiles; ++u) {
+        const int t = wave + 16 * u;
+        if (t < ntile) {
+          const int I = t >> 1, J = t & 1;
+          chol_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+          for (int st = 0; st < kCb / 4; ++st)
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][st], X[4 * st + kk][16 * J + col], acc, 0, 0, 0);
+#pragma unroll
+          for (int g = 0; g < 4; ++g) Y[r0 + 16 * I + kk + 4 * g][16 * J + col] -= acc[g];
+        }
+      }
+      for (int t = wave + 16 * kSolveTiles; t < ntile; t += 16) {         // n > 288: the tiles beyond the prefetched ones
+        const int I = t >> 1, J = t & 1;
+        const int row = r0 + 16 * I + col;
+        chol_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int st = 0; st < kCb / 4; ++st) {
+          const int p = 4 * st + kk;
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(L[(int64_t)row * sr + (int64_t)(kb + p) * sc], X[p][16 * J + col], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int g = 0; g < 4; ++g) Y[r0 + 16 * I + kk + 4 * g][16 * J + col] -= acc[g];
+      }
+      __syncthreads();
     }
   }
-  // ---- backward: blocks bottom to top, with L^T:  x = Linv^T y
-  for (int kb = n - kCb; kb >= 0; kb -= kCb) {
-    const double* di = dinv + (size_t)(kb / kCb) * kCb * kCb;
-    double s = 0.0;
-#pragma unroll
-    for (int p = 0; p < kCb; ++p) s += di[(size_t)p * kCb + c] * y[kb + p];   // (Linv^T)[c][p] = Linv[p][c]
-    if (lane < kCb) xb[c] = s;
-    if (lane < kCb) y[kb + c] = xb[c];
-    // rows above: y[r] -= sum_p L[kb + p][r] x_p   (coalesced along r)
-    for (int r = lane; r < kb; r += 64) {
-      double t = 0.0;
-#pragma unroll
-      for (int p = 0; p < kCb; ++p) t += L[(int64_t)(kb + p) * lda + r] * xb[p];
-      y[r] -= t;
-    }
+  for (int e = tid; e < n * kCb; e += 1024) {
+    const int r = e >> 5, c = e & 31;
+    if (c0 + c < T) B[(int64_t)r * ldb + c0 + c] = Y[r][c];
   }
-  for (int r = lane; r < n; r += 64) B[(int64_t)r * ldb + col] = y[r];
 }
 
 }  // namespace hsr
@@ -267,10 +332,17 @@ extern "C" int hsr_chol_solve_f64(double* a_dev, int64_t lda, int32_t n, double*
     (void)hipGetLastError();
     configured = lds_f;
   }
-  hipLaunchKernelGGL(chol_factor_kernel, dim3(1), dim3(1024), lds_f, s, a_dev, lda, n, info_dev);
-  hipLaunchKernelGGL(chol_diag_inverse_kernel, dim3(n / kCb), dim3(128), 0, s, a_dev, lda, work_dev);
-  hipLaunchKernelGGL(chol_solve_kernel, dim3((nrhs + 3) / 4), dim3(256), (size_t)4 * (n + kCb) * sizeof(double), s, a_dev, lda, n,
-                     work_dev, b_dev, ldb, nrhs);
+  hipLaunchKernelGGL(chol_factor_kernel, dim3(1), dim3(1024), lds_f, s, a_dev, lda, n, info_dev, work_dev CHOL_STAMP_ARG);
+  size_t lds_s = ((size_t)n + kCb) * kYs * sizeof(double);
+  const int dinv_in_lds = lds_s + (size_t)n * kCb * sizeof(double) <= 160 * 1024 ? 1 : 0;
+  if (dinv_in_lds) lds_s += (size_t)n * kCb * sizeof(double);
+  static thread_local size_t configured_s = 0;
+  if (lds_s > configured_s) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s);
+    (void)hipGetLastError();
+    configured_s = lds_s;
+  }
+  hipLaunchKernelGGL(chol_solve_kernel, dim3((nrhs + kCb - 1) / kCb), dim3(1024), lds_s, s, a_dev, lda, n, work_dev, b_dev, ldb, nrhs, dinv_in_lds);
   HSR_LAUNCH_CHECK("chol kernels");
   return HSR_OK;
 }

@@ -1,0 +1,44 @@
+// Where the one-workgroup Cholesky factorisation (csrc/hsr_chol.hip) spends its cycles: s_memtime at the phase boundaries
+// of every 32-column block step.  Diagnostic build:
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 -ffp-contract=off -DHSR_CHOL_STAMPS tools/chol_stamps.hip \
+//         hyperspectral_super-resolution_amd/csrc/hsr_chol.hip hyperspectral_super-resolution_amd/csrc/hsr_lib.hip -o tools/chol_stamps
+#include <hip/hip_runtime.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+#include "../include/hsr.h"
+namespace hsr { extern unsigned long long* g_chol_stamps; }
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
+int main(int argc, char** argv) {
+  const int n = argc > 1 ? atoi(argv[1]) : 288, T = argc > 2 ? atoi(argv[2]) : 32;
+  std::vector<double> A((size_t)n * n), B((size_t)n * T, 1.0);
+  uint32_t s = 7;
+  std::vector<double> M((size_t)n * (n + 40));
+  for (auto& x : M) { s = s * 1664525u + 1013904223u; x = ((s >> 8) / 16777216.0) - 0.5; }
+  for (int i = 0; i < n; ++i) for (int j = 0; j <= i; ++j) { double v = 0; for (int k = 0; k < n + 40; ++k) v += M[(size_t)i * (n + 40) + k] * M[(size_t)j * (n + 40) + k]; v = v / n + (i == j ? 0.5 : 0.0); A[(size_t)i * n + j] = A[(size_t)j * n + i] = v; }
+  double *dA, *dB, *dW; int* dI; unsigned long long* dS;
+  CK(hipMalloc(&dA, A.size() * 8)); CK(hipMalloc(&dB, B.size() * 8)); CK(hipMalloc(&dW, hsr_chol_work_bytes(n))); CK(hipMalloc(&dI, 4)); CK(hipMalloc(&dS, 16 * 8 * 8));
+  hsr::g_chol_stamps = dS;
+  const char* nm[6] = {"load D, P -> LDS", "31 column steps", "sqrt, scale, inverse", "panel = P Linv^T (MFMA)", "panel -> global", "trailing update"};
+  for (int rep = 0; rep < 3; ++rep) {
+    CK(hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dB, B.data(), B.size() * 8, hipMemcpyHostToDevice));
+    CK(hipMemset(dS, 0, 16 * 8 * 8));
+    hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+    CK(hipEventRecord(e0, 0));
+    if (hsr_chol_solve_f64(dA, n, n, dB, T, T, dW, dI, 0)) { printf("error %s\n", hsr_last_error()); return 1; }
+    CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+    float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+    unsigned long long h[16 * 8]; CK(hipMemcpy(h, dS, sizeof h, hipMemcpyDeviceToHost));
+    double ph[6] = {0}; double tot = 0;
+    for (int b = 0; b < n / 32; ++b) for (int k = 0; k < 6; ++k) { ph[k] += (double)(h[b * 8 + k + 1] - h[b * 8 + k]); }
+    for (int k = 0; k < 6; ++k) tot += ph[k];
+    printf("rep %d: factor + solve %.1f us (events); factor kernel %.0f cycles over %d block steps\n", rep, ms * 1e3, tot, n / 32);
+    if (rep == 2) {
+      for (int k = 0; k < 6; ++k) printf("  %-28s %9.0f cycles  %5.1f %%\n", nm[k], ph[k], 100 * ph[k] / tot);
+      printf("  per block step (cycles):");
+      for (int b = 0; b < n / 32; ++b) printf(" %llu", h[b * 8 + 6] - h[b * 8]);
+      printf("\n");
+    }
+  }
+  return 0;
+}

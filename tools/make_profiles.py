@@ -70,16 +70,19 @@ def main():
                     w.writerow(r)
     # ---- fresh processes
     out = [f"# {tag}: the headline over fresh processes (one box, back to back)\n",
-           "`python bench.py --steps 100 --no-cpu-baseline` six times, then `--gpus 1 --steps 20 --warmup 5` (the driver's command) three times.\n",
-           "| run | steps | ms/step | K1+K2 ms (HIP events) | frac of 8 TB/s | placement trials (ms) |", "|---|---|---|---|---|---|"]
+           "`python bench.py --steps 100 --no-cpu-baseline` four times, then `--gpus 1 --steps 20 --warmup 5` (the driver's command) three times.  "
+           "`cold` = the same step in the same process before the placement trials, on first allocations, without the settle phase.\n",
+           "| run | steps | ms/step | K1+K2 ms (HIP events) | frac of 8 TB/s | cold ms/step | cold K1+K2 ms | placement trials (ms) |", "|---|---|---|---|---|---|---|---|"]
     for pat, st in (("fresh_%d.json", 100), ("s20_%d.json", 20)):
         for i in range(1, 7):
             d = jload(os.path.join(src, pat % i))
             if d:
-                out.append(f"| {i} | {st} | {d['ms_per_step']} | {d['roofline']['kernel_ms']} | {d['roofline']['frac']} | {d['config'].get('placement', {}).get('trials_ms')} |")
-    d = jload(os.path.join(src, "s20_nosettle.json"))
+                cold = d.get("cold") or {}
+                out.append(f"| {i} | {st} | {d['ms_per_step']} | {d['roofline']['kernel_ms']} | {d['roofline']['frac']} | {cold.get('ms_per_step')} | {cold.get('kernel_ms')} | {d['config'].get('placement', {}).get('trials_ms')} |")
+    d = jload(os.path.join(src, "s20_plain.json"))
     if d:
-        out.append(f"\nThe driver's command with `--settle-ms 0` (timed region started from an idle GPU): {d['ms_per_step']} ms/step, K1+K2 {d['roofline']['kernel_ms']} ms.")
+        out.append(f"\nThe driver's command with `--placement-trials 0 --settle-ms 0` (what a caller who just allocates and runs gets, timed region "
+                   f"started from an idle GPU): {d['ms_per_step']} ms/step, K1+K2 {d['roofline']['kernel_ms']} ms.")
     open(os.path.join(P, f"{tag}_fresh_processes.md"), "w").write("\n".join(out) + "\n")
     # ---- batch
     out = [f"# {tag}: batched small tiles (tools/bench_batch.py; 100 x 100 x 285 tiles, deg 3)\n"]
@@ -119,10 +122,14 @@ def main():
         json.dump(t, open(tf, "w"), indent=1)
     open(os.path.join(P, f"{tag}_u16_tiles.md"), "w").write("\n".join(out) + "\n")
     # ---- rehearsals
-    out = [f"# {tag}: multi-rank control flow rehearsed on one GPU\n"]
+    out = [f"# {tag}: multi-rank control flow rehearsed on one GPU - the JSON lines (bench.py started WITHOUT a launcher: it starts its own ranks)\n"]
     d = jload(os.path.join(src, "bench_gloo4.json"))
     if d:
-        out.append("4 ranks, `--backend gloo --same-device` (256 x 256 tiles): " + json.dumps({k: d[k] for k in ("value", "n_gpus", "ms_per_step", "degraded") if k in d}) + "\n")
+        out.append("`python bench.py --gpus 4 --backend gloo --same-device --height 256 --width 256`: " + json.dumps({k: d[k] for k in ("value", "n_gpus", "world_size", "exchange_ranks", "rccl_ranks", "scaling", "ms_per_step", "degraded") if k in d}) + "\n")
+    d = jload(os.path.join(src, "bench_strong2.json"))
+    if d:
+        out.append("`python bench.py --gpus 2 --backend gloo --same-device --scaling strong` (ONE 1024 x 1024 cube, two 512-row blocks): " +
+                   json.dumps({k: d[k] for k in ("value", "n_gpus", "scaling", "ms_per_step", "degraded") if k in d} | {"rows_per_gpu": d["config"]["rows_per_gpu"]}) + "\n")
     e = os.path.join(src, "two_ranks_one_gpu.err")
     if os.path.isfile(e):
         msg = [l for l in open(e) if "[bench]" in l]
@@ -134,7 +141,44 @@ def main():
     if d:
         out.append("8 x 1024 x 1024 x 285 tiles resident on one GPU, one global fit per step (`--tiles-per-gpu 8`): " +
                    json.dumps({"value": d["value"], "ms_per_step": d["ms_per_step"], "step_frac_of_peak": d["roofline"]["step_frac_of_peak"]}) + "\n")
-    open(os.path.join(P, f"{tag}_rehearsals.md"), "w").write("\n".join(out) + "\n")
+    open(os.path.join(P, f"{tag}_rehearsal_lines.md"), "w").write("\n".join(out) + "\n")
+    # ---- a9
+    out = [f"# {tag}: variant a9 (K4, polynomial-ridge fusion) - `tools/bench_ridge.py`, rocprofv3 kernel trace and PMC, MI355X\n"]
+    rl = os.path.join(src, "ridge.log")
+    if os.path.isfile(rl):
+        out.append("```")
+        out += [l.strip() for l in open(rl) if l.startswith("{")]
+        out.append("```\n")
+    ks = kstats(os.path.join(src, "trace_ridge"))
+    if ks:
+        out += ["| kernel (rocprofv3 --kernel-trace --stats, all three configurations of bench_ridge.py) | calls | avg us | min us | max us |", "|---|---|---|---|---|"]
+        out += [f"| `{n}` | {c} | {a:.2f} | {lo:.2f} | {hi:.2f} |" for n, c, a, lo, hi in ks]
+    agg = {}
+    for f in glob.glob(os.path.join(src, "pmc_ridge", "*", "*counter_collection.csv")):
+        for r in csv.DictReader(open(f)):
+            if "hsr::" in r["Kernel_Name"]:
+                k = r["Kernel_Name"].split("(")[0].replace("void ", "")
+                if not any(x in k for x in ("predict103", "gram_f64", "chol_")):
+                    continue
+                a = agg.setdefault(k, {})
+                a.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+                a.setdefault("_dur_us", []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
+    if agg:
+        out.append("\nPMC (separate passes; averages per launch over all launches of the kernel in `bench_ridge.py`).  Matrix-pipe busy = "
+                   "`SQ_VALU_MFMA_BUSY_CYCLES` / (1024 SIMDs x `GRBM_GUI_ACTIVE` / 8); `SQ_*_CYCLES` / `SQ_WAIT_*` count quad-cycles.\n")
+        for k, cs in agg.items():
+            avg = {c: sum(v) / len(v) for c, v in cs.items()}
+            line = f"* `{k}`: " + ", ".join(f"{c} {v:,.0f}" for c, v in sorted(avg.items()) if c != "_dur_us")
+            if "SQ_VALU_MFMA_BUSY_CYCLES" in avg and "GRBM_GUI_ACTIVE" in avg and avg["GRBM_GUI_ACTIVE"] > 0:
+                line += f" -> matrix pipe busy {avg['SQ_VALU_MFMA_BUSY_CYCLES'] / (1024 * avg['GRBM_GUI_ACTIVE'] / 8) * 100:.1f} %"
+            out.append(line)
+    cs_ = os.path.join(src, "chol_stamps.log")
+    if os.path.isfile(cs_):
+        out += ["\nWhere the one-workgroup Cholesky factorisation spends its cycles (`tools/chol_stamps`, n = 288):\n", "```"] + [l.rstrip() for l in open(cs_)] + ["```"]
+    open(os.path.join(P, f"{tag}_k4_ridge.md"), "w").write("\n".join(out) + "\n")
+    sc = os.path.join(src, "shard_curve.log")
+    if os.path.isfile(sc):
+        shutil.copy(sc, os.path.join(P, f"{tag}_shard_curve.log"))
     ks = kstats(os.path.join(src, "trace_rs"))
     if ks:
         out = [f"# {tag}: slot reduction + solve kernels (`rocprofv3 --kernel-trace --stats -- python3 tools/dbg/rs_time.py`)\n",

@@ -393,9 +393,9 @@ __global__ __launch_bounds__(256) void apply_rows_kernel(const ApplyArgs a, cons
     const hsr_batch_tile tl = tiles[blockIdx.y];
     x = tl.pseudo_dev;
     out = tl.matched_dev;
-    mask = use_mask ? tl.mask_dev : nullptr;
+    mask = (use_mask & 1) ? tl.mask_dev : nullptr;
     npix = tl.npix;
-    coeffs = a.coeffs + (size_t)blockIdx.y * a.nb * N;
+    coeffs = (use_mask & 2) ? a.coeffs : a.coeffs + (size_t)blockIdx.y * a.nb * N;   // bit 1: one polynomial set for all tiles
   }
   const uint32_t nv = (uint32_t)(npix * Q);          // host guarantees npix * Q < 2^31
   const uint32_t tid = blockIdx.x * 256u + threadIdx.x;

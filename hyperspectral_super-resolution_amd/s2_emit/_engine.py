@@ -493,6 +493,9 @@ class TileBatch:
         self._build(torch.empty((total, self.row), dtype=torch.float32, device=dev))
         self.moments = torch.zeros((T, self.nb, self.M), dtype=torch.float64, device=dev)
         self.coeffs = torch.zeros((T, self.nb, max(deg, 0) + 1), dtype=torch.float64, device=dev)
+        # a mosaic's global fit (fuse_mosaic(resident=True)): the sum over the tiles and its polynomial live with the batch
+        self.total_moments = torch.zeros((self.nb, self.M), dtype=torch.float64, device=dev)
+        self.global_coeffs = torch.zeros((self.nb, max(deg, 0) + 1), dtype=torch.float64, device=dev)
 
     def _build(self, pseudo):
         """Tile and unit tables for the output image ``pseudo`` (the tables hold raw pointers into it)."""
@@ -578,13 +581,17 @@ def batch_reduce_solve(tb: TileBatch, min_count: int):
     return tb.moments, tb.coeffs
 
 
-def batch_poly_apply(tb: TileBatch, use_mask: bool = False, clip: bool = True, coeffs=None):
-    """K3 of every tile with its own coefficients in one launch -> tb.matched."""
+def batch_poly_apply(tb: TileBatch, use_mask: bool = False, clip: bool = True, coeffs=None, shared: bool = False):
+    """K3 of every tile in one launch -> tb.matched.  Every tile with its own coefficients (tb.coeffs, or ``coeffs`` of shape
+    (T, nb, deg+1)); ``shared=True``: ``coeffs`` is ONE (nb, deg+1) set used by all tiles (a mosaic's global fit)."""
     lib = nat.load()
     co = tb.coeffs if coeffs is None else coeffs
+    if shared and co.dim() != 2:
+        raise ValueError("shared coefficients must be one (nb, deg+1) tensor")
     with _launch(tb.pseudo) as st:
         nat.check(lib.hsr_poly_apply_batched(_ptr(tb.tiles_dev), tb.T, int(tb.info.max_npix), _ptr(co), tb.nb,
-                                             int(co.shape[-1]) - 1, tb.row, 1 if use_mask else 0, 1 if clip else 0, st),
+                                             int(co.shape[-1]) - 1, tb.row, (1 if use_mask else 0) | (2 if shared else 0),
+                                             1 if clip else 0, st),
                   "hsr_poly_apply_batched")
     return tb.matched
 
@@ -610,14 +617,16 @@ def moments_reduce_solve(ws: MomentWorkspace, min_count: int):
     return ws.moments, ws.coeffs
 
 
-def reduce_solve_slots(partials, slots: int, ws: MomentWorkspace, min_count: int):
+def reduce_solve_slots(partials, slots: int, ws: MomentWorkspace, min_count: int, moments=None, coeffs=None):
     """hsr_moments_reduce_solve over any [slot][band][moment] float64 array (e.g. the per-tile moments of a mosaic, one
-    "slot" per tile) -> (ws.moments, ws.coeffs)."""
+    "slot" per tile) -> (moments, coeffs): the given tensors, or the workspace's."""
     lib = nat.load()
+    mo = ws.moments if moments is None else moments
+    co = ws.coeffs if coeffs is None else coeffs
     with _launch(partials) as st:
         nat.check(lib.hsr_moments_reduce_solve(_ptr(partials), int(slots), ws.nb, ws.deg, int(min_count),
-                                               _ptr(ws.moments), _ptr(ws.coeffs), st), "hsr_moments_reduce_solve")
-    return ws.moments, ws.coeffs
+                                               _ptr(mo), _ptr(co), st), "hsr_moments_reduce_solve")
+    return mo, co
 
 
 def poly_moments(x, y, deg: int, ws: MomentWorkspace, mask=None, min_x=_NEG_INF, min_y=_NEG_INF,

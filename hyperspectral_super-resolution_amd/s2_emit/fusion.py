@@ -491,8 +491,9 @@ class SpectralFusion:
         ``resident=True``: the same tiles (same tensors) will be fused again and again - the mosaic then runs through
         the batch machinery of step_batch() in five launches instead of four per tile: batched K1+K2, batched slot
         reduction, the sum over the tiles + solve, a broadcast of the coefficients, batched K3.  Per-tile slots and
-        trees are those of the per-tile launches, so the per-tile moments carry the same bits; the outputs are views of
-        the batch's buffers, reused by the next call."""
+        trees are those of the per-tile launches, so the per-tile moments carry the same bits; the outputs - images,
+        moments and coefficients alike - are tensors of the batch, reused by the next call on the same tiles (clone what
+        you keep)."""
         torch = nat.require_gpu()
         tiles = list(tiles)
         if not tiles:
@@ -539,12 +540,14 @@ class SpectralFusion:
         eng.batch_srf_integrate_moments(tb, self.min_valid, self.min_valid, self.tile_scale, self.tile_nodata, events=k1_events)
         eng.batch_reduce_solve(tb, self.min_count)          # per-tile moments (the per-tile coefficients are not used)
         # the tiles' moments are T "slots" of the same [slot][band][moment] layout: one more fixed-order reduction
-        total, coeffs = eng.reduce_solve_slots(tb.moments, tb.T, self.ws, self.min_count)
+        # the sum over the tiles and its polynomial are written into the batch's own tensors (no copies out of the plan's
+        # workspace), and K3 reads that ONE set for every tile (no broadcast copy): r03 trace of the 8-tile mosaic, three
+        # 5 us copy kernels between the solve and K3
+        total, coeffs = eng.reduce_solve_slots(tb.moments, tb.T, self.ws, self.min_count, tb.total_moments, tb.global_coeffs)
         if self._exchanges():
-            total, coeffs = exchange_moments(total, self._solve, self.group, self.coeff_sync)
-        total, coeffs = total.clone(), coeffs.clone()     # the plan's workspace is rewritten by the next call
-        tb.coeffs.copy_(coeffs.expand(tb.T, -1, -1))
-        eng.batch_poly_apply(tb, use_mask=self.apply_mask, clip=self.clip)
+            total, coeffs = exchange_moments(total, lambda m: eng.poly_solve(m, self.deg, self.min_count, out=tb.global_coeffs),
+                                             self.group, self.coeff_sync)
+        eng.batch_poly_apply(tb, use_mask=self.apply_mask, clip=self.clip, coeffs=coeffs, shared=True)
         outs = [FusionOutput(self.names, tb.tile_rows(i, "pseudo"), total, coeffs, tb.tile_rows(i, "matched"), self.layout)
                 for i in range(tb.T)]
         return coeffs, total, outs

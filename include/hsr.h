@@ -313,8 +313,9 @@ int hsr_srf_integrate_moments_batched(const hsr_batch_unit* units_dev, const hsr
 int hsr_moments_reduce_solve_batched(const hsr_batch_tile* tiles_dev, int32_t ntiles, const double* partials_dev,
                                      int32_t nb, int32_t deg, int64_t min_count, double* moments_dev,
                                      double* coeffs_dev, hsr_stream_t stream);
-/* K3 over the whole batch: matched = apply(pseudo) with the tile's own coefficients (hsr_poly_apply semantics;
- * use_mask: polynomial only where the tile's mask is set). */
+/* K3 over the whole batch: matched = apply(pseudo) with the tile's own coefficients (hsr_poly_apply semantics).
+ * use_mask is a set of flags: 1 = polynomial only where the tile's mask is set; 2 = coeffs_dev holds ONE (nb, deg+1) set
+ * that every tile uses (a mosaic with a global fit) instead of (T, nb, deg+1). */
 int hsr_poly_apply_batched(const hsr_batch_tile* tiles_dev, int32_t ntiles, int64_t max_npix, const double* coeffs_dev,
                            int32_t nb, int32_t deg, int32_t row, int32_t use_mask, int32_t clip, hsr_stream_t stream);
 

@@ -71,8 +71,11 @@ def parse_args(argv=None):
                          "(CPU-side rehearsal of the multi-rank control flow)")
     ap.add_argument("--same-device", action="store_true",
                     help="rehearsal only: every rank uses cuda:0 (needs --backend gloo)")
-    ap.add_argument("--pipeline", default="auto", choices=["auto", "on", "off"],
-                    help="one-tile-deep software pipeline (exchange of tile i under K1 of tile i+1); auto = on for N > 1")
+    ap.add_argument("--pipeline", default="auto", choices=["auto", "on", "off", "fused"],
+                    help="software pipeline: on = one tile deep (fit of tile i on a side stream under K1 of tile i+1, K3(i) behind "
+                         "K1(i+1)); fused = K3 of tile i-2 as a pre-phase of K1's launch for tile i (one kernel per tile on the "
+                         "caller's stream; fit of tile i-1 as tail work of the same launch; needs no exchange); auto = on for N > 1, "
+                         "fused at N = 1 if its self-check against step() passes, else off")
     ap.add_argument("--reserve-cus", type=int, default=8,
                     help="CUs left free of persistent K1 workgroups in pipelined mode (side-stream tail of the previous tile)")
     ap.add_argument("--force-exchange", action="store_true",
@@ -362,16 +365,41 @@ def main(argv=None):
     probs = [device_problem(H, W, B, deg=args.deg, seed=rank * ntl + i, device=device) for i in range(ntl)]
     prob = probs[0]
     exchanging = world > 1 or args.force_exchange
-    pipelined = ntl == 1 and (args.pipeline == "on" or (args.pipeline == "auto" and exchanging))
+    want_fused = ntl == 1 and args.cube == "f32" and not exchanging and not args.fused_fit and args.pipeline in ("fused", "auto")
+    fused_note = None
+    if want_fused:
+        # self-check on THIS tile before anything is timed: five tiles through the fused pipeline must come out with the bits of
+        # step() (pseudo, matched, moments, coefficients).  auto falls back to the plain sequence if they do not.
+        chk = SpectralFusion(prob.emit_w, prob.srf, prob.good_mask, deg=args.deg, min_valid=0.0, min_count=50, clip=True,
+                             device=device, coeff_sync="local", fuse_apply=True)
+        ref_out = chk.step(prob.cube, prob.real, reuse_buffers=False)
+        got = [chk.submit(prob.cube, prob.real) for _ in range(5)]
+        got = [o for o in got if o is not None] + chk.drain()
+        same = chk._pipe["fused"] and len(got) == 5 and all(
+            torch.equal(o.pseudo.view(torch.int32), ref_out.pseudo.view(torch.int32)) and
+            torch.equal(o.matched.view(torch.int32), ref_out.matched.view(torch.int32)) and
+            torch.equal(o.moments.view(torch.int64), ref_out.moments.view(torch.int64)) and
+            torch.equal(o.coeffs.view(torch.int64), ref_out.coeffs.view(torch.int64)) for o in got)
+        chk.close()
+        del chk, got, ref_out
+        if not same:
+            if args.pipeline == "fused":
+                raise SystemExit("[bench] --pipeline fused: the fused pipeline did not reproduce step() on this tile")
+            want_fused = False
+            fused_note = "auto: the fused pipeline's self-check failed, plain sequence used"
+        else:
+            fused_note = "self-checked before timing: five tiles through the fused pipeline carry the bits of step()"
+    pipelined = ntl == 1 and (args.pipeline == "on" or want_fused or (args.pipeline == "auto" and exchanging))
+    fused = pipelined and want_fused
 
     def make_plan(trials):
         return SpectralFusion(prob.emit_w, prob.srf, prob.good_mask, deg=args.deg, min_valid=0.0, min_count=50,
                               clip=True, device=device, group=None,
                               coeff_sync=args.coeff_sync if exchanging else "local",
                               force_exchange=args.force_exchange,
-                              reserved_cus=args.reserve_cus if pipelined else 0,   # CUs kept free for the side stream
+                              reserved_cus=args.reserve_cus if (pipelined and not fused) else 0,   # CUs kept free for the side stream
                               u16_fast=args.u16_fast, fused_fit=args.fused_fit, placement_trials=trials,
-                              placement_budget_gb=args.placement_budget_gb)
+                              placement_budget_gb=args.placement_budget_gb, fuse_apply=fused)
     real = prob.real            # (H, W, row) band-last, like the cube and the reference's (H, W, C) images
     cube = prob.cube
     if args.cube == "u16":      # quantise once, outside the timed region (the writer's arithmetic, on the device)
@@ -495,23 +523,27 @@ def main(argv=None):
         cube_bytes = npb * esz
         full_bytes = H * W * (esz * B + 16 * nb)        # + pseudo write, real read, apply read + write (no mask in this run)
         launch_bytes = cube_bytes * ntl            # a mosaic step runs K1+K2 of all its tiles in one batched launch
+        if fused:                                  # the timed launch also carries K3 of tile i-2: + 8 * row bytes per pixel
+            launch_bytes += H * W * 8 * prob.real.shape[-1]
         achieved = launch_bytes / (k1_ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": "srf_kernel<deg,fast> (K1+K2 fused)" if args.cube == "f32" else "srf_u16_ring_kernel<deg> (K1+K2 fused, uint16 tile decode%s)" % (", fast arithmetic" if args.u16_fast else ""), "achieved": round(achieved, 1),
+        roof = {"bound": "hbm", "kernel": ("srf_kernel<deg,fast,...,APPLY>: K1+K2 of tile i + K3 of tile i-2 (pre-phase) + fit of tile i-1 (tail) "
+                                           "in one launch; algorithmic bytes = cube + K3's 8 x row bytes per pixel" if fused else
+                                           "srf_kernel<deg,fast> (K1+K2 fused)") if args.cube == "f32" else "srf_u16_ring_kernel<deg> (K1+K2 fused, uint16 tile decode%s)" % (", fast arithmetic" if args.u16_fast else ""), "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": None, "traffic_source": None, "algorithmic_bytes": launch_bytes, "kernel_ms": round(k1_ms, 4),
                 "kernel_launches_timed": len(k1_all),
                 "kernel_ms_in_timed_region": round(sum(in_region) / max(1, len(in_region)), 4), "launches_in_timed_region": len(in_region),
                 "kernel_ms_after_region": round(sum(extra) / max(1, len(extra)), 4) if extra else None,
                 "agrees_with": "profiles/r03_kernel_stats.csv (rocprofv3 --kernel-trace --stats of this command): average duration of "
-                               "the srf_kernel / srf_u16_ring_kernel row; HIP-event brackets add ~10 us of record overhead per launch",
+                               "the srf_kernel<..., true> (fused pipeline) / srf_kernel / srf_u16_ring_kernel row",
                 "step_frac_of_peak": round(ntl * cube_bytes * args.steps / dt_max / 1e9 / HBM_PEAK_GBS, 4),
                 "total_fraction": round(ntl * full_bytes * args.steps / dt_max / 1e9 / HBM_PEAK_GBS, 4),
                 "total_bytes_per_step": ntl * full_bytes}
         tf = os.path.join(ROOT, TRAFFIC_FILE)
         if ntl == 1 and (H, W, B) == (1024, 1024, 285) and os.path.isfile(tf):       # the PMC figure is per single-tile launch of this shape
             try:
-                roof["traffic"] = json.load(open(tf)).get("srf_kernel_hbm_bytes_per_launch" if args.cube == "f32"
-                                                          else "srf_u16_kernel_hbm_bytes_per_launch")
+                roof["traffic"] = json.load(open(tf)).get(("srf_fused_kernel_hbm_bytes_per_launch" if fused else "srf_kernel_hbm_bytes_per_launch")
+                                                          if args.cube == "f32" else "srf_u16_kernel_hbm_bytes_per_launch")
                 roof["traffic_source"] = (f"{TRAFFIC_FILE}: FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024 per launch from separate "
                                           f"rocprofv3 --pmc passes over this command (committed file, not measured in this run)")
             except Exception:
@@ -541,11 +573,14 @@ def main(argv=None):
                 "config": {"workload": wl,
                            "tiles_per_gpu": ntl, "rows_per_gpu": H, "coeff_sync": (args.coeff_sync if world > 1 else "none") +
                            (f" (rehearsal: one-rank RCCL {args.coeff_sync} forced)" if args.force_exchange else ""),
-                           "pipeline": f"one tile deep, {args.reserve_cus} CUs reserved" if pipelined else "off",
+                           "pipeline": ("one kernel per tile: K3 of tile i-2 as a pre-phase, K1+K2 of tile i, fit of tile i-1 as tail work "
+                                        "(no side stream, no events, no reserved CUs); " + str(fused_note) if fused else
+                                        f"one tile deep, {args.reserve_cus} CUs reserved") if pipelined else "off",
                            "settle": {"ms": args.settle_ms, "untimed_steps": settle_steps,
                                       "note": "untimed load before the W warm-up steps: from idle a 20-step region sits in a "
                                               "power-management transient 6-10 % slower than the continuous-load state"},
-                           "launches_per_step": 2 if (args.fused_fit and world == 1 and not args.force_exchange and ntl == 1) else None,
+                           "pipeline_note": fused_note,
+                           "launches_per_step": 1 if fused else (2 if (args.fused_fit and world == 1 and not args.force_exchange and ntl == 1) else None),
                            "placement": {"trials": plan.placement_trials, "trials_ms": plan.placement_log.get(H * W),
                                          "joint_with_inputs": input_log is not None,
                                          "search_seconds": (input_log or {}).get("seconds"),

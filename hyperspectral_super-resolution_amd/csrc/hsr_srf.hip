@@ -80,6 +80,23 @@ struct SrfArgs {
   int32_t u16_fast;  // opt-in fast arithmetic of the uint16 kernels (hsr_srf_options.flags & HSR_SRF_U16_FAST)
   float scale;
   uint32_t nodata;   // > 0xffff: no nodata value
+  // K3 of an OLDER tile riding in this launch (APPLY variants, hsr_srf_integrate_moments_apply): matched = poly(x) over
+  // apply_npix pixels of pixel-major rows with this launch's row length (out_ps) and band count
+  const float* apply_x;
+  float* apply_out;
+  const double* apply_coeffs;       // (nb, DEG + 1) float64, highest power first
+  const uint8_t* apply_mask;        // polynomial only where != 0 (NULL: everywhere)
+  int64_t apply_npix;
+  int32_t apply_clip;
+  // the fit of the PREVIOUS tile in this launch's tail (hsr_apply_job.fit_*): the first nb workgroups to finish their groups
+  // take a ticket each and reduce + solve one band of the previous launch's partial slots
+  const double* lazy_partials;      // [lazy_slots][nb][3 DEG + 2]; NULL: no tail fit
+  int32_t lazy_slots;
+  long long lazy_min_count;
+  double* lazy_moments;             // (nb, 3 DEG + 2) out
+  double* lazy_coeffs;              // (nb, DEG + 1) out
+  unsigned int* lazy_counter;       // running ticket counter (one ticket per workgroup and launch)
+  unsigned int lazy_base;           // its value before this launch
 #ifdef HSR_PHASE_STAMPS
   unsigned long long* stamps;
   unsigned long long* stamps2;   // [grid][4]: REFCLK (100 MHz) at workgroup entry and exit, XCC id, HW_ID
@@ -448,7 +465,120 @@ __device__ __forceinline__ void fused_fit(const SrfFit& f, const double* part, i
   if (t < 65) __hip_atomic_store(f.tickets + t, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // re-arm: every other workgroup has drawn its tickets
 }
 
-template <int DEG, bool FAST, bool WLDS, int P, bool OUTV, bool BATCH>
+// The fit of the PREVIOUS tile as tail work of a K1 launch (APPLY variants, no exchange).  Its partial slots were written
+// by the previous launch, so - unlike fused_fit above, which reduces the launch's OWN slots and pays memory-side coherence
+// round trips for it - nothing has to cross between running workgroups: a workgroup that has finished its groups draws a
+// ticket, and tickets 0 .. nb-1 reduce + solve one band each while the slower workgroups are still streaming.  Idle tail
+// time instead of a launch of its own, a side stream, two events and CUs kept free for it.  Same tree as
+// hsr_moments_reduce_solve ("lane" l adds slots l, l + 64, ... in batches of eight, butterfly over the 64 lane sums, the
+// same solve), hence the same bits.
+template <int DEG, int T>
+__device__ __forceinline__ void lazy_fit(const SrfArgs& a, unsigned char* smem, int t) {
+  constexpr int M = moment_count(DEG);
+  static_assert(T == 512, "two passes of 32 lane rows");
+  int* ticket = reinterpret_cast<int*>(smem);
+  __syncthreads();                                        // everybody is done with the tile buffers
+  if (t == 0) *ticket = (int)(__hip_atomic_fetch_add(a.lazy_counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - a.lazy_base);
+  __syncthreads();
+  const int b = *ticket;
+  if (b < 0 || b >= a.nb) return;                         // workgroup-uniform
+  double (*lsum)[16] = reinterpret_cast<double (*)[16]>(smem + 64);
+  double* mom = reinterpret_cast<double*>(smem + 64 + 64 * 16 * 8);
+  double* work = mom + 16;
+  const int stride = a.nb * M, m = t & 15;
+  const double* row = a.lazy_partials + (size_t)b * M + (m < M ? m : 0);
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    const int l = pass * 32 + (t >> 4);
+    double s = 0.0;
+    for (int i0 = l; i0 < a.lazy_slots; i0 += 64 * 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int i = i0 + 64 * u;
+        v[u] = (i < a.lazy_slots && m < M) ? row[(size_t)i * stride] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) s += v[u];
+    }
+    lsum[l][m] = s;
+  }
+  __syncthreads();
+  if (t < M) {
+    double acc[32];
+#pragma unroll
+    for (int l = 0; l < 32; ++l) acc[l] = lsum[l][t] + lsum[l + 32][t];
+#pragma unroll
+    for (int off = 16; off >= 1; off >>= 1)
+#pragma unroll
+      for (int l = 0; l < off; ++l) acc[l] = acc[l] + acc[l + off];
+    mom[t] = acc[0];
+    a.lazy_moments[(size_t)b * M + t] = acc[0];
+  }
+  __syncthreads();
+  if (t == 0) solve_band_t<DEG, true>(mom, a.lazy_min_count, a.lazy_coeffs + (size_t)b * (DEG + 1), work);
+}
+
+// K3 as a pre-phase of a K1 launch (APPLY variants; round 3).  In the pipelined order K3 of tile i-2 only needs coefficients
+// that were ready a whole K1 ago, so it does not need a launch of its own: every workgroup applies its slice of the older
+// tile before it starts its groups.  What that buys (profiles/r03_strong_scaling.md): a separate K3 is 20.6 us + a launch
+// boundary on a 1024 x 1024 tile and a fixed ~8 us of latency on a 128-row block; as a pre-phase it costs its bytes
+// (101 MB at the chip's rate = ~15 us; 2-3 us for the block).  Same arithmetic as apply_rows_kernel (float64 Horner
+// without FMA contraction, mask select, clip, channels >= nb pass through), hence the same bits.  504 of the 512 threads
+// take part: 504 is a multiple of every row length in float4 (1 .. 4), so a thread keeps its channel group and its
+// coefficients stay in registers.
+template <int N, int T>
+__device__ __forceinline__ void apply_prephase(const SrfArgs& a, int t) {
+  constexpr int kUse = T / 12 * 12;
+  constexpr int U = 4;
+  if (a.apply_x == nullptr || t >= kUse) return;
+  const int q = (int)(a.out_ps >> 2);
+  const uint32_t nv = (uint32_t)(a.apply_npix * q);            // host: apply_npix * q < 2^31
+  const uint32_t stride = gridDim.x * (uint32_t)kUse;
+  const uint32_t i0 = blockIdx.x * (uint32_t)kUse + (uint32_t)t;
+  const int c0 = (int)(i0 % (uint32_t)q) * 4;
+  double c[4][N];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int ch = c0 + j < a.nb ? c0 + j : 0;
+#pragma unroll
+    for (int k = 0; k < N; ++k) c[j][k] = a.apply_coeffs[ch * N + k];
+  }
+  const float4* x4 = reinterpret_cast<const float4*>(a.apply_x);
+  float4* o4 = reinterpret_cast<float4*>(a.apply_out);
+  for (uint32_t ib = i0; ib < nv; ib += stride * U) {
+    float4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t i = ib + u * stride;
+      if (i < nv) v[u] = ld_stream(x4 + i);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t i = ib + u * stride;
+      if (i >= nv) break;
+      const bool m = !a.apply_mask || a.apply_mask[i / (uint32_t)q];
+      float r[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (c0 + j < a.nb) {
+          float xv = r[j];
+          if (m) {                      // np.polyval: y = 0; y = y*x + c, separately rounded
+            const double xd = (double)xv;
+            double y = 0.0;
+#pragma unroll
+            for (int k = 0; k < N; ++k) y = __dadd_rn(__dmul_rn(y, xd), c[j][k]);
+            xv = (float)y;
+          }
+          r[j] = a.apply_clip ? (xv < 0.0f ? 0.0f : (xv > 1.0f ? 1.0f : xv)) : xv;
+        }
+      }
+      st_stream(o4 + i, make_float4(r[0], r[1], r[2], r[3]));
+    }
+  }
+}
+
+template <int DEG, bool FAST, bool WLDS, int P, bool OUTV, bool BATCH, bool APPLY = false>
 __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
   constexpr int T = 8 * P;
   constexpr int NW = T / 64;
@@ -477,6 +607,8 @@ __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
   const int pl = t % P;     // pixel of this thread inside the group
   const int grp = wave;     // band group 0..7: wave-uniform, so the band parameters below live in SGPRs (-20 VGPRs)
   const int nchunk = P * B / 4;  // 16-byte chunks of a full group (P is a multiple of 4)
+
+  if constexpr (APPLY && DEG > 0) apply_prephase<DEG + 1, T>(a, t);
 
   // the (at most two) bands of this thread, fixed for the whole launch
   int bk0[kBandSlots], bkl[kBandSlots], bwo[kBandSlots], bidx[kBandSlots];
@@ -772,6 +904,8 @@ __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
   if (DEG > 0 && pend) flush_moments<M, P, true, !BATCH>(acc_m, bval, bidx, pend_part, lane);
   if constexpr (DEG > 0 && !BATCH)
     if (a.fit.tickets) fused_fit<DEG>(a.fit, a.one.part_dev, a.one.slots, a.nb, smem, t);
+  if constexpr (APPLY && DEG > 0)
+    if (a.lazy_partials) lazy_fit<DEG, T>(a, smem, t);
 #ifdef HSR_PHASE_STAMPS
   if (a.stamps2 && t == 0) {
     uint32_t xcc, hw;
@@ -1419,11 +1553,11 @@ static int dispatch_u16(const SrfArgs& a, int deg, bool fast, bool ring, int gri
   return HSR_ERR_UNSUPPORTED;
 }
 
-template <int DEG, bool FAST, bool WLDS, int P, bool OUTV, bool BATCH>
+template <int DEG, bool FAST, bool WLDS, int P, bool OUTV, bool BATCH, bool APPLY = false>
 static int launch_srf(const SrfArgs& a, int grid, hipStream_t stream) {
   const size_t lds = (size_t)P * a.ldsB * 4 + (64 + (BATCH ? 16 : 0)) * sizeof(uint32_t) + (WLDS ? (size_t)a.wtaps * 4 : 0) +
                      (OUTV ? (size_t)P * a.out_ps * 4 : 0) + (DEG > 0 ? target_stage_bytes(a.nb) : 0);
-  auto kern = srf_kernel<DEG, FAST, WLDS, P, OUTV, BATCH>;
+  auto kern = srf_kernel<DEG, FAST, WLDS, P, OUTV, BATCH, APPLY>;
   static thread_local size_t configured = 0;
   ensure_dynamic_lds(kern, lds, &configured);
 #ifdef HSR_PHASE_STAMPS
@@ -1441,6 +1575,10 @@ static int dispatch_fast(const SrfArgs& a, bool fast, int grid, hipStream_t s) {
   // pixel-major output with a 16-byte friendly row: stage the slab in LDS and flush it vectorised
   const bool outv = out_rows_vectorised(a, a.one.pseudo_dev);
   if (a.wtaps == 0) return launch_srf<DEG, false, false, 64, false, false>(a, grid, s);  // rare fallback: one generic kernel
+  if (a.apply_x != nullptr || a.lazy_partials != nullptr) {   // srf_common has checked that this launch can carry it (outv, weights in LDS, DEG > 0)
+    if constexpr (DEG > 0)
+      return fast ? launch_srf<DEG, true, true, P, true, false, true>(a, grid, s) : launch_srf<DEG, false, true, P, true, false, true>(a, grid, s);
+  }
   if (outv) return fast ? launch_srf<DEG, true, true, P, true, false>(a, grid, s) : launch_srf<DEG, false, true, P, true, false>(a, grid, s);
   return fast ? launch_srf<DEG, true, true, P, false, false>(a, grid, s) : launch_srf<DEG, false, true, P, false, false>(a, grid, s);
 }
@@ -1560,6 +1698,8 @@ static int srf_common(SrfArgs& a, const int32_t* k0, const int32_t* klen, int32_
   HSR_REQUIRE(((uintptr_t)a.one.cube_dev & (a.u16 ? 1 : 3)) == 0, HSR_ERR_INVALID, "hsr_srf_integrate: cube not %d-byte aligned",
               a.u16 ? 2 : 4);
   if (a.one.npix == 0) return HSR_OK;
+  HSR_REQUIRE((a.apply_x == nullptr && a.lazy_partials == nullptr) || a.wtaps > 0, HSR_ERR_UNSUPPORTED,
+              "hsr_srf_integrate_moments_apply: the weight table does not fit LDS, this launch cannot carry an apply job");
   a.u16_fast = a.u16 && tn.u16_fast;
   int P = a.u16 ? 64 : tn.tile_pixels;
   if (a.wtaps == 0) P = 64;  // the generic fallback kernel exists for 64-pixel groups only
@@ -1602,7 +1742,7 @@ static int srf_moments_entry(const char* who, const void* cube_dev, bool u16, fl
                              float* out_dev, int64_t out_bs, int64_t out_ps, const float* real_dev, int64_t real_bs,
                              int64_t real_ps, const uint8_t* mask_dev, float min_x, float min_y, int32_t deg,
                              double* partials_dev, int32_t* slots_out, const hsr_fused_fit* fit,
-                             const hsr_srf_options* opts, hsr_stream_t stream) {
+                             const hsr_srf_options* opts, hsr_stream_t stream, const hsr_apply_job* job = nullptr) {
   HSR_REQUIRE(deg >= 1 && deg <= HSR_MAX_DEG, HSR_ERR_UNSUPPORTED, "%s: deg=%d outside [1,%d]", who, deg, HSR_MAX_DEG);
   HSR_REQUIRE(real_dev && partials_dev, HSR_ERR_INVALID, "%s: NULL pointer", who);
   HSR_REQUIRE((real_ps == 1 && real_bs >= npix) || (real_bs == 1 && real_ps >= nb), HSR_ERR_INVALID,
@@ -1641,6 +1781,30 @@ static int srf_moments_entry(const char* who, const void* cube_dev, bool u16, fl
   a.real_ps = real_ps;
   a.min_x = min_x;
   a.min_y = min_y;
+  if (job) {
+    HSR_REQUIRE((job->x_dev == nullptr && job->fit_partials_dev) || (job->x_dev && job->out_dev && job->coeffs_dev && job->npix >= 1),
+                HSR_ERR_INVALID, "%s: NULL pointer or npix < 1 in hsr_apply_job", who);
+    HSR_REQUIRE(!u16 && out_bs == 1 && (out_ps & 3) == 0 && out_ps <= HSR_MAX_BANDS && job->npix * (out_ps >> 2) < ((int64_t)1 << 31) &&
+                    ((((uintptr_t)job->x_dev) | ((uintptr_t)job->out_dev) | ((uintptr_t)out_dev)) & 15) == 0,
+                HSR_ERR_UNSUPPORTED, "%s: a launch carries an apply job only for float32 cubes and 16-byte aligned pixel-major rows of 4, 8, 12 or 16 floats", who);
+    a.apply_x = job->x_dev;
+    a.apply_out = job->out_dev;
+    a.apply_coeffs = job->coeffs_dev;
+    a.apply_mask = job->mask_dev;
+    a.apply_npix = job->npix;
+    a.apply_clip = job->clip;
+    if (job->fit_partials_dev) {
+      HSR_REQUIRE(job->fit_moments_dev && job->fit_coeffs_dev && job->fit_counter_dev && job->fit_slots >= 1 && job->fit_min_count >= 0,
+                  HSR_ERR_INVALID, "%s: incomplete tail fit in hsr_apply_job", who);
+      a.lazy_partials = job->fit_partials_dev;
+      a.lazy_slots = job->fit_slots;
+      a.lazy_min_count = (long long)job->fit_min_count;
+      a.lazy_moments = job->fit_moments_dev;
+      a.lazy_coeffs = job->fit_coeffs_dev;
+      a.lazy_counter = job->fit_counter_dev;
+      a.lazy_base = job->fit_ticket_base;
+    }
+  }
   int rc = hsr::srf_common(a, k0, klen, deg, opts, (hipStream_t)stream);
   if (rc == HSR_OK && slots_out) *slots_out = a.one.slots;
   return rc;
@@ -1655,6 +1819,17 @@ extern "C" int hsr_srf_integrate_moments(const float* cube_dev, int64_t npix, in
   return srf_moments_entry("hsr_srf_integrate_moments", cube_dev, false, 0.0f, -1, npix, B, wn_dev, k0, klen, nb, out_dev,
                            out_bs, out_ps, real_dev, real_bs, real_ps, mask_dev, min_x, min_y, deg, partials_dev, slots_out,
                            nullptr, opts, stream);
+}
+
+extern "C" int hsr_srf_integrate_moments_apply(const float* cube_dev, int64_t npix, int32_t B, const float* wn_dev,
+                                               const int32_t* k0, const int32_t* klen, int32_t nb, float* out_dev,
+                                               int64_t out_bs, int64_t out_ps, const float* real_dev, int64_t real_bs,
+                                               int64_t real_ps, const uint8_t* mask_dev, float min_x, float min_y, int32_t deg,
+                                               double* partials_dev, int32_t* slots_out, const hsr_srf_options* opts,
+                                               const hsr_apply_job* job, hsr_stream_t stream) {
+  return srf_moments_entry("hsr_srf_integrate_moments_apply", cube_dev, false, 0.0f, -1, npix, B, wn_dev, k0, klen, nb, out_dev,
+                           out_bs, out_ps, real_dev, real_bs, real_ps, mask_dev, min_x, min_y, deg, partials_dev, slots_out,
+                           nullptr, opts, stream, job);
 }
 
 extern "C" int hsr_srf_integrate_fit(const float* cube_dev, int64_t npix, int32_t B, const float* wn_dev,

@@ -106,6 +106,8 @@ SIGNATURES = {
     "hsr_srf_integrate_moments_u16": (C.c_int, [_vp, _i64, _i32, _f32, _i32, _vp, C.POINTER(_i32), C.POINTER(_i32),
                                                 _i32, _vp, _i64, _i64, _vp, _i64, _i64, _vp, _f32, _f32, _i32, _vp,
                                                 C.POINTER(_i32), _popt, _vp]),
+    "hsr_srf_integrate_moments_apply": (C.c_int, [_vp, _i64, _i32, _vp, _pi32, _pi32, _i32, _vp, _i64, _i64,
+                                                  _vp, _i64, _i64, _vp, _f32, _f32, _i32, _vp, _pi32, _popt, _vp, _vp]),
     "hsr_srf_integrate_fit": (C.c_int, [_vp, _i64, _i32, _vp, _pi32, _pi32, _i32, _vp, _i64, _i64, _vp, _i64, _i64, _vp,
                                         _f32, _f32, _i32, _vp, _pi32, C.POINTER(FusedFit), _popt, _vp]),
     "hsr_srf_integrate_fit_u16": (C.c_int, [_vp, _i64, _i32, _f32, _i32, _vp, _pi32, _pi32, _i32, _vp, _i64, _i64, _vp,
@@ -151,6 +153,7 @@ SIGNATURES = {
     "hsr_step_run_solve": (C.c_int, [_vp, _vp]),
     "hsr_step_run_apply": (C.c_int, [_vp, _vp, _vp]),
     "hsr_pipeline_create": (C.c_int, [_vp, _vp, _vp, _i32, C.POINTER(_vp)]),
+    "hsr_pipeline_create_fused": (C.c_int, [_vp, _vp, _vp, _vp, _i32, C.POINTER(_vp)]),
     "hsr_pipeline_destroy": (None, [_vp]),
     "hsr_pipeline_submit": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _pi32, _vp, _vp]),
     "hsr_pipeline_fit_done": (C.c_int, [_vp]),

@@ -109,7 +109,7 @@ class SpectralFusion:
                  reserved_cus: Optional[int] = None, tile_pixels: int = 0, u16_single_buffer: bool = False,
                  u16_fast: bool = False, placement_trials: int = 0, fused_fit: bool = False,
                  placement_pitch_gb: float = eng.PLACEMENT_PITCH_GB, placement_budget_gb: Optional[float] = None,
-                 side_stream=None):
+                 side_stream=None, fuse_apply: bool = False):
         """``placement_trials`` (default 0 = OFF: the plan allocates once and never synchronises with the host): opt in to
         the placement search of eng.placement_search for tiles of >= 65 536 pixels - up to min(4, trials) candidate output
         images on the first step()/submit()/step_batch() over a tile size, up to ``trials`` candidate (cube, target, image)
@@ -170,6 +170,12 @@ class SpectralFusion:
         # the stream the fits of submit() run on: None = chosen by measurement on the first submit (_pick_side_stream)
         self.side_stream = side_stream
         self.side_stream_log = None                  # us per pipelined step of each candidate stream, if measured
+        # fuse_apply: submit() runs the FUSED pipeline - ONE kernel per tile on the caller's stream and nothing else: launch i
+        # = K3 of tile i-2 as a pre-phase + K1+K2 of tile i + the fit of tile i-1 as tail work of the first workgroups to
+        # finish (hsr_srf_integrate_moments_apply).  No side stream, no events, no CUs kept free; results two submits late
+        # instead of one.  Needs float32 cubes, the pixel-major layout and no exchange (a collective cannot ride in a kernel's
+        # tail); otherwise submit() quietly uses the two-slot pipeline.
+        self.fuse_apply = bool(fuse_apply)
         self._native: Dict[tuple, object] = {}       # prepared launches of step(), by _native_key
         self._native_handles: list = []              # ("plan" | "pipe", handle) to destroy with the plan
         self._pipe_images: Dict[int, list] = {}      # output images placed by place_inputs() for the pipeline's two slots
@@ -752,21 +758,38 @@ class SpectralFusion:
             placed = [eng.alloc_image(torch, nb, npix, self.layout, self.device) for _ in range(2)]
             if self.placement_trials > 1 and npix >= (1 << 16):
                 placed = self._place(npix, placed, probe, count=2)       # ONE search for both slots' images
+        # with an exchange the fit needs a collective between reduce and solve, which cannot ride in a kernel's tail: the
+        # two-slot pipeline (fit on the side stream) stays the multi-rank form
+        fused = self.fuse_apply and self.layout == nat.PIXMAJOR and cube.dtype == torch.float32 and not self._exchanges()
+        if fused:
+            placed = list(placed) + [eng.alloc_image(torch, nb, npix, self.layout, self.device)]
         slots, outs = [], []
-        for k in range(2):
+        for k in range(3 if fused else 2):
             ws = eng.MomentWorkspace(self.device, nb, self.deg)
             matched = eng.alloc_image(torch, nb, npix, self.layout, self.device)
             h, keep = self._native_plan(cube, real2, real_layout, placed[k], matched, ws)
             slots.append(dict(plan=h, ws=ws, keep=keep, mask=None))
             outs.append(FusionOutput(self.names, placed[k], ws.moments, ws.coeffs, matched, self.layout))
         exchange = self._exchanges()
-        side = self.side_stream if self.side_stream is not None else self._pick_side_stream(slots, cube, real2, mask)
+        if self.side_stream is not None:
+            side = self.side_stream
+        elif fused:                                    # the fused pipeline has no side-stream work: nothing to choose
+            side = torch.cuda.Stream(device=self.device)
+        else:
+            side = self._pick_side_stream(slots, cube, real2, mask)
         ph = C.c_void_p()
-        nat.check(lib.hsr_pipeline_create(slots[0]["plan"], slots[1]["plan"], C.c_void_p(side.cuda_stream), 1 if exchange else 0,
-                                          C.byref(ph)), "hsr_pipeline_create")
+        if fused:
+            rc = lib.hsr_pipeline_create_fused(slots[0]["plan"], slots[1]["plan"], slots[2]["plan"], C.c_void_p(side.cuda_stream),
+                                               1 if exchange else 0, C.byref(ph))
+            if rc != nat.HSR_OK:                       # geometry the fused launch does not cover: the two-slot pipeline
+                fused = False
+                slots, outs = slots[:2], outs[:2]
+        if not fused:
+            nat.check(lib.hsr_pipeline_create(slots[0]["plan"], slots[1]["plan"], C.c_void_p(side.cuda_stream), 1 if exchange else 0,
+                                              C.byref(ph)), "hsr_pipeline_create")
         self._native_handles.append(("pipe", ph))
         self._pipe = dict(key=key, npix=npix, h=ph, slots=slots, outs=outs, side=side, side_handle=C.c_void_p(side.cuda_stream),
-                          exchange=exchange, n=0, fin=C.c_int32(-1))
+                          exchange=exchange, n=0, fin=C.c_int32(-1), fused=fused, S=len(slots), inflight=[])
         return self._pipe
 
     @staticmethod
@@ -778,7 +801,8 @@ class SpectralFusion:
         return C.c_void_p(ev.cuda_event)
 
     def submit(self, cube, real, mask=None, k1_events=None) -> Optional[FusionOutput]:
-        """Pipelined step: start tile i, finish and return tile i-1 (None on the first call).  One call into the native
+        """Pipelined step: start tile i, finish and return tile i-1 (None on the first call) - tile i-2 with
+        ``fuse_apply=True`` (None on the first two calls).  One call into the native
         pipeline (csrc/hsr_exec.hip) enqueues K1(i) and K3(i-1) on the caller's stream and - without an exchange - the fit
         of tile i on the side stream; with an exchange the fit (slot reduction -> collective -> solve) is enqueued from
         here on the side stream."""
@@ -794,8 +818,10 @@ class SpectralFusion:
         if mask is not None and not (mask.dtype == torch.uint8 and mask.numel() == st["npix"] and mask.is_contiguous()
                                      and mask.device == self.device):
             raise ValueError("mask must be a contiguous uint8 tensor with one byte per pixel")
-        cur = st["n"] & 1
-        prev_mask = st["slots"][cur ^ 1]["mask"]
+        S = st["S"]
+        cur = st["n"] % S
+        # the tile this call finishes: i-1 (two slots) or i-2 (fused) - the oldest one in flight, once S - 1 are
+        prev_mask = st["slots"][st["inflight"][0]]["mask"] if len(st["inflight"]) == S - 1 else None
         fin = st["fin"]
         with eng._launch(cube) as stream:
             e0 = e1 = None
@@ -819,28 +845,38 @@ class SpectralFusion:
                     exchange_moments(slot["ws"].moments, solve, self.group, self.coeff_sync)
                 nat.check(lib.hsr_pipeline_fit_done(st["h"]), "hsr_pipeline_fit_done")
         st["n"] += 1
+        st["inflight"].append(cur)
         if fin.value < 0:
             return None
+        st["inflight"].remove(fin.value)
         st["slots"][fin.value]["mask"] = None
         return st["outs"][fin.value]
 
-    def flush(self) -> Optional[FusionOutput]:
-        """Finish (K3, on the caller's stream) the tile left in the pipeline by the last submit() and return it."""
+    def drain(self) -> List[FusionOutput]:
+        """Finish (K3, on the caller's stream) every tile still in the pipeline, oldest first, and return their outputs."""
         st = self._pipe
         if st is None or st["n"] == 0:
-            return None
+            return []
         import ctypes as C
         lib = nat._lib or nat.load()
-        last = (st["n"] - 1) & 1
-        mask = st["slots"][last]["mask"]
         fin = st["fin"]
+        outs = []
         with eng._launch(st["outs"][0].pseudo) as stream:
-            nat.check(lib.hsr_pipeline_flush(st["h"], None if mask is None else mask.data_ptr(), stream, C.byref(fin)),
-                      "hsr_pipeline_flush")
-        if fin.value < 0:
-            return None
-        st["slots"][fin.value]["mask"] = None
-        return st["outs"][fin.value]
+            while st["inflight"]:
+                slot = st["inflight"].pop(0)             # oldest first; its mask was kept with the slot
+                mask = st["slots"][slot]["mask"]
+                nat.check(lib.hsr_pipeline_flush(st["h"], None if mask is None else mask.data_ptr(), stream, C.byref(fin)),
+                          "hsr_pipeline_flush")
+                if fin.value != slot:
+                    raise nat.HsrError(f"pipeline out of step: expected slot {slot}, library finished {fin.value}")
+                st["slots"][slot]["mask"] = None
+                outs.append(st["outs"][slot])
+        return outs
+
+    def flush(self) -> Optional[FusionOutput]:
+        """Finish the tile(s) left in the pipeline by the last submit() and return the LAST one (drain() returns all)."""
+        outs = self.drain()
+        return outs[-1] if outs else None
 
 
 def fuse_pair(R, emit_w, srf_dict, good_mask, real_s2: Dict[str, np.ndarray], deg: int = 3,

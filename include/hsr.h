@@ -114,6 +114,37 @@ int hsr_srf_integrate_moments(const float* cube_dev, int64_t npix, int32_t B,
                               double* partials_dev, int32_t* slots_out, const hsr_srf_options* opts,
                               hsr_stream_t stream);
 
+/* ---- K1+K2 with K3 of an OLDER tile as a pre-phase of the same launch (ABI 4) -----------------------------
+ * hsr_srf_integrate_moments, and before a workgroup starts its groups it applies its slice of `job`: matched = polynomial(x)
+ * over job->npix pixels of pixel-major rows with THIS launch's row length (out_ps) and band count, degree = deg
+ * (hsr_poly_apply semantics and bits: float64 Horner, mask select, clip, channels >= nb pass through).  For the pipelined
+ * order, where K3 of tile i-2 only needs coefficients that have been ready for a whole K1: one launch per tile on the
+ * caller's stream.  Float32 cubes, 16-byte aligned rows of 4 / 8 / 12 / 16 floats; HSR_ERR_UNSUPPORTED otherwise.
+ * job == NULL: plain hsr_srf_integrate_moments. */
+typedef struct hsr_apply_job {
+  const float* x_dev;            /* pseudo image of the older tile (npix, out_ps)                                      */
+  float* out_dev;                /* its matched image                                                                  */
+  const double* coeffs_dev;      /* (nb, deg+1)                                                                        */
+  const uint8_t* mask_dev;       /* polynomial only where != 0; NULL: everywhere                                       */
+  int64_t npix;
+  int32_t clip;
+  int32_t fit_slots;             /* tail fit (optional, fit_partials_dev != NULL): the first nb workgroups to finish their groups   */
+  const double* fit_partials_dev;/* reduce + solve one band each of the PREVIOUS launch's partial slots [fit_slots][nb][3deg+2]   */
+  double* fit_moments_dev;       /* -> (nb, 3deg+2) and (nb, deg+1), bit-identical to hsr_moments_reduce_solve; no launch of its  */
+  double* fit_coeffs_dev;        /* own, no side stream.  x_dev may be NULL when only the tail fit rides.                           */
+  int64_t fit_min_count;
+  unsigned int* fit_counter_dev; /* running ticket counter (device, zero before the first launch that uses it)                      */
+  unsigned int fit_ticket_base;  /* = number of workgroups of all earlier launches that used the counter (mod 2^32)                */
+  int32_t reserved;
+} hsr_apply_job;
+int hsr_srf_integrate_moments_apply(const float* cube_dev, int64_t npix, int32_t B,
+                                    const float* wn_dev, const int32_t* k0, const int32_t* klen, int32_t nb,
+                                    float* out_dev, int64_t out_bs, int64_t out_ps,
+                                    const float* real_dev, int64_t real_bs, int64_t real_ps, const uint8_t* mask_dev,
+                                    float min_x, float min_y, int32_t deg,
+                                    double* partials_dev, int32_t* slots_out, const hsr_srf_options* opts,
+                                    const hsr_apply_job* job, hsr_stream_t stream);
+
 /* ---- K1+K2+fit in ONE launch (single tile) ----------------------------------------------------
  * hsr_srf_integrate_moments followed by hsr_moments_reduce_solve without the second launch: every workgroup draws a
  * ticket when its slot of partials is written; the workgroup that completes a group of slots (slot mod 64) adds the
@@ -494,6 +525,12 @@ int hsr_step_run_apply(hsr_step_plan* plan, const uint8_t* mask_dev, hsr_stream_
  * -1 = none.  side_stream must be a real stream (not NULL); a high-priority one gets its own hardware queue. */
 int hsr_pipeline_create(hsr_step_plan* slot0, hsr_step_plan* slot1, hsr_stream_t side_stream, int32_t exchange,
                         hsr_pipeline** pipeline_out);
+/* Fused form over THREE plans: K3 of tile i-2 rides in the launch of K1 of tile i (hsr_srf_integrate_moments_apply) - one kernel
+ * per tile on the caller's stream.  submit(i) finishes tile i-2 (prev_mask_dev = ITS mask); hsr_pipeline_flush finishes the
+ * OLDEST unfinished tile per call (call it until *finished_slot == -1).  HSR_ERR_UNSUPPORTED unless all plans describe the same
+ * float32 geometry with 16-byte aligned pixel-major rows of 4 / 8 / 12 / 16 floats. */
+int hsr_pipeline_create_fused(hsr_step_plan* slot0, hsr_step_plan* slot1, hsr_step_plan* slot2, hsr_stream_t side_stream,
+                              int32_t exchange, hsr_pipeline** pipeline_out);
 void hsr_pipeline_destroy(hsr_pipeline* pipeline);
 int hsr_pipeline_submit(hsr_pipeline* pipeline, const void* cube_dev, const float* real_dev, const uint8_t* mask_dev,
                         const uint8_t* prev_mask_dev, hsr_stream_t main_stream, int32_t* finished_slot,

@@ -1673,6 +1673,69 @@ def test_prepared_launches_match_the_operator_path_bit_for_bit(torch_gpu):
     assert lib.hsr_pipeline_flush(None, None, None, None) == 1 and lib.hsr_pipeline_count(None) == -1
 
 
+def test_fused_pipeline_k3_inside_k1_launch_bit_identical(torch_gpu):
+    """SpectralFusion(fuse_apply=True): K3 of tile i-2 rides in the launch of K1 of tile i (hsr_srf_integrate_moments_apply,
+    hsr_pipeline_create_fused).  Every tile that comes out - two submits late, the rest through drain() - carries the bits of
+    its own step(): degrees 1-4, masks that come and go (the mask of the tile being FINISHED is the one K3 must use), a
+    13-band table (rows of 16 floats) and 3 bands (rows of 4), odd pixel counts, the generic (unaligned) loader; a uint16
+    cube quietly takes the two-slot pipeline; the C entry refuses what the fused launch does not cover."""
+    torch = torch_gpu
+    import ctypes as C
+    from s2_emit import SpectralFusion, _engine as eng, _native as nat
+    w, good = onp.synthetic_wavelengths()
+    srf13 = onp.synthetic_srf()
+    g = torch.Generator(device="cuda")
+    g.manual_seed(11)
+    for names_sel, gm, H, W in ((None, good, 70, 61), (("B4", "B3", "B2"), good, 64, 64), (None, None, 33, 97)):
+        srf = srf13 if names_sel is None else {k: srf13[k] for k in names_sel}
+        nb = eng.build_srf_table(w, srf, gm).nb
+        row = eng.padded_row(nb)
+        npix = H * W
+        base = torch.rand((npix * 285 + 4,), generator=g, device="cuda") * 0.6
+        cubes = [base[:npix * 285].view(H, W, 285), base[1:npix * 285 + 1].view(H, W, 285).clone(),
+                 base[1:npix * 285 + 1].view(H, W, 285)]                          # the last one: 4-byte aligned only
+        reals = [torch.rand((H, W, row), generator=g, device="cuda") for _ in range(3)]
+        masks = [None, (torch.rand(npix, generator=g, device="cuda") > 0.3).to(torch.uint8), None,
+                 (torch.rand(npix, generator=g, device="cuda") > 0.6).to(torch.uint8), None]
+        for deg in (1, 2, 3, 4):
+            kw = dict(deg=deg, min_valid=0.0, min_count=5, apply_mask=True)
+            ref = SpectralFusion(w, srf, gm, **kw)
+            pipe = SpectralFusion(w, srf, gm, fuse_apply=True, **kw)
+            seq = [(cubes[i % 3], reals[i % 3], masks[i % 5]) for i in range(7)]
+            got = []
+            for i, (c, r, m) in enumerate(seq):
+                o = pipe.submit(c, r, m)
+                assert (o is None) == (i < 2), (deg, i)
+                if o is not None:
+                    got.append(tuple(t.clone() for t in (o.pseudo, o.matched, o.moments, o.coeffs)))
+            assert pipe._pipe["fused"] and pipe._pipe["S"] == 3
+            got += [tuple(t.clone() for t in (o.pseudo, o.matched, o.moments, o.coeffs)) for o in pipe.drain()]
+            assert len(got) == len(seq) and pipe.drain() == [] and pipe.flush() is None
+            for i, ((c, r, m), gt) in enumerate(zip(seq, got)):
+                want = ref.step(c, r, m, reuse_buffers=False)
+                assert torch.equal(gt[0].view(torch.int32), want.pseudo.view(torch.int32)), (nb, deg, i, "pseudo")
+                assert torch.equal(gt[1].view(torch.int32), want.matched.view(torch.int32)), (nb, deg, i, "matched")
+                assert torch.equal(gt[2].view(torch.int64), want.moments.view(torch.int64)), (nb, deg, i, "moments")
+                assert torch.equal(gt[3].view(torch.int64), want.coeffs.view(torch.int64)), (nb, deg, i, "coeffs")
+            pipe.close()
+    # uint16 cubes: submit() falls back to the two-slot pipeline, results still equal step()
+    p16 = SpectralFusion(w, srf13, good, deg=2, min_valid=0.0, min_count=5, fuse_apply=True)
+    cu = eng.tile_encode_u16(torch.rand((40, 64, 285), generator=g, device="cuda") * 0.6)
+    ru = torch.rand((40, 64, 12), generator=g, device="cuda")
+    assert p16.submit(cu, ru) is None
+    o = p16.flush()
+    assert not p16._pipe["fused"]
+    want = SpectralFusion(w, srf13, good, deg=2, min_valid=0.0, min_count=5).step(cu, ru, reuse_buffers=False)
+    assert torch.equal(o.matched.view(torch.int32), want.matched.view(torch.int32))
+    # the C entry: a planar output cannot carry an apply job
+    lib = nat.load()
+    job = (C.c_byte * 48)()
+    k = (C.c_int32 * 1)(0)
+    rc = lib.hsr_srf_integrate_moments_apply(C.c_void_p(16), 64, 285, C.c_void_p(16), k, k, 1, C.c_void_p(16), 64, 1, C.c_void_p(16), 64, 1,
+                                             None, 0.0, 0.0, 1, C.c_void_p(16), None, None, C.cast(job, C.c_void_p), None)
+    assert rc in (1, 2) and b"hsr_apply_job" in lib.hsr_last_error() or b"apply job" in lib.hsr_last_error()
+
+
 def test_padded_rows_are_owned_and_zeroed(torch_gpu):
     """Pixel-major outputs with padded rows (nb = 3 -> 4, nb = 13 -> 16): the pad columns come back as zeros, never as
     whatever the LDS staging area held - in K1, through K3 ('channels >= nb pass through'), float32 and uint16."""

@@ -37,12 +37,15 @@ def main():
     out.append("| kernel | calls | avg us | median us | min us | max us |\n|---|---|---|---|---|---|")
     for k, v in sorted(dur.items(), key=lambda kv: -sum(kv[1])):
         out.append(f"| `{k}` | {len(v)} | {sum(v)/len(v)/1e3:.2f} | {statistics.median(v)/1e3:.2f} | {min(v)/1e3:.2f} | {max(v)/1e3:.2f} |")
-    srf = [k for k in dur if "srf_kernel<3" in k] or [k for k in dur if "srf_u16_ring_kernel<3" in k]
+    srf = sorted([k for k in dur if "srf_kernel<3" in k], key=lambda k: -len(dur[k])) or [k for k in dur if "srf_u16_ring_kernel<3" in k]
     if srf:
         avg = sum(dur[srf[0]]) / len(dur[srf[0]])
         cube = 1024 * 1024 * 285 * (2 if "u16" in srf[0] else 4)
-        out.append(f"\nDominant kernel `{srf[0]}`: {avg/1e3:.1f} us average -> {cube/avg:.0f} GB/s of algorithmic cube bytes "
-                   f"({cube} B per launch) = {cube/avg/8000*100:.1f} % of 8 TB/s.\n")
+        fusedk = srf[0].rstrip().endswith("false, true>")          # the fused pipeline's launch also carries K3 of an older tile
+        algo = cube + (1024 * 1024 * 8 * 12 if fusedk else 0)
+        out.append(f"\nDominant kernel `{srf[0]}`: {avg/1e3:.1f} us average -> {algo/avg:.0f} GB/s of algorithmic bytes "
+                   f"({algo} B per launch: the cube{' + 96 B per pixel of K3 (pseudo read, matched written; 12 channels)' if fusedk else ''}) "
+                   f"= {algo/avg/8000*100:.1f} % of 8 TB/s.\n")
     traffic = {}
     if pmc_dir:
         out.append("## PMC passes (`rocprofv3 --pmc <counters> --kernel-trace`), averages per launch\n")
@@ -69,7 +72,12 @@ def main():
         old = json.load(open(tf)) if os.path.isfile(tf) else {}
         per = dict(old.get("per_kernel", {}))
         per.update(traffic)
-        key = [k for k in traffic if "srf_kernel<3" in k and "true, false>" in k] or [k for k in traffic if "srf_kernel<3" in k]
+        fkey = [k for k in traffic if "srf_kernel<3" in k and k.rstrip().endswith("false, true>")]       # APPLY variant: the fused pipeline's launch
+        key = [k for k in traffic if "srf_kernel<3" in k and "true, false>" in k and k not in fkey] or \
+              [k for k in traffic if "srf_kernel<3" in k and k not in fkey]
+        if fkey:
+            old["srf_fused_kernel_hbm_bytes_per_launch"] = traffic[fkey[0]]
+            old["source_fused"] = f"profiles/{tag}_rocprof_summary.md (the launch of the fused pipeline: K1+K2 + K3 of an older tile + tail fit)"
         ukey = [k for k in traffic if "srf_u16_ring_kernel<3" in k]
         old["per_kernel"] = per
         if key:

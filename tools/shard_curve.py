@@ -25,7 +25,8 @@ def main():
     ap.add_argument("--graph", action="store_true")
     ap.add_argument("--ranks", default="1,2,4,8")
     ap.add_argument("--sync-every", type=int, default=0, help="synchronise the device every K calls inside the timed loop (bounds the host's run-ahead)")
-    ap.add_argument("--modes", default="operators,step,submit")
+    ap.add_argument("--modes", default="operators,step,submit,fused")
+    ap.add_argument("--reserve", type=int, default=-1, help="CUs left free of K1 workgroups (-1: 8 in the pipelined modes, 0 otherwise)")
     ap.add_argument("--rows", default=None, help="comma-separated row counts instead of 1024 / ranks (pipeline resonance sweeps)")
     ap.add_argument("--host-cost", action="store_true", help="also time the ISSUE of 200 calls per mode on the 1024-row tile (GPU slower than host: the loop time is the host cost per call)")
     a = ap.parse_args()
@@ -41,7 +42,8 @@ def main():
         res = {"ranks": n, "rows": H}
         for mode in tuple(a.modes.split(",")) + (("graph",) if a.graph else ()):
             plan = SpectralFusion(p.emit_w, p.srf, p.good_mask, deg=3, min_valid=0.0, min_count=50, device=dev,
-                                  reserved_cus=8 if mode == "submit" else 0)
+                                  reserved_cus=(8 if mode == "submit" else 0) if a.reserve < 0 else a.reserve,
+                                  fuse_apply=mode == "fused")
             if mode == "graph":
                 plan.step(p.cube, p.real)
                 torch.cuda.synchronize()
@@ -49,7 +51,7 @@ def main():
                 with torch.cuda.graph(g):
                     plan.step(p.cube, p.real)
                 run = g.replay
-            elif mode == "submit":
+            elif mode in ("submit", "fused"):
                 run = lambda: plan.submit(p.cube, p.real)
             elif mode == "operators":            # the operator-by-operator Python path (what step() was before the executor)
                 import torch as _t
@@ -60,14 +62,14 @@ def main():
             for _ in range(max(50, int(300 * n))):          # settle (profiles/r02_ramp.log) + warm-up
                 run()
             if a.host_cost and H == 1024 and mode != "graph":
-                if mode == "submit":
+                if mode in ("submit", "fused"):
                     plan.flush()
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 for _ in range(200):
                     run()
                 res[mode + "_host"] = round((time.perf_counter() - t0) / 200 * 1e6, 2)      # issue only: no sync inside
-            if mode == "submit":
+            if mode in ("submit", "fused"):
                 plan.flush()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -75,7 +77,7 @@ def main():
                 run()
                 if a.sync_every and (i + 1) % a.sync_every == 0:
                     torch.cuda.synchronize()
-            if mode == "submit":
+            if mode in ("submit", "fused"):
                 plan.flush()
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / a.steps

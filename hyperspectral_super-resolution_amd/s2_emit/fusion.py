@@ -241,8 +241,8 @@ class SpectralFusion:
             return cube, real, {}
         nb = self.table.nb
 
-        def images():          # the plan's output image for step() and the two of the submit() pipeline, in one stretch
-            return [eng.alloc_image(torch, nb, npix, self.layout, self.device) for _ in range(3)]
+        def images():          # the plan's output image for step() and the (up to three) of the submit() pipeline, in one stretch
+            return [eng.alloc_image(torch, nb, npix, self.layout, self.device) for _ in range(4 if self.fuse_apply else 3)]
 
         def make():
             return (cube.clone(), real.clone(), images())
@@ -254,7 +254,7 @@ class SpectralFusion:
                                       reduce=False, layout=self.layout, real_layout=rl, scale=self.tile_scale,
                                       nodata=self.tile_nodata, opts=self.opts)
         first = (cube, real, images())
-        cand_bytes = cube.numel() * cube.element_size() + real.numel() * 4 + 3 * npix * eng.padded_row(nb) * 4
+        cand_bytes = cube.numel() * cube.element_size() + real.numel() * 4 + 4 * npix * eng.padded_row(nb) * 4
         (cube, real, outs), times = self._trials(first, make, k1, candidate_bytes=cand_bytes)
         self._buf[npix] = (outs[0], eng.alloc_image(torch, nb, npix, self.layout, self.device))
         self._pipe_images[npix] = outs[1:]
@@ -753,7 +753,7 @@ class SpectralFusion:
             eng.srf_integrate_moments(cube, self.table, real2, self.deg, self.ws, mask, self.min_valid, self.min_valid,
                                       out=img, reduce=False, layout=self.layout, real_layout=real_layout,
                                       scale=self.tile_scale, nodata=self.tile_nodata, opts=self.opts)
-        placed = self._pipe_images.pop(npix, [])           # placed together with the resident inputs (place_inputs)
+        placed = list(self._pipe_images.pop(npix, []))     # placed together with the resident inputs (place_inputs)
         if len(placed) < 2:
             placed = [eng.alloc_image(torch, nb, npix, self.layout, self.device) for _ in range(2)]
             if self.placement_trials > 1 and npix >= (1 << 16):
@@ -761,7 +761,7 @@ class SpectralFusion:
         # with an exchange the fit needs a collective between reduce and solve, which cannot ride in a kernel's tail: the
         # two-slot pipeline (fit on the side stream) stays the multi-rank form
         fused = self.fuse_apply and self.layout == nat.PIXMAJOR and cube.dtype == torch.float32 and not self._exchanges()
-        if fused:
+        if fused and len(placed) < 3:
             placed = list(placed) + [eng.alloc_image(torch, nb, npix, self.layout, self.device)]
         slots, outs = [], []
         for k in range(3 if fused else 2):

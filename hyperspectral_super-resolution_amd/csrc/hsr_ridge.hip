@@ -10,6 +10,7 @@
 //            LDS (never written to HBM: 1.2 GB per Mpixel otherwise), v_mfma_f32_32x32x2_f32 (exact
 //            float32 fma chain), epilogue intercept + clip + sigmoid, coalesced band-major stores.
 // Feature order = sklearn's: degree-major, combinations_with_replacement (x0..x9, x0^2, x0x1, ..., x9^3).
+#include <mutex>
 #include <vector>
 
 #include "hsr_common.h"
@@ -190,129 +191,324 @@ __global__ __launch_bounds__(256) void gram_f64_kernel(const double* __restrict_
 // the wave's own VALU work (a variant that built the feature panels on chip, 2 v_mul_f64 per operand, ran the
 // MFMAs at exactly MFMA time + VALU time), and the register-operand kernel above stalls on its 24 global loads
 // per batch.  So the operands take the one route that costs no VALU and no VGPRs: global_load_lds_dwordx4
-// straight into two 16-row x 96-column panels (A and B) per batch, double-buffered, and conflict-free
-// ds_read_b64 from there.  A workgroup (4 waves = 2 x 2 blocks of 3 x 3 MFMA tiles) owns a 96 x 96 output block
-// over a chunk of rows; blocks below the diagonal of the symmetric part are not launched.
+// (scalar row base + one constant per-lane offset) straight into two 8-row x 96-column panels (A and B) per
+// batch, ring-buffered, and conflict-free ds_read_b64 from there.  A workgroup (4 waves = 2 x 2 blocks of 3 x 3
+// MFMA tiles) owns a 96 x 96 output block over a chunk of rows; blocks below the diagonal of the symmetric part
+// are not launched.
+//
+// r03 (rocprofv3 PMC on the r02 kernel: matrix pipe busy 58 %, and 9 launched 96 x 96 blocks for 207 useful tiles
+// of 324 at 288 features + 32 targets):
+//  * a last column strip of <= 32 columns (the 32 targets of the notebook) is no longer a ragged 96-wide block
+//    with two thirds of its MFMAs on padding: it is a NARROW block, 96 x 32, 3 x 1 tiles per wave, over chunks
+//    5/2 as long (a third of the MFMAs per row, but the same DMA / barrier / address work: measured 0.72 us against
+//    1.80 us per batch), so that every workgroup takes the same time (9 -> 7.2 block equivalents at T = 32);
+//  * the DMA address is a scalar (global_load_lds with an SGPR base), one exec region covers a wave's four DMAs,
+//    and only batches at the ragged end of the last chunk take the row-checked path;
+//  * ONE workgroup of kGramGroups x 4 waves per CU instead of two of 4 waves: the groups take the batches of the
+//    chunk in turn (group g: batches g, g + G, ...), each with its own panel ring, and their accumulators are added
+//    in group order through LDS at the end.  Three waves per SIMD instead of two, in lockstep - with independent
+//    workgroups (3 x 4 waves per CU, also measured) the oldest workgroup of a CU wins the matrix pipe, finishes at
+//    86 us and leaves the youngest alone until 139 us - and a third of the partial sums: every workgroup writes
+//    72 KB and the reduction reads them again (55 MB each way with 768 workgroups, 18 MB with 256);
+//  * software pipeline over the barrier: the operands of batch b + 1 are read from LDS while the MFMAs of batch b
+//    run, and after the barrier every wave first issues MFMAs and only then its ~60 scalar / DMA / LDS
+//    instructions (4 240 -> 3 750 shader cycles per batch of 3 x 18 MFMAs = 3 456).
+//  What is left: the shader clock runs at 2.10 GHz under this kernel (s_memtime against s_memrealtime), not 2.4.
+#ifndef HSR_GRAM_BUFS
+#define HSR_GRAM_BUFS 4
+#endif
+#ifndef HSR_GRAM_GROUPS
+#define HSR_GRAM_GROUPS 3
+#endif
+#ifndef HSR_GRAM_WGS
+#define HSR_GRAM_WGS 1
+#endif
 constexpr int kGpCols = 96;          // panel width = 6 MFMA tiles
+constexpr int kGpNarrow = 32;        // widest last strip that becomes a narrow block
 constexpr int kGpRows = 8;           // rows per batch = 2 k-steps
-constexpr int kGpBufs = 4;           // panel ring: batch b lives in slot b % 4, the DMA runs 3 batches ahead
+constexpr int kGpBufs = HSR_GRAM_BUFS;   // panel ring: batch b lives in slot b % kGpBufs, the DMA runs kGpBufs - 1 batches ahead
 constexpr int kGpAhead = kGpBufs - 1;
-constexpr int kGpStride = 112;       // doubles per LDS panel row: 896 B = 128 B mod 256 B -> kk rows 0/1 and 2/3 on disjoint banks
-constexpr int kGpDmaPerWave = 2 * kGpRows / 4;   // panel rows (A and B) each wave moves per batch
+constexpr int kGpStride = 208;       // doubles per LDS row = [A 96 | B 96 | 16 spare]: 1664 B = 128 B mod 256 B -> kk rows 0/1 and 2/3 on disjoint banks
+constexpr int kGpDmaPerWave = 2 * kGpRows / 4;   // panel rows each wave moves per batch (waves 0, 1: A; waves 2, 3: B)
+constexpr int kGramGroups = HSR_GRAM_GROUPS;     // 4-wave groups per workgroup
+constexpr int kGramWgs = HSR_GRAM_WGS;           // workgroups per CU
+constexpr int kGramSlots = 256 * kGramWgs;       // resident workgroups of this kernel on the chip
+constexpr int kGramThreads = 256 * kGramGroups;
+constexpr int kGpRingDoubles = kGpBufs * kGpRows * kGpStride;       // one group's panel ring (4 slots: 53 248 B; three groups: 159 744 B)
+constexpr int kGpDumpDoubles = 4 * 9 * 4 * 64;                      // one group's accumulators (72 KB)
+constexpr int kGramLdsDoubles = (kGramGroups == 1 || kGramGroups * kGpRingDoubles > kGpDumpDoubles)
+                                    ? kGramGroups * kGpRingDoubles : kGpDumpDoubles;
+constexpr int kGpMaxBlocks = 64;
 
-struct GramLdsArgs {
-  const double* A;
-  const double* B;
-  int64_t lda, ldb, n, rows_per_chunk;
+struct GramCore {                     // scalars only: handed to the block routine by value (a struct with a dynamically
+  const double* A;                    // indexed array would be copied to scratch, and everything read from it would count
+  const double* B;                    // as divergent)
+  int64_t lda, ldb, n;
+  int64_t rows_wide, rows_narrow;    // rows per chunk of a 96-wide / a narrow block
   int32_t na, nb, tiles_i, tiles_j;
-  double* partials;
-  uint8_t blocks[64][2];             // (bi, bj) of the launched output blocks
+  int32_t nwide, nnarrow;            // launched blocks of either kind (wide ones first in `blocks`)
+  int32_t chunks_wide, chunks_narrow;
+  int32_t narrow_col, narrow_width;  // first column and width of the narrow strip of B
+  int32_t total, per_xcd;            // workgroups with work; ceil(total / 8)
+  double* partials;                  // [chunk][tile][256]
+#ifdef HSR_GRAM_STAMPS
+  unsigned long long* stamps;        // [workgroup][8] s_memrealtime at the phase boundaries (diagnostic builds only)
+#endif
+};
+#ifdef HSR_GRAM_STAMPS
+__device__ __forceinline__ unsigned long long gram_realtime() {   // 100 MHz
+  unsigned long long t;
+  asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+  return t;
+}
+static unsigned long long* g_gram_stamps = nullptr;
+extern "C" void hsr_dbg_gram_stamps(unsigned long long* dev) { g_gram_stamps = dev; }
+#define GRAM_STAMP(i)                                                                                   \
+  do {                                                                                                  \
+    if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 8 + (i)] = gram_realtime();           \
+  } while (0)
+#else
+#define GRAM_STAMP(i) \
+  do {                \
+  } while (0)
+#endif
+struct GramLdsArgs {
+  GramCore c;
+  uint8_t blocks[kGpMaxBlocks][2];   // (bi, bj) in 96-column units; bj is ignored for narrow blocks
 };
 
-__device__ __forceinline__ void glds16_asm(const void* gaddr, uint32_t lds_base) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gaddr), "s"(lds_base) : "memory");
+__device__ __forceinline__ void glds16_s(uint32_t voff, const void* sbase, uint32_t lds_base) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1" ::"v"(voff), "s"(sbase), "s"(lds_base)
+               : "memory");
 }
 
-__global__ __launch_bounds__(256, 2) void gram_f64_lds_kernel(const GramLdsArgs a) {
-  __shared__ __attribute__((aligned(16))) double pan[kGpBufs][2][kGpRows][kGpStride];   // [slot][A|B][row][col]
-  const int bi = a.blocks[blockIdx.x][0], bj = a.blocks[blockIdx.x][1];
+__device__ __forceinline__ const double* uniform_ptr(const double* p) {   // a wave-uniform pointer, provably in SGPRs
+  const uint64_t v = (uint64_t)(uintptr_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v), hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return (const double*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+}
+
+template <int RY>
+__device__ __forceinline__ void gram_block(const GramCore a, double* pan_base, int acol0, int bcol0, int bw,
+                                           int64_t c0, int64_t cend, int chunk) {
   const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wave = __builtin_amdgcn_readfirstlane((tid >> 6) & 3);        // wave inside its group
+  const int grp = __builtin_amdgcn_readfirstlane(tid >> 8);
+  constexpr int G = kGramGroups;
   const int col = lane & 15, kk = lane >> 4;
   const int wx = wave >> 1, wy = wave & 1;
-  const int64_t c0 = (int64_t)blockIdx.y * a.rows_per_chunk;
-  int64_t cend = c0 + a.rows_per_chunk;
-  if (cend > a.n) cend = a.n;
-  const int nbatch = (int)((cend - c0 + kGpRows - 1) / kGpRows);
-  const int nfull = (int)((cend - c0) / kGpRows);   // batches whose rows all exist (every wave issues all its DMAs)
-  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(&pan[0][0][0][0]);
+  // the chunk's batches are dealt to the groups in turn; all groups run the same number of local batches (a batch
+  // past the end of the chunk is zero-filled), so that every wave meets the same barriers
+  const int nbatch_all = (int)((cend - c0 + kGpRows - 1) / kGpRows);
+  const int nbatch = (nbatch_all + G - 1) / G;              // local batches per group
+  const int nfull = (int)((cend - c0) / kGpRows) / G;       // local batches whose rows all exist in every group
+  pan_base += grp * kGpRingDoubles;                         // this group's ring
+  typedef double Slot[kGpRows][kGpStride];
+  Slot* pan = reinterpret_cast<Slot*>(pan_base);            // [slot][row][A cols | B cols]
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(pan_base);
 
-  // 16 panel rows per batch (8 of A, 8 of B), 4 per wave; a row is 96 doubles = 48 lanes x 16 bytes.  Lanes whose
-  // columns lie past the matrix (last block of a ragged width) stay off: their LDS words only feed tiles that are
-  // never stored.  Rows past the chunk are zero-filled by hand (only in the last batch of the last chunk).
-  const int acol = bi * kGpCols + 2 * lane, bcol = bj * kGpCols + 2 * lane;
-  const bool a_on = lane < 48 && acol < a.na, b_on = lane < 48 && bcol < a.nb;
-  auto issue = [&](int b) {
+  // 16 panel rows per batch (8 of A, 8 of B), 4 per wave; a row is up to 96 doubles = 48 lanes x 16 bytes.  Lanes whose
+  // columns lie past the block or the matrix stay off: their LDS words only feed tiles that are never stored.
+  const int p = wave >> 1;                 // which panel this wave fills
+  const int pr0 = (wave & 1) * kGpDmaPerWave;
+  const int mcol0 = p ? bcol0 : acol0;
+  const bool on = p ? (2 * lane < bw && mcol0 + 2 * lane < a.nb) : (lane < 48 && mcol0 + 2 * lane < a.na);
+  const int64_t ld = p ? a.ldb : a.lda;
+  const double* mbase = uniform_ptr((p ? a.B : a.A) + mcol0);
+  const uint32_t voff = (uint32_t)lane * 16u;
+  auto issue_full = [&](int b) {           // every row of batch b exists
+    const int slot = b % kGpBufs;
+    const double* src = mbase + (c0 + (int64_t)(b * G + grp) * kGpRows + pr0) * ld;
+    const uint32_t dst = lds0 + (uint32_t)(((slot * kGpRows + pr0) * kGpStride + p * kGpCols) * 8);
+    if (on) {
+#pragma unroll
+      for (int i = 0; i < kGpDmaPerWave; ++i) glds16_s(voff, src + i * ld, dst + (uint32_t)(i * kGpStride * 8));
+    }
+  };
+  auto issue_any = [&](int b) {            // rows past the chunk are zero-filled by hand
     const int slot = b % kGpBufs;
 #pragma unroll
     for (int i = 0; i < kGpDmaPerWave; ++i) {
-      const int pr = wave * kGpDmaPerWave + i;     // panel row: A rows, then B rows
-      const int p = pr / kGpRows, r = pr % kGpRows;
-      const int64_t row = c0 + (int64_t)b * kGpRows + r;
-      const uint32_t dst = lds0 + (uint32_t)(((slot * 2 + p) * kGpRows + r) * kGpStride * 8);
-      const bool on = p ? b_on : a_on;
+      const int64_t row = c0 + (int64_t)(b * G + grp) * kGpRows + pr0 + i;
+      const uint32_t dst = lds0 + (uint32_t)(((slot * kGpRows + pr0 + i) * kGpStride + p * kGpCols) * 8);
       if (row < cend) {
-        const double* src = p ? a.B + row * a.ldb + bcol : a.A + row * a.lda + acol;
-        if (on) glds16_asm(src, dst);
+        if (on) glds16_s(voff, mbase + row * ld, dst);
       } else if (lane < 48) {
-        pan[slot][p][r][2 * lane] = 0.0;
-        pan[slot][p][r][2 * lane + 1] = 0.0;
+        pan[slot][pr0 + i][p * kGpCols + 2 * lane] = 0.0;
+        pan[slot][pr0 + i][p * kGpCols + 2 * lane + 1] = 0.0;
       }
     }
   };
 
-  constexpr int R = 3;
-  f64x4 acc[R][R];
+  constexpr int R = 3, KU = kGpRows / 4;
+  f64x4 acc[R][RY];
 #pragma unroll
   for (int x = 0; x < R; ++x)
 #pragma unroll
-    for (int y = 0; y < R; ++y) acc[x][y] = f64x4{0.0, 0.0, 0.0, 0.0};
-
-  for (int b = 0; b < kGpAhead && b < nbatch; ++b) issue(b);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  for (int b = 0; b < nbatch; ++b) {
-    // slot (b+3) % 4 held batch b-1: every wave finished reading it before the barrier that ended iteration b-1
-    if (b + kGpAhead < nbatch) issue(b + kGpAhead);
-    const double (*pa)[kGpStride] = pan[b % kGpBufs][0];
-    const double (*pb)[kGpStride] = pan[b % kGpBufs][1];
+    for (int y = 0; y < RY; ++y) acc[x][y] = f64x4{0.0, 0.0, 0.0, 0.0};
+  const int asub = wx * 48;
+  const int bsub = kGpCols + (RY == 3 ? wy * 48 : wy * 16);     // this wave's first B column inside the row
+  struct Ops {
+    double a[KU][R], b[KU][RY];
+  };
+  auto fetch = [&](Ops& o, int b) {        // the operands of local batch b: LDS -> registers
+    const double (*ps)[kGpStride] = pan[b % kGpBufs];
 #pragma unroll
-    for (int u = 0; u < kGpRows / 4; ++u) {
-      double av[R], bv[R];
+    for (int u = 0; u < KU; ++u) {
 #pragma unroll
-      for (int x = 0; x < R; ++x) {
-        av[x] = pa[4 * u + kk][wx * 48 + 16 * x + col];
-        bv[x] = pb[4 * u + kk][wy * 48 + 16 * x + col];
-      }
+      for (int x = 0; x < R; ++x) o.a[u][x] = ps[4 * u + kk][asub + 16 * x + col];
+#pragma unroll
+      for (int y = 0; y < RY; ++y) o.b[u][y] = ps[4 * u + kk][bsub + 16 * y + col];
+    }
+  };
+  auto mma_row = [&](const Ops& o, int u, int x) {
+#pragma unroll
+    for (int y = 0; y < RY; ++y)
+      acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a[u][x], o.b[u][y], acc[x][y], 0, 0, 0);
+  };
+  // One local batch.  On entry the panels of batches <= b + 1 have landed (for every wave of the workgroup) and `cur`
+  // holds the operands of batch b.  The DMA of batch b + 3 goes to the slot of batch b - 1, whose LDS reads were issued
+  // during step b - 2 and had completed before the barrier that ended it.  The operands of batch b + 1 are read while
+  // the MFMAs of batch b run, so that no wave starts a batch by waiting for LDS behind the barrier; the step ends when
+  // the panel of batch b + 2 has landed (the 4 DMAs of batch b + 3 may stay in flight).
+  // The three waves of a SIMD leave the barrier together: each first feeds the matrix pipe (RY MFMAs whose operands are
+  // in registers) and only then runs its ~60 scalar / DMA / LDS instructions, in the shadow of those MFMAs - with the
+  // address work first the pipe stood idle for ~800 of the 4 240 cycles of a batch.
+  auto step = [&](Ops& cur, Ops& nxt, int b) {
+    const bool steady = b + kGpAhead < nfull;
+    mma_row(cur, 0, 0);
+    __builtin_amdgcn_sched_barrier(0);
+    if (steady) issue_full(b + kGpAhead);
+    else if (b + kGpAhead < nbatch) issue_any(b + kGpAhead);
+    if (b + 1 < nbatch) fetch(nxt, b + 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < KU; ++u)
 #pragma unroll
       for (int x = 0; x < R; ++x)
-#pragma unroll
-        for (int y = 0; y < R; ++y)
-          acc[x][y] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[x], bv[y], acc[x][y], 0, 0, 0);
-    }
-    // panel(b+1) must have landed; the DMAs of batches b+2 and b+3 (a full complement each, when both are whole
-    // batches) may stay in flight.  Near the end of the chunk the counts are no longer fixed: wait for everything.
-    if (b + kGpAhead < nfull) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((kGpAhead - 1) * kGpDmaPerWave) : "memory");
+        if (u || x) mma_row(cur, u, x);
+    if (steady) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kGpDmaPerWave) : "memory");
     else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
+  };
+
+  GRAM_STAMP(0);
+  for (int b = 0; b < kGpAhead && b < nbatch; ++b) issue_any(b);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  GRAM_STAMP(1);
+#ifdef HSR_GRAM_STAMPS
+  if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 8 + 6] = __builtin_readcyclecounter();   // s_memtime: shader clock
+#endif
+  {
+    Ops o0, o1;
+    fetch(o0, 0);
+#pragma unroll 1
+    for (int b = 0; b < nbatch; b += 2) {
+      step(o0, o1, b);
+      if (b + 1 < nbatch) step(o1, o0, b + 1);
+    }
   }
+
+#ifdef HSR_GRAM_STAMPS
+  if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 8 + 7] = __builtin_readcyclecounter();
+#endif
+  GRAM_STAMP(2);
+  // the groups' sums, added in group order through LDS (the rings are free: the loop ended in a barrier)
+  if (G > 1) {
+    double* dump = pan_base - grp * kGpRingDoubles + (wave * 9 * 4) * 64 + lane;
+#pragma unroll 1
+    for (int g = 1; g < G; ++g) {
+      if (grp == g) {
+#pragma unroll
+        for (int x = 0; x < R; ++x)
+#pragma unroll
+          for (int y = 0; y < RY; ++y)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) dump[((x * RY + y) * 4 + r) * 64] = acc[x][y][r];
+      }
+      __syncthreads();
+      if (grp == 0) {
+#pragma unroll
+        for (int x = 0; x < R; ++x)
+#pragma unroll
+          for (int y = 0; y < RY; ++y)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[x][y][r] += dump[((x * RY + y) * 4 + r) * 64];
+      }
+      __syncthreads();
+    }
+    if (grp != 0) return;
+  }
+  GRAM_STAMP(3);
 
   const int ntiles = a.tiles_i * a.tiles_j;
 #pragma unroll
   for (int x = 0; x < R; ++x) {
 #pragma unroll
-    for (int y = 0; y < R; ++y) {
-      const int ti = bi * 6 + wx * 3 + x, tj = bj * 6 + wy * 3 + y;
-      if (ti >= a.tiles_i || tj >= a.tiles_j) continue;
-      double* out = a.partials + ((size_t)blockIdx.y * ntiles + (size_t)ti * a.tiles_j + tj) * 256;
+    for (int y = 0; y < RY; ++y) {
+      const int ti = acol0 / 16 + wx * 3 + x, tjl = RY == 3 ? wy * 3 + y : wy;
+      const int tj = bcol0 / 16 + tjl;
+      if (ti >= a.tiles_i || tj >= a.tiles_j || 16 * tjl >= bw) continue;
+      double* out = a.partials + ((size_t)chunk * ntiles + (size_t)ti * a.tiles_j + tj) * 256;
 #pragma unroll
       for (int g = 0; g < 4; ++g) out[(kk + 4 * g) * 16 + col] = acc[x][y][g];
     }
   }
+#ifdef HSR_GRAM_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  GRAM_STAMP(4);
+  if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 8 + 5] = (unsigned long long)(RY * 1000000 + nbatch);
+#endif
+}
+
+// Workgroup id -> (block, chunk): consecutive ids are the blocks of one chunk of rows, and the eight XCDs take
+// contiguous runs of ids (hardware deals workgroup w to XCD w % 8), so that the workgroups that read the same rows
+// of A sit behind the same L2.
+__global__ __launch_bounds__(kGramThreads, HSR_GRAM_WGS) void gram_f64_lds_kernel(const GramLdsArgs args) {
+  extern __shared__ __attribute__((aligned(16))) double pan[];   // kGramLdsDoubles
+  const GramCore a = args.c;
+  const int id = (int)(blockIdx.x % 8) * a.per_xcd + (int)(blockIdx.x / 8);
+  if (id >= a.total) return;
+  const int wide_ids = a.nwide * a.chunks_wide;
+  if (id < wide_ids) {
+    const int k = id % a.nwide, chunk = id / a.nwide;
+    const int64_t c0 = (int64_t)chunk * a.rows_wide;
+    int64_t cend = c0 + a.rows_wide;
+    if (cend > a.n) cend = a.n;
+    gram_block<3>(a, pan, args.blocks[k][0] * kGpCols, args.blocks[k][1] * kGpCols, kGpCols, c0, cend, chunk);
+  } else {
+    const int k = a.nwide + (id - wide_ids) % a.nnarrow, chunk = (id - wide_ids) / a.nnarrow;
+    const int64_t c0 = (int64_t)chunk * a.rows_narrow;
+    int64_t cend = c0 + a.rows_narrow;
+    if (cend > a.n) cend = a.n;
+    gram_block<1>(a, pan, args.blocks[k][0] * kGpCols, a.narrow_col, a.narrow_width, c0, cend, chunk);
+  }
 }
 
 // chunks summed in index order -> C[(ti*16 + r) * ldc + tj*16 + c]; tiles of skipped blocks are the
-// transposes of their mirror tiles
+// transposes of their mirror tiles.  Tiles from column tile `narrow_tj` on have `chunks_narrow` chunks.
 __global__ __launch_bounds__(256) void gram_reduce_kernel(const double* __restrict__ partials, int ntiles, int chunks,
-                                                          int tiles_j, int sym, int blk, double* __restrict__ C,
-                                                          int64_t ldc) {
+                                                          int tiles_j, int sym, int blk, int narrow_tj,
+                                                          int chunks_narrow, double* __restrict__ C, int64_t ldc) {
   const int tile = blockIdx.x, e = threadIdx.x;
   const int ti = tile / tiles_j, tj = tile % tiles_j;
   const bool mirror = gram_block_skipped(ti / blk, tj / blk, sym);   // blk = tiles per skipped block edge
   const int src_tile = mirror ? tj * tiles_j + ti : tile;
   const int src_e = mirror ? (e & 15) * 16 + (e >> 4) : e;
+  const int nc = (src_tile % tiles_j) >= narrow_tj ? chunks_narrow : chunks;
+  const double* p = partials + (size_t)src_tile * 256 + src_e;
+  const size_t step = (size_t)ntiles * 256;
   double s = 0.0;
-  for (int c = 0; c < chunks; ++c) s += partials[((size_t)c * ntiles + src_tile) * 256 + src_e];
+  int c = 0;
+  for (; c + 8 <= nc; c += 8) {          // eight loads in flight, the sum stays in chunk order
+    double v[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) v[i] = p[(size_t)(c + i) * step];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += v[i];
+  }
+  for (; c < nc; ++c) s += p[(size_t)c * step];
   C[(size_t)(ti * 16 + (e >> 4)) * ldc + tj * 16 + (e & 15)] = s;
 }
 
@@ -786,28 +982,58 @@ extern "C" int hsr_polyfeat_expand_f64(const float* x_dev, int64_t x_rs, int64_t
   return HSR_OK;
 }
 
-// Row chunking of the LDS-panel kernel: launched blocks x chunks should fill the 512 resident workgroup slots
-// (256 CUs x 2) in whole rounds - 513 workgroups take as long as 1024.  One round when that leaves >= 256 rows
-// per chunk, else as many chunks as fit.
-static int gram_lds_blocks(int na, int nb, int sym) {
-  const int nbi = (na + kGpCols - 1) / kGpCols, nbj = (nb + kGpCols - 1) / kGpCols;
+// Decomposition of the LDS-panel kernel.  Blocks: every 96 x 96 block of the result that is not below the diagonal
+// of the symmetric part, plus - when B ends in a strip of <= 32 columns - one narrow block per 96 rows of A.
+// Chunks: rows per chunk (whole batches of 16) as small as fills the resident workgroup slots in ONE round
+// (513 workgroups take as long as 1024), a narrow block taking 5/2 of the rows of a wide one; >= 256 rows per
+// chunk and <= 256 chunks, as the work buffer is sized for.
+static bool gram_lds_plan(int na, int nb, int sym, int64_t n, GramLdsArgs* g) {
+  const int nbi = (na + kGpCols - 1) / kGpCols;
+  const int rem = nb % kGpCols;
+  const bool strip = rem > 0 && rem <= kGpNarrow;
+  const int nbj = strip ? nb / kGpCols : (nb + kGpCols - 1) / kGpCols;
   int k = 0;
   for (int bi = 0; bi < nbi; ++bi)
     for (int bj = 0; bj < nbj; ++bj)
-      if (!(sym && bj < bi)) ++k;
-  return k;
-}
-
-static int64_t gram_lds_chunks(int64_t n, int nblocks, int64_t* rows_out) {
-  int64_t chunks = 512 / nblocks;
-  if (chunks * 256 > n) chunks = n / 256;
-  if (chunks > 256) chunks = 256;
-  if (chunks < 1) chunks = 1;
-  int64_t rows = (n + chunks - 1) / chunks;
-  rows = (rows + 15) / 16 * 16;                    // whole batches
-  chunks = (n + rows - 1) / rows;
-  if (rows_out) *rows_out = rows;
-  return chunks;
+      if (!(sym && bj < bi)) {
+        if (k < kGpMaxBlocks) {
+          g->blocks[k][0] = (uint8_t)bi;
+          g->blocks[k][1] = (uint8_t)bj;
+        }
+        ++k;
+      }
+  g->c.nwide = k;
+  g->c.nnarrow = strip ? nbi : 0;
+  for (int bi = 0; strip && bi < nbi; ++bi, ++k)
+    if (k < kGpMaxBlocks) {
+      g->blocks[k][0] = (uint8_t)bi;
+      g->blocks[k][1] = (uint8_t)nbj;
+    }
+  if (k > kGpMaxBlocks) return false;
+  g->c.narrow_col = strip ? nbj * kGpCols : nb;
+  g->c.narrow_width = strip ? rem : 0;
+  // a narrow block has a third of the MFMAs of a wide one per row but the same DMA, barrier and address work:
+  // measured 0.72 us against 1.80 us per batch, so it takes 5/2 of the rows for the same time
+  auto narrow_rows = [](int64_t rows) { return rows / 2 * 5; };
+  auto count = [&](int64_t rows, int64_t* cw, int64_t* cn) {
+    *cw = g->c.nwide ? (n + rows - 1) / rows : 0;
+    *cn = g->c.nnarrow ? (n + narrow_rows(rows) - 1) / narrow_rows(rows) : 0;
+    return g->c.nwide * *cw + g->c.nnarrow * *cn;
+  };
+  // start from the even split and grow until the count fits
+  int64_t rows = (int64_t)((double)n * (g->c.nwide + g->c.nnarrow / 2.5) / kGramSlots);
+  rows = (rows + 15) / 16 * 16;
+  const int64_t floor_rows = g->c.nwide ? 256 : 96;   // narrow-only (nb <= 32): chunks of >= 288 rows
+  if (rows < floor_rows) rows = floor_rows;
+  int64_t cw = 0, cn = 0;
+  while (count(rows, &cw, &cn) > kGramSlots || cw > 256 || cn > 256) rows += 16;
+  g->c.rows_wide = rows;
+  g->c.rows_narrow = narrow_rows(rows);
+  g->c.chunks_wide = (int32_t)cw;
+  g->c.chunks_narrow = (int32_t)cn;
+  g->c.total = (int32_t)(g->c.nwide * cw + g->c.nnarrow * cn);
+  g->c.per_xcd = (g->c.total + 7) / 8;
+  return true;
 }
 
 static int64_t gram_reg_chunks(int64_t n, int64_t* rows_out) {
@@ -823,7 +1049,9 @@ static int64_t gram_reg_chunks(int64_t n, int64_t* rows_out) {
 extern "C" size_t hsr_gram_work_bytes(int32_t na, int32_t nb, int64_t n) {
   if (na < 16 || nb < 16 || n < 1) return 0;
   // both kernels use at most 256 chunks; size for the larger count so that either path can run
-  int64_t c1 = gram_reg_chunks(n, nullptr), c2 = gram_lds_chunks(n, gram_lds_blocks(na, nb, nb >= na), nullptr);
+  GramLdsArgs g{};
+  int64_t c1 = gram_reg_chunks(n, nullptr), c2 = 0;
+  if (gram_lds_plan(na, nb, nb >= na, n, &g)) c2 = g.c.chunks_wide > g.c.chunks_narrow ? g.c.chunks_wide : g.c.chunks_narrow;
   const int64_t chunks = c1 > c2 ? c1 : c2;
   return (size_t)chunks * (na / 16) * (nb / 16) * 256 * sizeof(double);
 }
@@ -840,33 +1068,32 @@ extern "C" int hsr_gram_f64(const double* a_dev, int64_t lda, int32_t na, const 
   const int sym = (a_dev == b_dev && lda == ldb && nb >= na) ? 1 : 0;
   hipStream_t s = (hipStream_t)stream;
   const bool dma_ok = (lda % 2 == 0) && (ldb % 2 == 0) && (((uintptr_t)a_dev | (uintptr_t)b_dev) & 15) == 0;
-  const int nblocks = gram_lds_blocks(na, nb, sym);
-  if (dma_ok && nblocks <= 64) {
-    GramLdsArgs g{};
-    g.A = a_dev;
-    g.B = b_dev;
-    g.lda = lda;
-    g.ldb = ldb;
-    g.n = n;
-    g.na = na;
-    g.nb = nb;
-    g.tiles_i = ti;
-    g.tiles_j = tj;
-    g.partials = work_dev;
-    const int nbi = (na + kGpCols - 1) / kGpCols, nbj = (nb + kGpCols - 1) / kGpCols;
-    int k = 0;
-    for (int bi = 0; bi < nbi; ++bi)
-      for (int bj = 0; bj < nbj; ++bj)
-        if (!(sym && bj < bi)) {
-          g.blocks[k][0] = (uint8_t)bi;
-          g.blocks[k][1] = (uint8_t)bj;
-          ++k;
-        }
-    const int64_t chunks = gram_lds_chunks(n, nblocks, &g.rows_per_chunk);
-    hipLaunchKernelGGL(gram_f64_lds_kernel, dim3(nblocks, (unsigned)chunks), dim3(256), 0, s, g);
-    hipLaunchKernelGGL(gram_reduce_kernel, dim3(ti * tj), dim3(256), 0, s, work_dev, ti * tj, (int)chunks, tj, sym,
-                       kGpCols / 16, c_dev, ldc);
+  GramLdsArgs g{};
+  if (dma_ok && gram_lds_plan(na, nb, sym, n, &g)) {
+    g.c.A = a_dev;
+    g.c.B = b_dev;
+    g.c.lda = lda;
+    g.c.ldb = ldb;
+    g.c.n = n;
+    g.c.na = na;
+    g.c.nb = nb;
+    g.c.tiles_i = ti;
+    g.c.tiles_j = tj;
+    g.c.partials = work_dev;
+#ifdef HSR_GRAM_STAMPS
+    g.c.stamps = g_gram_stamps;
+#endif
+    static std::once_flag lds_once;
+    constexpr size_t lds_bytes = (size_t)kGramLdsDoubles * sizeof(double);
+    std::call_once(lds_once, [] {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(gram_f64_lds_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds_bytes);
+    });
+    hipLaunchKernelGGL(gram_f64_lds_kernel, dim3(8 * (unsigned)g.c.per_xcd), dim3(kGramThreads), lds_bytes, s, g);
     HSR_LAUNCH_CHECK("gram_f64_lds_kernel");
+    hipLaunchKernelGGL(gram_reduce_kernel, dim3(ti * tj), dim3(256), 0, s, work_dev, ti * tj, g.c.chunks_wide, tj, sym,
+                       kGpCols / 16, g.c.narrow_col / 16, g.c.chunks_narrow, c_dev, ldc);
+    HSR_LAUNCH_CHECK("gram_reduce_kernel");
     return HSR_OK;
   }
   int64_t rows = 0;
@@ -874,7 +1101,8 @@ extern "C" int hsr_gram_f64(const double* a_dev, int64_t lda, int32_t na, const 
   constexpr int R = hsr::kGramR;
   hipLaunchKernelGGL(gram_f64_kernel, dim3(((ti + R - 1) / R) * ((tj + R - 1) / R), (unsigned)chunks), dim3(256), 0, s,
                      a_dev, lda, ti, b_dev, ldb, tj, n, rows, sym, work_dev);
-  hipLaunchKernelGGL(gram_reduce_kernel, dim3(ti * tj), dim3(256), 0, s, work_dev, ti * tj, (int)chunks, tj, sym, R, c_dev, ldc);
+  hipLaunchKernelGGL(gram_reduce_kernel, dim3(ti * tj), dim3(256), 0, s, work_dev, ti * tj, (int)chunks, tj, sym, R, tj,
+                     (int)chunks, c_dev, ldc);
   HSR_LAUNCH_CHECK("gram_f64_kernel");
   return HSR_OK;
 }

@@ -81,7 +81,10 @@ def test_sizing_helpers_and_error_strings():
     assert lib.hsr_ot_sinkhorn_barycentric(P, 10, P, 10, -1.0, 5, 1e-6, P, P, None, None) == 1 and b"reg must be > 0" in lib.hsr_last_error()
     assert lib.hsr_ot_iterate(10, 10, 0, 5, 1e-6, ctypes.c_void_p(8), None, None) == 1 and b"256-byte aligned" in lib.hsr_last_error()
     assert lib.hsr_gram_f64(P, 30, 32, P, 48, 48, 10, P, P, 48, None) == 1
-    assert lib.hsr_gram_work_bytes(288, 576, 29127) >= 34 * 18 * 36 * 256 * 8
+    # one 2 KB tile of partial sums per (chunk, output tile): 29 chunks of <= 1024 rows for the register-operand kernel
+    # (the LDS-panel kernel uses fewer, longer chunks: one workgroup per CU)
+    assert lib.hsr_gram_work_bytes(288, 576, 29127) >= 29 * 18 * 36 * 256 * 8
+    assert lib.hsr_gram_work_bytes(288, 320, 29127) >= 29 * 18 * 20 * 256 * 8 and lib.hsr_gram_work_bytes(8, 16, 100) == 0
     assert lib.hsr_probe_read(P, 1 << 20, 4, P, None) == 1 and b"mode" in lib.hsr_last_error()
     # entry points added in round 2 validate the same way (no launch without a GPU: every call below fails its checks first)
     assert lib.hsr_srf_integrate_fit(P, 10, 285, P, k, k, 1, P, 1, 16, P, 1, 16, None, 0.0, 0.0, 3, P, None, None, None, None) == 1

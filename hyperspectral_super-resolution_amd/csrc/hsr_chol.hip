@@ -47,6 +47,10 @@ __device__ __forceinline__ double rcp_nr(double d) {
   return r;
 }
 
+// Barrier that orders LDS traffic only: __syncthreads() also waits for vmcnt(0), i.e. for global loads a wave has issued
+// ahead of time on purpose (chol_solve_kernel's tile of the next step).
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
 // sum over the 4 lanes of a quad (two DPP quad permutes per half), in every lane
 __device__ __forceinline__ double quad_sum(double v) {
   v += __hiloint2double(__builtin_amdgcn_update_dpp(0, __double2hiint(v), 0xB1, 0xf, 0xf, false),
@@ -108,7 +112,11 @@ __global__ __launch_bounds__(1024) void chol_factor_kernel(double* __restrict__ 
     // r03 cycle stamps: this loop is ~48 % of the kernel at ~620 cycles per column step.  Two restructurings were built to parity
     // and measured slower, so the loop stays as it is: two columns per barrier with a rank-2 update (1 350 cycles per pair), and
     // the next pivot's reciprocal computed one step ahead next to the update (+6 %).  The step is not bound by the reciprocal
-    // chain or by the barrier count but by the LDS round trips of the 16 waves.
+    // chain or by the barrier count but by the LDS round trips of the 16 waves.  Later in r03 the block was moved out of LDS
+    // altogether - every thread's element of (D | E^T) in a register, only the column the next step needs published (32
+    // doubles, double-buffered) and read back with three loads per thread; the panel arriving by LDS-DMA meanwhile - bit-identical
+    // and SLOWER: 706 cycles per step fully unrolled, 772 rolled (601 here); waves 0-3 alone with a 2 x 2 register tile per
+    // thread: 880.  The step's floor is the write -> barrier -> read round trip plus the reciprocal chain, not the LDS volume.
     for (int j = 0; j < kCb - 1; ++j) {
       if (ti > j && tj > j && tj <= ti) {
         D[ti][tj] -= D[ti][j] * D[tj][j] * rcp_nr(D[j][j]);
@@ -209,108 +217,143 @@ __global__ __launch_bounds__(1024) void chol_factor_kernel(double* __restrict__ 
 }
 
 // L y = b, then L^T x = y, in place in B - blocked, on the float64 matrix cores.  One workgroup of 1024 threads per slab
-// of 32 right-hand sides; the slab lives in LDS (Y, n x 32) for the whole solve.  Per 32-row block k, forward:
-//     X   = Linv_kk  Y_k                      four 16 x 16 tiles (waves 0-3), 8 MFMA steps each
-//     Y_r -= L_rk X   for the rows r below    (n - kb - 32) / 16 x 2 tiles over the 16 waves, L read from global (L2)
+// of 16 right-hand sides; the slab lives in LDS (Y, n x 16) for the whole solve.  Per 32-row block k, forward:
+//     X   = Linv_kk  Y_k                      two 16 x 16 tiles (waves 0, 1), 8 MFMA steps each
+//     Y_r -= L_rk X   for the rows r below    (n - kb - 32) / 16 tiles, one per wave, L read from global (L2)
 // and backward the same with Linv_kk^T and L^T (whose tiles are read along the coalesced direction of the row-major
 // factor).  Round 2 ran one wave per right-hand side with matrix-VECTOR products: every wave re-read all of L and the
 // block inverses with one 8-byte load per multiply-add - 92 us for 32 right-hand sides (r03 rocprofv3), most of it load
-// latency.  Here a tile of L is read once per slab and feeds 32 right-hand sides.
+// latency.  The first r03 version (slabs of 32, two tiles per wave) took 67 us: 18 block steps of 3.7 us, each of them
+// one exposed L2 round trip for the wave's tiles of L (issued at the top of the step, needed after the block solve) on top
+// of two chains of 8 dependent MFMAs.  With slabs of 16 a wave has ONE tile per step, so that the tile of the NEXT step
+// fits in registers beside it (2 x 8 doubles) and is fetched a whole step ahead; a 32-target fit also runs on two CUs.
 // MFMA operand layout (as in chol_factor_kernel): lane (col = lane & 15, kk = lane >> 4) supplies A[16 I + col][4 s + kk]
-// and B^T[16 J + col][4 s + kk]; accumulator register g is element (row kk + 4 g, column col) of the tile.
-constexpr int kYs = kCb + 1;   // LDS row stride of the slab
-constexpr int kSolveTiles = 2; // update tiles per wave whose L operands are prefetched: n = 288 -> 32 tiles over 16 waves
+// and B^T[col][4 s + kk]; accumulator register g is element (row kk + 4 g, column col) of the tile.
+constexpr int kSw = 16;        // right-hand sides per slab
+constexpr int kYs = kSw + 1;   // LDS row stride of the slab
 __global__ __launch_bounds__(1024) void chol_solve_kernel(const double* __restrict__ L, int64_t lda, int n,
                                                           const double* __restrict__ dinv, double* __restrict__ B,
-                                                          int64_t ldb, int T, int dinv_in_lds) {
+                                                          int64_t ldb, int T, int dinv_in_lds CHOL_STAMP_PARAM) {
   extern __shared__ __attribute__((aligned(16))) double solve_lds[];
+#ifdef HSR_CHOL_STAMPS
+#define SOLVE_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x == 0 && stamps) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); stamps[200 + (k)] = t_; } } while (0)
+#else
+#define SOLVE_STAMP(k)
+#endif
+  SOLVE_STAMP(0);
   double (*Y)[kYs] = reinterpret_cast<double (*)[kYs]>(solve_lds);
   double (*X)[kYs] = reinterpret_cast<double (*)[kYs]>(solve_lds + (size_t)n * kYs);
-  double* dl = solve_lds + (size_t)(n + kCb) * kYs;        // all block inverses, when they fit (n <= 288)
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double* dl = solve_lds + (size_t)(n + kCb) * kYs;        // all block inverses, when they fit
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int col = lane & 15, kk = lane >> 4;
-  const int c0 = blockIdx.x * kCb;
-  for (int e = tid; e < n * kCb; e += 1024) {
-    const int r = e >> 5, c = e & 31;
+  const int c0 = blockIdx.x * kSw;
+  for (int e = tid; e < n * kSw; e += 1024) {
+    const int r = e >> 4, c = e & 15;
     Y[r][c] = c0 + c < T ? B[(int64_t)r * ldb + c0 + c] : 0.0;
   }
+  // rows of the block inverses padded to 33 doubles in LDS: with the dense stride of 32 (= 64 banks) the 16 rows a wave reads
+  // for one MFMA operand start in the same bank
   if (dinv_in_lds)
-    for (int e = tid; e < n * kCb; e += 1024) dl[e] = dinv[e];
-  __syncthreads();
-  const double* dsrc = dinv_in_lds ? dl : dinv;
-#pragma unroll 1
-  for (int pass = 0; pass < 2; ++pass) {                 // 0: forward with L, 1: backward with L^T
-    const int64_t sr = pass == 0 ? lda : 1, sc = pass == 0 ? 1 : lda;    // L (forward) or L^T (backward) element (r, c)
-    const int dr = pass == 0 ? kCb : 1, dc = pass == 0 ? 1 : kCb;        // the same for the block inverse
-#pragma unroll 1
-    for (int step = 0; step < n / kCb; ++step) {
-      const int kb = pass == 0 ? step * kCb : n - kCb - step * kCb;
-      // (1) this wave's tiles of L for the update of the other rows: they do not depend on X, so their loads go out
-      //     first and their L2 latency runs under the block solve and its barrier
-      const int r0 = pass == 0 ? kb + kCb : 0;
-      const int ntile = (pass == 0 ? (n - kb - kCb) : kb) / 16 * 2;
-      double av[kSolveTiles][kCb / 4];
+    for (int e = tid; e < n * kCb; e += 1024) dl[(e >> 5) * kCs + (e & 31)] = dinv[e];
+  const int ds = dinv_in_lds ? kCs : kCb;                                // row stride of a block inverse
+  const int nsteps = n / kCb;
+  // step q = 0 .. 2 nsteps - 1: forward with L over the blocks top down, then backward with L^T bottom up
+  struct Step {
+    int kb, r0, ntile;
+    int64_t sr, sc;      // element (r, c) of L (forward) or L^T (backward)
+  };
+  auto step_of = [&](int q) {
+    Step s;
+    const bool fwd = q < nsteps;
+    s.kb = fwd ? q * kCb : n - kCb - (q - nsteps) * kCb;
+    s.r0 = fwd ? s.kb + kCb : 0;
+    s.ntile = (fwd ? n - s.kb - kCb : s.kb) / 16;
+    s.sr = fwd ? lda : 1;
+    s.sc = fwd ? 1 : lda;
+    return s;
+  };
+  auto load_tile = [&](double (&av)[kCb / 4], const Step& s, int t) {   // this wave's 16 x 32 tile of L for the update of step s
+    const int row = s.r0 + 16 * t + col;
 #pragma unroll
-      for (int u = 0; u < kSolveTiles; ++u) {
-        const int t = wave + 16 * u;
-        if (t < ntile) {
-          const int row = r0 + 16 * (t >> 1) + col;
+    for (int st = 0; st < kCb / 4; ++st) av[st] = L[(int64_t)row * s.sr + (int64_t)(s.kb + 4 * st + kk) * s.sc];
+  };
+  double av[kCb / 4], an[kCb / 4];
 #pragma unroll
-          for (int st = 0; st < kCb / 4; ++st) {
-            const int p = 4 * st + kk;
-            av[u][st] = L[(int64_t)row * sr + (int64_t)(kb + p) * sc];
-          }
-        }
-      }
-      // (2) X = Linv_kk Y_k (forward) / Linv_kk^T Y_k (backward)
-      const double* di = dsrc + (size_t)(kb / kCb) * kCb * kCb;          // Linv_kk, row-major
-      if (wave < 4) {
-        const int I = wave >> 1, J = wave & 1;
-        chol_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int st = 0; st < kCb / 4; ++st) {
-          const int p = 4 * st + kk;
-          const double a = di[(16 * I + col) * dr + p * dc];
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, Y[kb + p][16 * J + col], acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) X[16 * I + kk + 4 * g][16 * J + col] = acc[g];
-      }
-      __syncthreads();
-      Y[kb + (tid >> 5)][tid & 31] = X[tid >> 5][tid & 31];              // 32 x 32 = one element per thread
-      // (3) the other rows: below the block (forward) / above it (backward)
-#pragma unroll
-      for (int u = 0; u < kSolveTiles; ++u) {
-        const int t = wave + 16 * u;
-        if (t < ntile) {
-          const int I = t >> 1, J = t & 1;
-          chol_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-          for (int st = 0; st < kCb / 4; ++st)
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u][st], X[4 * st + kk][16 * J + col], acc, 0, 0, 0);
-#pragma unroll
-          for (int g = 0; g < 4; ++g) Y[r0 + 16 * I + kk + 4 * g][16 * J + col] -= acc[g];
-        }
-      }
-      for (int t = wave + 16 * kSolveTiles; t < ntile; t += 16) {         // n > 288: the tiles beyond the prefetched ones
-        const int I = t >> 1, J = t & 1;
-        const int row = r0 + 16 * I + col;
-        chol_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int st = 0; st < kCb / 4; ++st) {
-          const int p = 4 * st + kk;
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(L[(int64_t)row * sr + (int64_t)(kb + p) * sc], X[p][16 * J + col], acc, 0, 0, 0);
-        }
-#pragma unroll
-        for (int g = 0; g < 4; ++g) Y[r0 + 16 * I + kk + 4 * g][16 * J + col] -= acc[g];
-      }
-      __syncthreads();
-    }
+  for (int st = 0; st < kCb / 4; ++st) av[st] = an[st] = 0.0;
+  {
+    const Step s0 = step_of(0);
+    if (wave < s0.ntile) load_tile(av, s0, wave);
   }
-  for (int e = tid; e < n * kCb; e += 1024) {
-    const int r = e >> 5, c = e & 31;
+  __syncthreads();
+  SOLVE_STAMP(1);
+  // one step; `cur` holds this wave's tile of L for step q, `nxt` receives the one for step q + 1 (the two arrays swap roles
+  // from step to step: a register copy at the end of the step would wait for the loads just issued)
+  auto run_step = [&](double (&cur)[kCb / 4], double (&nxt)[kCb / 4], int q) {
+    const Step s = step_of(q);
+    const bool fwd = q < nsteps;
+    const int dr = fwd ? ds : 1, dc = fwd ? 1 : ds;                     // element (r, c) of the block inverse / its transpose
+    // (1) the wave's tile of the NEXT step: does not depend on anything computed here, a whole step of lead
+    if (q + 1 < 2 * nsteps) {
+      const Step sn = step_of(q + 1);
+      if (wave < sn.ntile) load_tile(nxt, sn, wave);
+    }
+    // (2) X = Linv_kk Y_k (forward) / Linv_kk^T Y_k (backward)
+    // (two copies on purpose: through ONE pointer that may be LDS or global the operand loads become flat loads, and a flat
+    // load waits for vmcnt(0) - i.e. for the tile fetched ahead in (1); measured: 3.5 k cycles per block solve instead of 1 k)
+    if (wave < 2) {
+      chol_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+      const size_t blk = (size_t)(s.kb / kCb) * kCb * ds;                // Linv_kk, row-major
+      if (dinv_in_lds) {
+#pragma unroll
+        for (int st = 0; st < kCb / 4; ++st) {
+          const int p = 4 * st + kk;
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(dl[blk + (16 * wave + col) * dr + p * dc], Y[s.kb + p][col], acc, 0, 0, 0);
+        }
+      } else {
+#pragma unroll
+        for (int st = 0; st < kCb / 4; ++st) {
+          const int p = 4 * st + kk;
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(dinv[blk + (16 * wave + col) * dr + p * dc], Y[s.kb + p][col], acc, 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) X[16 * wave + kk + 4 * g][col] = acc[g];
+    }
+    lds_barrier();
+    SOLVE_STAMP(2 + 2 * q);
+    if (tid < kCb * kSw) Y[s.kb + (tid >> 4)][tid & 15] = X[tid >> 4][tid & 15];
+    // (3) the other rows: below the block (forward) / above it (backward)
+    if (wave < s.ntile) {
+      chol_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int st = 0; st < kCb / 4; ++st) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(cur[st], X[4 * st + kk][col], acc, 0, 0, 0);
+#pragma unroll
+      for (int g = 0; g < 4; ++g) Y[s.r0 + 16 * wave + kk + 4 * g][col] -= acc[g];
+    }
+    for (int t = wave + 16; t < s.ntile; t += 16) {                      // n > 288: the tiles beyond one per wave
+      const int row = s.r0 + 16 * t + col;
+      chol_f64x4 acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int st = 0; st < kCb / 4; ++st) {
+        const int p = 4 * st + kk;
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(L[(int64_t)row * s.sr + (int64_t)(s.kb + p) * s.sc], X[p][col], acc, 0, 0, 0);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) Y[s.r0 + 16 * t + kk + 4 * g][col] -= acc[g];
+    }
+    lds_barrier();
+    SOLVE_STAMP(3 + 2 * q);
+  };
+#pragma unroll 1
+  for (int q = 0; q < 2 * nsteps; q += 2) {
+    run_step(av, an, q);
+    run_step(an, av, q + 1);
+  }
+  for (int e = tid; e < n * kSw; e += 1024) {
+    const int r = e >> 4, c = e & 15;
     if (c0 + c < T) B[(int64_t)r * ldb + c0 + c] = Y[r][c];
   }
+  SOLVE_STAMP(2 + 4 * nsteps);
 }
 
 }  // namespace hsr
@@ -334,15 +377,15 @@ extern "C" int hsr_chol_solve_f64(double* a_dev, int64_t lda, int32_t n, double*
   }
   hipLaunchKernelGGL(chol_factor_kernel, dim3(1), dim3(1024), lds_f, s, a_dev, lda, n, info_dev, work_dev CHOL_STAMP_ARG);
   size_t lds_s = ((size_t)n + kCb) * kYs * sizeof(double);
-  const int dinv_in_lds = lds_s + (size_t)n * kCb * sizeof(double) <= 160 * 1024 ? 1 : 0;
-  if (dinv_in_lds) lds_s += (size_t)n * kCb * sizeof(double);
+  const int dinv_in_lds = lds_s + (size_t)n * kCs * sizeof(double) <= 160 * 1024 ? 1 : 0;
+  if (dinv_in_lds) lds_s += (size_t)n * kCs * sizeof(double);
   static thread_local size_t configured_s = 0;
   if (lds_s > configured_s) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_solve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_s);
     (void)hipGetLastError();
     configured_s = lds_s;
   }
-  hipLaunchKernelGGL(chol_solve_kernel, dim3((nrhs + kCb - 1) / kCb), dim3(1024), lds_s, s, a_dev, lda, n, work_dev, b_dev, ldb, nrhs, dinv_in_lds);
+  hipLaunchKernelGGL(chol_solve_kernel, dim3((nrhs + kSw - 1) / kSw), dim3(1024), lds_s, s, a_dev, lda, n, work_dev, b_dev, ldb, nrhs, dinv_in_lds CHOL_STAMP_ARG);
   HSR_LAUNCH_CHECK("chol kernels");
   return HSR_OK;
 }

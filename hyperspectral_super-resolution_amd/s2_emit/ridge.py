@@ -157,9 +157,9 @@ class PolyRidge:
         nat.check(lib.hsr_polyfeat_prepare(n_in, self.degree), "hsr_polyfeat_prepare")
         na = (nf + 1 + 15) // 16 * 16                                          # [1 | features] padded
         tp = (T + 15) // 16 * 16
-        G = torch.zeros((na, na + tp), dtype=torch.float64, device=Xd.device)
         if n == 0:
-            return G
+            return torch.zeros((na, na + tp), dtype=torch.float64, device=Xd.device)
+        G = torch.empty((na, na + tp), dtype=torch.float64, device=Xd.device)   # hsr_gram_f64 writes every element
         Q = torch.empty((n, na + tp), dtype=torch.float64, device=Xd.device)    # [P | Y | 0]; expand fills [0, na)
         Q[:, na:na + T] = Yd
         if tp > T:

@@ -17,18 +17,18 @@ int main(int argc, char** argv) {
   for (auto& x : M) { s = s * 1664525u + 1013904223u; x = ((s >> 8) / 16777216.0) - 0.5; }
   for (int i = 0; i < n; ++i) for (int j = 0; j <= i; ++j) { double v = 0; for (int k = 0; k < n + 40; ++k) v += M[(size_t)i * (n + 40) + k] * M[(size_t)j * (n + 40) + k]; v = v / n + (i == j ? 0.5 : 0.0); A[(size_t)i * n + j] = A[(size_t)j * n + i] = v; }
   double *dA, *dB, *dW; int* dI; unsigned long long* dS;
-  CK(hipMalloc(&dA, A.size() * 8)); CK(hipMalloc(&dB, B.size() * 8)); CK(hipMalloc(&dW, hsr_chol_work_bytes(n))); CK(hipMalloc(&dI, 4)); CK(hipMalloc(&dS, 16 * 8 * 8));
+  CK(hipMalloc(&dA, A.size() * 8)); CK(hipMalloc(&dB, B.size() * 8)); CK(hipMalloc(&dW, hsr_chol_work_bytes(n))); CK(hipMalloc(&dI, 4)); CK(hipMalloc(&dS, 512 * 8));
   hsr::g_chol_stamps = dS;
   const char* nm[6] = {"load D, P -> LDS", "31 column steps", "sqrt, scale, inverse", "panel = P Linv^T (MFMA)", "panel -> global", "trailing update"};
   for (int rep = 0; rep < 3; ++rep) {
     CK(hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dB, B.data(), B.size() * 8, hipMemcpyHostToDevice));
-    CK(hipMemset(dS, 0, 16 * 8 * 8));
+    CK(hipMemset(dS, 0, 512 * 8));
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     CK(hipEventRecord(e0, 0));
     if (hsr_chol_solve_f64(dA, n, n, dB, T, T, dW, dI, 0)) { printf("error %s\n", hsr_last_error()); return 1; }
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-    unsigned long long h[16 * 8]; CK(hipMemcpy(h, dS, sizeof h, hipMemcpyDeviceToHost));
+    unsigned long long h[512]; CK(hipMemcpy(h, dS, sizeof h, hipMemcpyDeviceToHost));
     double ph[6] = {0}; double tot = 0;
     for (int b = 0; b < n / 32; ++b) for (int k = 0; k < 6; ++k) { ph[k] += (double)(h[b * 8 + k + 1] - h[b * 8 + k]); }
     for (int k = 0; k < 6; ++k) tot += ph[k];
@@ -37,6 +37,11 @@ int main(int argc, char** argv) {
       for (int k = 0; k < 6; ++k) printf("  %-28s %9.0f cycles  %5.1f %%\n", nm[k], ph[k], 100 * ph[k] / tot);
       printf("  per block step (cycles):");
       for (int b = 0; b < n / 32; ++b) printf(" %llu", h[b * 8 + 6] - h[b * 8]);
+      printf("\n");
+      const int ns = n / 32;
+      printf("  solve kernel (slab 0): load %llu cycles, %d steps, store %llu; per step (block solve + barrier | copy, update + barrier):\n   ",
+             h[201] - h[200], 2 * ns, h[202 + 4 * ns] - h[201 + 4 * ns]);
+      for (int q = 0; q < 2 * ns; ++q) printf(" %llu|%llu", h[202 + 2 * q] - h[201 + 2 * q], h[203 + 2 * q] - h[202 + 2 * q]);
       printf("\n");
     }
   }

@@ -546,9 +546,22 @@ def test_gram_f64_mfma_layout_exact(torch_gpu):
         Cd = torch.full((32, 48), -1.0, dtype=torch.float64, device="cuda")
         nat.check(lib.hsr_gram_f64(_ptr(Ad), 32, 32, _ptr(Bd), 48, 48, n, _ptr(work), _ptr(Cd), 48, _stream(torch)))
         np.testing.assert_array_equal(Cd.cpu().numpy(), A.T @ B)
+    for n, na, nb_ in ((777, 48, 128), (50, 96, 32), (3000, 112, 16)):       # two different matrices, B ending in a narrow strip
+        A = rng.integers(-4, 5, (n, na)).astype(np.float64)
+        B = rng.integers(-4, 5, (n, nb_)).astype(np.float64)
+        Ad, Bd = torch.from_numpy(A).cuda(), torch.from_numpy(B).cuda()
+        work = torch.empty(max(1, lib.hsr_gram_work_bytes(na, nb_, n) // 8), dtype=torch.float64, device="cuda")
+        Cd = torch.full((na, nb_), -1.0, dtype=torch.float64, device="cuda")
+        nat.check(lib.hsr_gram_f64(_ptr(Ad), na, na, _ptr(Bd), nb_, nb_, n, _ptr(work), _ptr(Cd), nb_, _stream(torch)))
+        np.testing.assert_array_equal(Cd.cpu().numpy(), A.T @ B)
     # the Gram of one matrix with itself takes the symmetric path (blocks below the diagonal mirrored):
     # [first na columns]^T [all columns], shapes that leave ragged 3 x 3 tile blocks on both axes
-    for n, na, nb_ in ((501, 112, 160), (64, 16, 16), (2000, 288, 320), (333, 64, 64)):
+    # r03: a last strip of <= 32 columns becomes narrow blocks (96 x 32, chunks 5/2 as long), every workgroup splits its
+    # chunk's batches of 8 rows over three 4-wave groups: shapes with and without a strip (16 / 32 wide), strip only,
+    # fewer batches than groups, ragged last batches, one and many chunks, the fit's own (288 | 32) and (288 | 288)
+    for n, na, nb_ in ((501, 112, 160), (64, 16, 16), (2000, 288, 320), (333, 64, 64), (7, 16, 32), (25, 32, 32),
+                       (1237, 96, 112), (4099, 96, 128), (9001, 192, 208), (29127, 288, 320), (6151, 288, 576),
+                       (8, 288, 304), (70001, 48, 80)):
         Q = rng.integers(-3, 4, (n, nb_)).astype(np.float64)
         Qd = torch.from_numpy(Q).cuda()
         work = torch.empty(max(1, lib.hsr_gram_work_bytes(na, nb_, n) // 8), dtype=torch.float64, device="cuda")

@@ -34,6 +34,8 @@ for c in "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_
   step "ridge pmc $n" 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_ridge/$n -o p -- python3 tools/bench_ridge.py > /dev/null 2> $O/pmc_ridge_$n.log || echo "ridge pmc failed"
 done
 timeout -k 5 60 tools/chol_stamps 288 32 > $O/chol_stamps.log 2>&1
+# phase timeline of the Gram kernel (diagnostic library: tools/dbg/build_variants.sh "gstamp:-DHSR_GRAM_STAMPS:hsr_ridge")
+if [ -f tools/dbg/libhsr_gstamp.so ]; then HSR_LIBRARY=$PWD/tools/dbg/libhsr_gstamp.so timeout -k 5 100 python tools/gram_stamps.py > $O/gram_stamps.log 2>&1; fi
 echo "== stamps"; timeout -k 5 120 tools/k1_stamps 1024 1024 64 > $O/k1_stamps.log 2>&1
 step shard 300 python tools/shard_curve.py --graph --host-cost > $O/shard_curve.log 2>&1
 echo done

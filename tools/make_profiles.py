@@ -175,6 +175,10 @@ def main():
     cs_ = os.path.join(src, "chol_stamps.log")
     if os.path.isfile(cs_):
         out += ["\nWhere the one-workgroup Cholesky factorisation spends its cycles (`tools/chol_stamps`, n = 288):\n", "```"] + [l.rstrip() for l in open(cs_)] + ["```"]
+    gs_ = os.path.join(src, "gram_stamps.log")
+    if os.path.exists(gs_):
+        out += ["\nPhase timeline of `gram_f64_lds_kernel` (`tools/gram_stamps.py`: s_memrealtime at the phase boundaries of every workgroup, "
+                "s_memtime around the batch loop; 29 127 rows, 288 features + T targets):\n", "```"] + [l.rstrip() for l in open(gs_) if "amdgpu.ids" not in l] + ["```"]
     open(os.path.join(P, f"{tag}_k4_ridge.md"), "w").write("\n".join(out) + "\n")
     sc = os.path.join(src, "shard_curve.log")
     if os.path.isfile(sc):

@@ -34,7 +34,9 @@ unsigned long long* g_chol_stamps = nullptr;   // [16 blocks][8 phases], device 
 constexpr int kCb = 32;        // block size
 constexpr int kCs = kCb + 1;   // LDS row stride (doubles)
 constexpr int kTrailTiles = 5; // trailing-update tiles a wave loads before its first MFMA (9 = one pass at n = 288 spilled 75 VGPRs
-                               // under the 128-register cap of a 1024-thread workgroup and was 35 % slower)
+                               // under the 128-register cap of a 1024-thread workgroup and was 35 % slower; two alternating
+                               // batches of 2 / 3 / 4 tiles, the next one's loads in flight under the MFMAs: 112 k / 113 k / 136 k
+                               // cycles for the phase against 105 k)
 
 typedef double chol_f64x4 __attribute__((ext_vector_type(4)));
 

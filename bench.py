@@ -365,15 +365,16 @@ def main(argv=None):
     probs = [device_problem(H, W, B, deg=args.deg, seed=rank * ntl + i, device=device) for i in range(ntl)]
     prob = probs[0]
     exchanging = world > 1 or args.force_exchange
-    want_fused = ntl == 1 and args.cube == "f32" and not exchanging and not args.fused_fit and args.pipeline in ("fused", "auto")
+    want_fused = ntl == 1 and not exchanging and not args.fused_fit and args.pipeline in ("fused", "auto")
     fused_note = None
     if want_fused:
         # self-check on THIS tile before anything is timed: five tiles through the fused pipeline must come out with the bits of
         # step() (pseudo, matched, moments, coefficients).  auto falls back to the plain sequence if they do not.
         chk = SpectralFusion(prob.emit_w, prob.srf, prob.good_mask, deg=args.deg, min_valid=0.0, min_count=50, clip=True,
-                             device=device, coeff_sync="local", fuse_apply=True)
-        ref_out = chk.step(prob.cube, prob.real, reuse_buffers=False)
-        got = [chk.submit(prob.cube, prob.real) for _ in range(5)]
+                             device=device, coeff_sync="local", fuse_apply=True, u16_fast=args.u16_fast)
+        chk_cube = prob.cube if args.cube == "f32" else eng.tile_encode_u16(prob.cube)
+        ref_out = chk.step(chk_cube, prob.real, reuse_buffers=False)
+        got = [chk.submit(chk_cube, prob.real) for _ in range(5)]
         got = [o for o in got if o is not None] + chk.drain()
         same = chk._pipe["fused"] and len(got) == 5 and all(
             torch.equal(o.pseudo.view(torch.int32), ref_out.pseudo.view(torch.int32)) and
@@ -381,7 +382,7 @@ def main(argv=None):
             torch.equal(o.moments.view(torch.int64), ref_out.moments.view(torch.int64)) and
             torch.equal(o.coeffs.view(torch.int64), ref_out.coeffs.view(torch.int64)) for o in got)
         chk.close()
-        del chk, got, ref_out
+        del chk, got, ref_out, chk_cube
         if not same:
             if args.pipeline == "fused":
                 raise SystemExit("[bench] --pipeline fused: the fused pipeline did not reproduce step() on this tile")
@@ -528,7 +529,11 @@ def main(argv=None):
         achieved = launch_bytes / (k1_ms * 1e-3) / 1e9
         roof = {"bound": "hbm", "kernel": ("srf_kernel<deg,fast,...,APPLY>: K1+K2 of tile i + K3 of tile i-2 (pre-phase) + fit of tile i-1 (tail) "
                                            "in one launch; algorithmic bytes = cube + K3's 8 x row bytes per pixel" if fused else
-                                           "srf_kernel<deg,fast> (K1+K2 fused)") if args.cube == "f32" else "srf_u16_ring_kernel<deg> (K1+K2 fused, uint16 tile decode%s)" % (", fast arithmetic" if args.u16_fast else ""), "achieved": round(achieved, 1),
+                                           "srf_kernel<deg,fast> (K1+K2 fused)") if args.cube == "f32" else
+                          "srf_u16_ring_kernel<deg%s> (K1+K2 fused, uint16 tile decode%s)%s" % (
+                              ",...,APPLY" if fused else "", ", fast arithmetic" if args.u16_fast else "",
+                              " + K3 of tile i-2 (pre-phase) + fit of tile i-1 (tail) in one launch; algorithmic bytes = cube + K3's 8 x row "
+                              "bytes per pixel" if fused else ""), "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": None, "traffic_source": None, "algorithmic_bytes": launch_bytes, "kernel_ms": round(k1_ms, 4),
                 "kernel_launches_timed": len(k1_all),
@@ -543,7 +548,8 @@ def main(argv=None):
         if ntl == 1 and (H, W, B) == (1024, 1024, 285) and os.path.isfile(tf):       # the PMC figure is per single-tile launch of this shape
             try:
                 roof["traffic"] = json.load(open(tf)).get(("srf_fused_kernel_hbm_bytes_per_launch" if fused else "srf_kernel_hbm_bytes_per_launch")
-                                                          if args.cube == "f32" else "srf_u16_kernel_hbm_bytes_per_launch")
+                                                          if args.cube == "f32" else
+                                                          ("srf_u16_fused_kernel_hbm_bytes_per_launch" if fused else "srf_u16_kernel_hbm_bytes_per_launch"))
                 roof["traffic_source"] = (f"{TRAFFIC_FILE}: FETCH_SIZE x 1024 x 2 + WRITE_SIZE x 1024 per launch from separate "
                                           f"rocprofv3 --pmc passes over this command (committed file, not measured in this run)")
             except Exception:

@@ -47,6 +47,10 @@ __global__ void side_delay_kernel(int n) {
 int run_k1(hsr_step_plan* p, const void* cube, const float* real, const uint8_t* mask, hipStream_t s,
            const hsr_apply_job* job = nullptr) {
   const hsr_step_desc& d = p->d;
+  if (job && d.cube_dtype == 2)
+    return hsr_srf_integrate_moments_u16_apply(static_cast<const uint16_t*>(cube), d.npix, d.B, d.scale, d.nodata, d.wn_dev, p->k0,
+                                               p->klen, d.nb, d.pseudo_dev, d.out_bs, d.out_ps, real, d.real_bs, d.real_ps, mask,
+                                               d.min_x, d.min_y, d.deg, d.partials_dev, &p->slots, &d.opts, job, s);
   if (job)
     return hsr_srf_integrate_moments_apply(static_cast<const float*>(cube), d.npix, d.B, d.wn_dev, p->k0, p->klen, d.nb,
                                            d.pseudo_dev, d.out_bs, d.out_ps, real, d.real_bs, d.real_ps, mask, d.min_x, d.min_y,
@@ -193,11 +197,11 @@ extern "C" int hsr_pipeline_create_fused(hsr_step_plan* slot0, hsr_step_plan* sl
   hsr_step_plan* ps[3] = {slot0, slot1, slot2};
   for (hsr_step_plan* p : ps) {
     const hsr_step_desc& d = p->d;
-    HSR_REQUIRE(d.cube_dtype == 0 && d.out_bs == 1 && (d.out_ps & 3) == 0 && d.out_ps <= HSR_MAX_BANDS && d.matched_bs == 1 &&
+    HSR_REQUIRE(d.cube_dtype == slot0->d.cube_dtype && d.out_bs == 1 && (d.out_ps & 3) == 0 && d.out_ps <= HSR_MAX_BANDS && d.matched_bs == 1 &&
                     d.matched_ps == d.out_ps && ((((uintptr_t)d.pseudo_dev) | ((uintptr_t)d.matched_dev)) & 15) == 0 &&
                     d.npix == slot0->d.npix && d.out_ps == slot0->d.out_ps && d.nb == slot0->d.nb && d.deg == slot0->d.deg,
-                HSR_ERR_UNSUPPORTED, "hsr_pipeline_create_fused: float32 cubes and 16-byte aligned pixel-major rows of 4 / 8 / 12 / 16 floats, "
-                "the same geometry in all three plans");
+                HSR_ERR_UNSUPPORTED, "hsr_pipeline_create_fused: 16-byte aligned pixel-major rows of 4 / 8 / 12 / 16 floats, "
+                "the same geometry and cube type in all three plans");
   }
   return pipeline_new(slot0, slot1, slot2, side_stream, exchange, out, "hsr_pipeline_create_fused");
 }

@@ -1253,7 +1253,7 @@ __device__ __forceinline__ void glds4_asm(const void* gaddr, uint32_t lds_base) 
 // group's 64 target rows (3 instructions, 24 cache lines) instead of 16 scattered wave loads (512 lines) - within 1 % of
 // this kernel in three alternating fresh processes each; each wave issuing its share of the DMA at a different point of
 // the iteration (wave mod 5) - 3 % slower.  (All in the settled power state: 0.124-0.132 ms exact, 0.120-0.132 ms fast.)
-template <int DEG, bool OUTV, bool BATCH, bool FASTU>
+template <int DEG, bool OUTV, bool BATCH, bool FASTU, bool APPLY = false>
 __global__ __launch_bounds__(512, 4) void srf_u16_ring_kernel(const SrfArgs a) {
   constexpr int P = 64, T = 512;
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -1274,6 +1274,8 @@ __global__ __launch_bounds__(512, 4) void srf_u16_ring_kernel(const SrfArgs a) {
   const uint32_t nd2 = (a.nodata & 0xffffu) * 0x00010001u;
   const bool has_nodata = a.nodata <= 0xffffu;
   const int nchunk_full = tile_bytes >> 4;
+
+  if constexpr (APPLY && DEG > 0) apply_prephase<DEG + 1, T>(a, t);   // K3 of an older tile (fused pipeline, as in srf_kernel)
 
   int bk0[kBandSlots], bkl[kBandSlots], bwo[kBandSlots], bidx[kBandSlots];
   bool bval[kBandSlots];
@@ -1483,6 +1485,8 @@ __global__ __launch_bounds__(512, 4) void srf_u16_ring_kernel(const SrfArgs a) {
   if (DEG > 0 && pend) flush_moments<M, P, false, !BATCH>(acc_m, bval, bidx, pend_part, lane);
   if constexpr (DEG > 0 && !BATCH)
     if (a.fit.tickets) fused_fit<DEG>(a.fit, a.one.part_dev, a.one.slots, a.nb, smem, t);
+  if constexpr (APPLY && DEG > 0)
+    if (a.lazy_partials) lazy_fit<DEG, T>(a, smem, t);   // the previous tile's fit as tail work (fused pipeline)
 }
 
 template <typename K>
@@ -1494,10 +1498,10 @@ static void ensure_dynamic_lds(K kern, size_t lds, size_t* configured) {
   }
 }
 
-template <int DEG, bool OUTV, bool BATCH, bool FASTU>
+template <int DEG, bool OUTV, bool BATCH, bool FASTU, bool APPLY = false>
 static int launch_srf_u16_ring(const SrfArgs& a, int grid, hipStream_t stream) {
   const size_t lds = (size_t)2 * 64 * a.B * 2 + 128 * sizeof(uint32_t) + (size_t)a.wtaps * 4 + (OUTV ? (size_t)64 * a.out_ps * 4 : 0);
-  auto kern = srf_u16_ring_kernel<DEG, OUTV, BATCH, FASTU>;
+  auto kern = srf_u16_ring_kernel<DEG, OUTV, BATCH, FASTU, APPLY>;
 #ifdef HSR_PHASE_STAMPS
   const_cast<SrfArgs&>(a).stamps = g_stamp_buffer;
 #endif
@@ -1533,6 +1537,17 @@ static bool u16_ring_fits(const SrfArgs& a, bool outv) {
 template <int DEG>
 static int dispatch_u16_deg(const SrfArgs& a, bool fast, bool ring, int grid, hipStream_t s) {
   const bool outv = out_rows_vectorised(a, a.one.pseudo_dev);
+  if (a.apply_x != nullptr || a.lazy_partials != nullptr) {   // the fused pipeline's launch: only the ring kernel carries it
+    if constexpr (DEG > 0) {
+      if (!(fast && ring && outv && a.wtaps > 0 && u16_ring_fits(a, true) && 2 * 64 * a.B * 2 >= 12 * 1024)) {
+        set_error("hsr_srf_integrate_moments_u16_apply: this launch cannot carry an apply job (needs the ring kernel: 16-byte aligned "
+                  "cube, weights in LDS, pixel-major rows, 48 <= B <= ~300)");
+        return HSR_ERR_UNSUPPORTED;
+      }
+      return a.u16_fast ? launch_srf_u16_ring<DEG, true, false, true, true>(a, grid, s)
+                        : launch_srf_u16_ring<DEG, true, false, false, true>(a, grid, s);
+    }
+  }
   if (fast && ring && u16_ring_fits(a, outv)) {
     if (outv && a.u16_fast && a.wtaps > 0) return launch_srf_u16_ring<DEG, true, false, true>(a, grid, s);
     return outv ? launch_srf_u16_ring<DEG, true, false, false>(a, grid, s) : launch_srf_u16_ring<DEG, false, false, false>(a, grid, s);
@@ -1784,9 +1799,9 @@ static int srf_moments_entry(const char* who, const void* cube_dev, bool u16, fl
   if (job) {
     HSR_REQUIRE((job->x_dev == nullptr && job->fit_partials_dev) || (job->x_dev && job->out_dev && job->coeffs_dev && job->npix >= 1),
                 HSR_ERR_INVALID, "%s: NULL pointer or npix < 1 in hsr_apply_job", who);
-    HSR_REQUIRE(!u16 && out_bs == 1 && (out_ps & 3) == 0 && out_ps <= HSR_MAX_BANDS && job->npix * (out_ps >> 2) < ((int64_t)1 << 31) &&
+    HSR_REQUIRE(out_bs == 1 && (out_ps & 3) == 0 && out_ps <= HSR_MAX_BANDS && job->npix * (out_ps >> 2) < ((int64_t)1 << 31) &&
                     ((((uintptr_t)job->x_dev) | ((uintptr_t)job->out_dev) | ((uintptr_t)out_dev)) & 15) == 0,
-                HSR_ERR_UNSUPPORTED, "%s: a launch carries an apply job only for float32 cubes and 16-byte aligned pixel-major rows of 4, 8, 12 or 16 floats", who);
+                HSR_ERR_UNSUPPORTED, "%s: a launch carries an apply job only for 16-byte aligned pixel-major rows of 4, 8, 12 or 16 floats", who);
     a.apply_x = job->x_dev;
     a.apply_out = job->out_dev;
     a.apply_coeffs = job->coeffs_dev;
@@ -1874,6 +1889,18 @@ extern "C" int hsr_srf_integrate_moments_u16(const uint16_t* cube_dev, int64_t n
   return srf_moments_entry("hsr_srf_integrate_moments_u16", cube_dev, true, scale, nodata, npix, B, wn_dev, k0, klen, nb,
                            out_dev, out_bs, out_ps, real_dev, real_bs, real_ps, mask_dev, min_x, min_y, deg, partials_dev,
                            slots_out, nullptr, opts, stream);
+}
+
+extern "C" int hsr_srf_integrate_moments_u16_apply(const uint16_t* cube_dev, int64_t npix, int32_t B, float scale,
+                                                   int32_t nodata, const float* wn_dev, const int32_t* k0,
+                                                   const int32_t* klen, int32_t nb, float* out_dev, int64_t out_bs,
+                                                   int64_t out_ps, const float* real_dev, int64_t real_bs, int64_t real_ps,
+                                                   const uint8_t* mask_dev, float min_x, float min_y, int32_t deg,
+                                                   double* partials_dev, int32_t* slots_out, const hsr_srf_options* opts,
+                                                   const hsr_apply_job* job, hsr_stream_t stream) {
+  return srf_moments_entry("hsr_srf_integrate_moments_u16_apply", cube_dev, true, scale, nodata, npix, B, wn_dev, k0, klen, nb,
+                           out_dev, out_bs, out_ps, real_dev, real_bs, real_ps, mask_dev, min_x, min_y, deg, partials_dev,
+                           slots_out, nullptr, opts, stream, job);
 }
 
 extern "C" int hsr_srf_integrate_fit_u16(const uint16_t* cube_dev, int64_t npix, int32_t B, float scale, int32_t nodata,

@@ -108,6 +108,8 @@ SIGNATURES = {
                                                 C.POINTER(_i32), _popt, _vp]),
     "hsr_srf_integrate_moments_apply": (C.c_int, [_vp, _i64, _i32, _vp, _pi32, _pi32, _i32, _vp, _i64, _i64,
                                                   _vp, _i64, _i64, _vp, _f32, _f32, _i32, _vp, _pi32, _popt, _vp, _vp]),
+    "hsr_srf_integrate_moments_u16_apply": (C.c_int, [_vp, _i64, _i32, _f32, _i32, _vp, _pi32, _pi32, _i32, _vp, _i64, _i64,
+                                                      _vp, _i64, _i64, _vp, _f32, _f32, _i32, _vp, _pi32, _popt, _vp, _vp]),
     "hsr_srf_integrate_fit": (C.c_int, [_vp, _i64, _i32, _vp, _pi32, _pi32, _i32, _vp, _i64, _i64, _vp, _i64, _i64, _vp,
                                         _f32, _f32, _i32, _vp, _pi32, C.POINTER(FusedFit), _popt, _vp]),
     "hsr_srf_integrate_fit_u16": (C.c_int, [_vp, _i64, _i32, _f32, _i32, _vp, _pi32, _pi32, _i32, _vp, _i64, _i64, _vp,

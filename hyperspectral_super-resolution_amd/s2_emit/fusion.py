@@ -147,6 +147,7 @@ class SpectralFusion:
         if reserved_cus is None:
             reserved_cus = 8 if self._exchanges() else 0
         self.opts = eng.srf_options(tile_pixels, reserved_cus, u16_single_buffer, u16_fast)
+        self.u16_single_buffer = bool(u16_single_buffer)
         self._batches: Dict[tuple, object] = {}
         # Placement (profiles/r02_two_speeds.md, eng.placement_search): K1 runs at one of two speeds, ~9 % apart, depending
         # on which stretch of device memory its operands lie in - the cube above all (its read stream), the output image
@@ -172,9 +173,10 @@ class SpectralFusion:
         self.side_stream_log = None                  # us per pipelined step of each candidate stream, if measured
         # fuse_apply: submit() runs the FUSED pipeline - ONE kernel per tile on the caller's stream and nothing else: launch i
         # = K3 of tile i-2 as a pre-phase + K1+K2 of tile i + the fit of tile i-1 as tail work of the first workgroups to
-        # finish (hsr_srf_integrate_moments_apply).  No side stream, no events, no CUs kept free; results two submits late
-        # instead of one.  Needs float32 cubes, the pixel-major layout and no exchange (a collective cannot ride in a kernel's
-        # tail); otherwise submit() quietly uses the two-slot pipeline.
+        # finish (hsr_srf_integrate_moments_apply / _u16_apply).  No side stream, no events, no CUs kept free; results two
+        # submits late instead of one.  Needs the pixel-major layout, no exchange (a collective cannot ride in a kernel's tail)
+        # and, for uint16 tiles, a cube the ring kernel can load (16-byte aligned, 48 <= B <= 300); otherwise submit()
+        # quietly uses the two-slot pipeline.
         self.fuse_apply = bool(fuse_apply)
         self._native: Dict[tuple, object] = {}       # prepared launches of step(), by _native_key
         self._native_handles: list = []              # ("plan" | "pipe", handle) to destroy with the plan
@@ -760,7 +762,10 @@ class SpectralFusion:
                 placed = self._place(npix, placed, probe, count=2)       # ONE search for both slots' images
         # with an exchange the fit needs a collective between reduce and solve, which cannot ride in a kernel's tail: the
         # two-slot pipeline (fit on the side stream) stays the multi-rank form
-        fused = self.fuse_apply and self.layout == nat.PIXMAJOR and cube.dtype == torch.float32 and not self._exchanges()
+        B = int(cube.shape[-1])
+        u16_ok = (cube.dtype != torch.float32 and cube.data_ptr() % 16 == 0 and 48 <= B <= 300 and not self.u16_single_buffer)
+        fused = (self.fuse_apply and self.layout == nat.PIXMAJOR and (cube.dtype == torch.float32 or u16_ok)
+                 and not self._exchanges())                # uint16 tiles: only the ring kernel carries the older tile's K3
         if fused and len(placed) < 3:
             placed = list(placed) + [eng.alloc_image(torch, nb, npix, self.layout, self.device)]
         slots, outs = [], []
@@ -809,7 +814,8 @@ class SpectralFusion:
         torch = nat.require_gpu()
         import ctypes as C
         lib = nat._lib or nat.load()
-        key = (tuple(cube.shape), cube.dtype, tuple(real.shape), tuple(real.stride()), real.dtype)
+        key = (tuple(cube.shape), cube.dtype, tuple(real.shape), tuple(real.stride()), real.dtype,
+               cube.dtype == torch.float32 or cube.data_ptr() % 16 == 0)   # (the fused launch of uint16 tiles needs the aligned loader)
         st = self._pipe
         if st is None or st["key"] != key:
             st = self._pipe_build(cube, real, mask, key)

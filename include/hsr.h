@@ -144,6 +144,16 @@ int hsr_srf_integrate_moments_apply(const float* cube_dev, int64_t npix, int32_t
                                     float min_x, float min_y, int32_t deg,
                                     double* partials_dev, int32_t* slots_out, const hsr_srf_options* opts,
                                     const hsr_apply_job* job, hsr_stream_t stream);
+/* The same for a cube in the uint16 tile format (hsr_srf_integrate_moments_u16's arguments + the job).  Only the ring kernel
+ * carries a job: HSR_ERR_UNSUPPORTED unless the cube is 16-byte aligned, 48 <= B <= ~300, the weights fit LDS and the rows
+ * are pixel-major. */
+int hsr_srf_integrate_moments_u16_apply(const uint16_t* cube_dev, int64_t npix, int32_t B, float scale, int32_t nodata,
+                                        const float* wn_dev, const int32_t* k0, const int32_t* klen, int32_t nb,
+                                        float* out_dev, int64_t out_bs, int64_t out_ps,
+                                        const float* real_dev, int64_t real_bs, int64_t real_ps, const uint8_t* mask_dev,
+                                        float min_x, float min_y, int32_t deg,
+                                        double* partials_dev, int32_t* slots_out, const hsr_srf_options* opts,
+                                        const hsr_apply_job* job, hsr_stream_t stream);
 
 /* ---- K1+K2+fit in ONE launch (single tile) ----------------------------------------------------
  * hsr_srf_integrate_moments followed by hsr_moments_reduce_solve without the second launch: every workgroup draws a
@@ -525,10 +535,10 @@ int hsr_step_run_apply(hsr_step_plan* plan, const uint8_t* mask_dev, hsr_stream_
  * -1 = none.  side_stream must be a real stream (not NULL); a high-priority one gets its own hardware queue. */
 int hsr_pipeline_create(hsr_step_plan* slot0, hsr_step_plan* slot1, hsr_stream_t side_stream, int32_t exchange,
                         hsr_pipeline** pipeline_out);
-/* Fused form over THREE plans: K3 of tile i-2 rides in the launch of K1 of tile i (hsr_srf_integrate_moments_apply) - one kernel
+/* Fused form over THREE plans: K3 of tile i-2 rides in the launch of K1 of tile i (hsr_srf_integrate_moments[_u16]_apply) - one kernel
  * per tile on the caller's stream.  submit(i) finishes tile i-2 (prev_mask_dev = ITS mask); hsr_pipeline_flush finishes the
  * OLDEST unfinished tile per call (call it until *finished_slot == -1).  HSR_ERR_UNSUPPORTED unless all plans describe the same
- * float32 geometry with 16-byte aligned pixel-major rows of 4 / 8 / 12 / 16 floats. */
+ * geometry and cube type (float32 or uint16) with 16-byte aligned pixel-major rows of 4 / 8 / 12 / 16 floats. */
 int hsr_pipeline_create_fused(hsr_step_plan* slot0, hsr_step_plan* slot1, hsr_step_plan* slot2, hsr_stream_t side_stream,
                               int32_t exchange, hsr_pipeline** pipeline_out);
 void hsr_pipeline_destroy(hsr_pipeline* pipeline);

@@ -1690,8 +1690,8 @@ def test_fused_pipeline_k3_inside_k1_launch_bit_identical(torch_gpu):
     """SpectralFusion(fuse_apply=True): K3 of tile i-2 rides in the launch of K1 of tile i (hsr_srf_integrate_moments_apply,
     hsr_pipeline_create_fused).  Every tile that comes out - two submits late, the rest through drain() - carries the bits of
     its own step(): degrees 1-4, masks that come and go (the mask of the tile being FINISHED is the one K3 must use), a
-    13-band table (rows of 16 floats) and 3 bands (rows of 4), odd pixel counts, the generic (unaligned) loader; a uint16
-    cube quietly takes the two-slot pipeline; the C entry refuses what the fused launch does not cover."""
+    13-band table (rows of 16 floats) and 3 bands (rows of 4), odd pixel counts, the generic (unaligned) loader; uint16
+    tiles through the ring kernel; the C entry refuses what the fused launch does not cover."""
     torch = torch_gpu
     import ctypes as C
     from s2_emit import SpectralFusion, _engine as eng, _native as nat
@@ -1731,14 +1731,45 @@ def test_fused_pipeline_k3_inside_k1_launch_bit_identical(torch_gpu):
                 assert torch.equal(gt[2].view(torch.int64), want.moments.view(torch.int64)), (nb, deg, i, "moments")
                 assert torch.equal(gt[3].view(torch.int64), want.coeffs.view(torch.int64)), (nb, deg, i, "coeffs")
             pipe.close()
-    # uint16 cubes: submit() falls back to the two-slot pipeline, results still equal step()
+    # uint16 tiles (r03, hsr_srf_integrate_moments_u16_apply): the ring kernel carries the older tile's K3 and the previous
+    # tile's fit as well - same bits as step(), exact and fast arithmetic, masks, nodata; a cube the ring kernel cannot
+    # load (2-byte aligned only) quietly takes the two-slot pipeline
+    raw = [eng.tile_encode_u16(torch.rand((40, 64, 285), generator=g, device="cuda") * 0.6) for _ in range(3)]
+    raw[1].view(torch.int16)[3, 5, 100] = -1                                          # 65535 = nodata
+    raw[2].view(torch.int16)[:, 7, :] = -1
+    rus = [torch.rand((40, 64, 12), generator=g, device="cuda") for _ in range(3)]
+    mus = [None, (torch.rand(40 * 64, generator=g, device="cuda") > 0.4).to(torch.uint8), None, None,
+           (torch.rand(40 * 64, generator=g, device="cuda") > 0.7).to(torch.uint8)]
+    for fastu in (False, True):
+        for deg in (1, 3):
+            kw = dict(deg=deg, min_valid=0.0, min_count=5, apply_mask=True, u16_fast=fastu)
+            p16 = SpectralFusion(w, srf13, good, fuse_apply=True, **kw)
+            ref = SpectralFusion(w, srf13, good, **kw)
+            seq = [(raw[i % 3], rus[i % 3], mus[i % 5]) for i in range(7)]
+            got = []
+            for i, (c, r, m) in enumerate(seq):
+                o = p16.submit(c, r, m)
+                assert (o is None) == (i < 2), (fastu, deg, i)
+                if o is not None:
+                    got.append(tuple(t.clone() for t in (o.pseudo, o.matched, o.moments, o.coeffs)))
+            assert p16._pipe["fused"] and p16._pipe["S"] == 3
+            got += [tuple(t.clone() for t in (o.pseudo, o.matched, o.moments, o.coeffs)) for o in p16.drain()]
+            assert len(got) == len(seq)
+            for i, ((c, r, m), gt) in enumerate(zip(seq, got)):
+                want = ref.step(c, r, m, reuse_buffers=False)
+                assert torch.equal(gt[0].view(torch.int32), want.pseudo.view(torch.int32)), (fastu, deg, i, "pseudo")
+                assert torch.equal(gt[1].view(torch.int32), want.matched.view(torch.int32)), (fastu, deg, i, "matched")
+                assert torch.equal(gt[2].view(torch.int64), want.moments.view(torch.int64)), (fastu, deg, i, "moments")
+                assert torch.equal(gt[3].view(torch.int64), want.coeffs.view(torch.int64)), (fastu, deg, i, "coeffs")
+            p16.close()
+    flat = torch.zeros(40 * 64 * 285 + 8, dtype=torch.int16, device="cuda")
+    flat[1:1 + 40 * 64 * 285] = raw[0].view(torch.int16).reshape(-1)
+    cu = flat[1:1 + 40 * 64 * 285].view(raw[0].dtype).view(40, 64, 285)               # 2-byte aligned
     p16 = SpectralFusion(w, srf13, good, deg=2, min_valid=0.0, min_count=5, fuse_apply=True)
-    cu = eng.tile_encode_u16(torch.rand((40, 64, 285), generator=g, device="cuda") * 0.6)
-    ru = torch.rand((40, 64, 12), generator=g, device="cuda")
-    assert p16.submit(cu, ru) is None
+    assert p16.submit(cu, rus[0]) is None
     o = p16.flush()
     assert not p16._pipe["fused"]
-    want = SpectralFusion(w, srf13, good, deg=2, min_valid=0.0, min_count=5).step(cu, ru, reuse_buffers=False)
+    want = SpectralFusion(w, srf13, good, deg=2, min_valid=0.0, min_count=5).step(cu, rus[0], reuse_buffers=False)
     assert torch.equal(o.matched.view(torch.int32), want.matched.view(torch.int32))
     # the C entry: a planar output cannot carry an apply job
     lib = nat.load()

@@ -17,8 +17,10 @@ for c in FETCH_SIZE WRITE_SIZE "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_INSTS_
   step "pmc $n" 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc/$n -o p -- python3 bench.py --steps 10 --warmup 2 --k1-launches 0 --cold-steps 0 --no-cpu-baseline --no-probe > /dev/null 2> $O/pmc_$n.log || echo "pmc $n failed"
 done
 echo "== u16"; timeout -k 10 200 python bench.py --cube u16 --steps 100 > $O/bench_u16.json 2>/dev/null; timeout -k 10 200 python bench.py --cube u16 --u16-fast --steps 100 > $O/bench_u16_fast.json 2>/dev/null
+timeout -k 10 200 python bench.py --cube u16 --steps 100 --pipeline off > $O/bench_u16_off.json 2>/dev/null
 step "trace u16" 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_u16 -o bench -- python3 bench.py --cube u16 --no-cpu-baseline --no-probe > /dev/null 2> $O/trace_u16.log
 for c in FETCH_SIZE WRITE_SIZE; do step "pmc u16 $c" 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_u16/$c -o p -- python3 bench.py --cube u16 --steps 10 --warmup 2 --k1-launches 0 --cold-steps 0 --no-cpu-baseline --no-probe > /dev/null 2> $O/pmc_u16_$c.log || echo fail; done
+for c in FETCH_SIZE WRITE_SIZE; do step "pmc u16 plain $c" 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $O/pmc_u16_plain/$c -o p -- python3 bench.py --cube u16 --pipeline off --steps 10 --warmup 2 --k1-launches 0 --cold-steps 0 --no-cpu-baseline --no-probe > /dev/null 2> $O/pmc_u16_plain_$c.log || echo fail; done
 step mosaic 300 python bench.py --tiles-per-gpu 8 --steps 10 --warmup 2 > $O/bench_mosaic8.json 2> $O/bench_mosaic8.err
 echo "== rehearsals: bench.py starting its own ranks (no launcher around it)"
 step gloo4 300 python bench.py --gpus 4 --steps 5 --warmup 2 --backend gloo --same-device --height 256 --width 256 > $O/bench_gloo4.json 2> $O/bench_gloo4.err

@@ -103,7 +103,7 @@ def main():
     open(os.path.join(P, f"{tag}_batch_tiles.md"), "w").write("\n".join(out) + "\n")
     # ---- u16
     out = [f"# {tag}: uint16 tiles (bench.py --cube u16 [--u16-fast])\n", "| run | ms/step | K1+K2 ms | frac of 8 TB/s on cube bytes |", "|---|---|---|---|"]
-    for name in ("bench_u16.json", "bench_u16_fast.json"):
+    for name in ("bench_u16.json", "bench_u16_fast.json", "bench_u16_off.json"):
         d = jload(os.path.join(src, name))
         if d:
             out.append(f"| {name} | {d['ms_per_step']} | {d['roofline']['kernel_ms']} | {d['roofline']['frac']} |")
@@ -111,15 +111,21 @@ def main():
     if ks:
         out += ["\n| kernel (rocprofv3) | calls | avg us | min us | max us |", "|---|---|---|---|---|"]
         out += [f"| `{n}` | {c} | {a:.2f} | {lo:.2f} | {hi:.2f} |" for n, c, a, lo, hi in ks]
-    b = pmc_bytes(os.path.join(src, "pmc_u16"), "srf_u16_ring_kernel<3")
+    tf = os.path.join(P, "traffic.json")
+    t = json.load(open(tf)) if os.path.isfile(tf) else {}
+    b = pmc_bytes(os.path.join(src, "pmc_u16_plain"), "srf_u16_ring_kernel<3") or pmc_bytes(os.path.join(src, "pmc_u16"), "false, false>")
     if b:
-        out.append(f"\nHBM traffic of the uint16 K1+K2 launch: read {b[0]/1e6:.1f} MB + write {b[1]/1e6:.1f} MB = {(b[0]+b[1])/1e6:.1f} MB "
+        out.append(f"\nHBM traffic of the uint16 K1+K2 launch (`--pipeline off`): read {b[0]/1e6:.1f} MB + write {b[1]/1e6:.1f} MB = {(b[0]+b[1])/1e6:.1f} MB "
                    f"(algorithmic: 597.7 MB cube + 50.3 MB targets + 50.3 MB planes = 698.3 MB).")
-        tf = os.path.join(P, "traffic.json")
-        t = json.load(open(tf)) if os.path.isfile(tf) else {}
         t["srf_u16_kernel_hbm_bytes_per_launch"] = int(b[0] + b[1])
-        t["source_u16"] = f"profiles/{tag}_u16_tiles.md (separate --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py --cube u16)"
-        json.dump(t, open(tf, "w"), indent=1)
+        t["source_u16"] = f"profiles/{tag}_u16_tiles.md (separate --pmc FETCH_SIZE / WRITE_SIZE passes of bench.py --cube u16 --pipeline off)"
+    b = pmc_bytes(os.path.join(src, "pmc_u16"), "false, true>")          # the APPLY variant: the fused pipeline's launch
+    if b:
+        out.append(f"\nHBM traffic of the fused uint16 launch (K1+K2 + K3 of an older tile + tail fit): read {b[0]/1e6:.1f} MB + write {b[1]/1e6:.1f} MB = "
+                   f"{(b[0]+b[1])/1e6:.1f} MB (algorithmic: 698.3 MB + 100.7 MB of K3 = 799.0 MB).")
+        t["srf_u16_fused_kernel_hbm_bytes_per_launch"] = int(b[0] + b[1])
+        t["source_u16_fused"] = f"profiles/{tag}_u16_tiles.md (separate --pmc passes of bench.py --cube u16, fused pipeline)"
+    json.dump(t, open(tf, "w"), indent=1)
     open(os.path.join(P, f"{tag}_u16_tiles.md"), "w").write("\n".join(out) + "\n")
     # ---- rehearsals
     out = [f"# {tag}: multi-rank control flow rehearsed on one GPU - the JSON lines (bench.py started WITHOUT a launcher: it starts its own ranks)\n"]

@@ -213,6 +213,7 @@ __global__ __launch_bounds__(256) void gram_f64_kernel(const double* __restrict_
 //  * software pipeline over the barrier: the operands of batch b + 1 are read from LDS while the MFMAs of batch b
 //    run, and after the barrier every wave first issues MFMAs and only then its ~60 scalar / DMA / LDS
 //    instructions (4 240 -> 3 750 shader cycles per batch of 3 x 18 MFMAs = 3 456).
+//  * the diagonal blocks of the symmetric part are a third kind (gram_diag_block below): upper tiles only.
 //  What is left: the shader clock runs at 2.10 GHz under this kernel (s_memtime against s_memrealtime), not 2.4.
 #ifndef HSR_GRAM_BUFS
 #define HSR_GRAM_BUFS 4
@@ -246,8 +247,10 @@ struct GramCore {                     // scalars only: handed to the block routi
   int64_t lda, ldb, n;
   int64_t rows_wide, rows_narrow;    // rows per chunk of a 96-wide / a narrow block
   int32_t na, nb, tiles_i, tiles_j;
-  int32_t nwide, nnarrow;            // launched blocks of either kind (wide ones first in `blocks`)
+  int32_t nwide, nnarrow;            // launched blocks of either kind (wide ones first in `blocks`, then diagonal, then narrow)
   int32_t chunks_wide, chunks_narrow;
+  int32_t ndiag, chunks_diag;        // diagonal blocks of the symmetric part (upper tiles only)
+  int64_t rows_diag;
   int32_t narrow_col, narrow_width;  // first column and width of the narrow strip of B
   int32_t total, per_xcd;            // workgroups with work; ceil(total / 8)
   double* partials;                  // [chunk][tile][256]
@@ -462,6 +465,177 @@ __device__ __forceinline__ void gram_block(const GramCore a, double* pan_base, i
 #endif
 }
 
+// Diagonal 96 x 96 block of the symmetric part (A's panel against itself): only its 21 upper tiles are needed - the reduction
+// mirrors every tile below the diagonal - so the four waves of a group do not take a 3 x 3 quadrant each (36 tiles, one
+// quadrant wasted, two half wasted) but a share of the upper triangle:
+//     role 0: (0,0) (0,1) (0,2) (0,3) (0,4) (0,5)        role 1: (1,1) (1,2) (1,3) (1,4) (1,5)
+//     role 2: (2,2) (2,3) (2,4) (2,5) (5,5)              role 3: (3,3) (3,4) (3,5) (4,4) (4,5)
+// (at most two distinct A operands and six B operands per k-step), role = (wave + group) mod 4 so that every SIMD carries
+// 15-16 MFMAs per k-step from its three waves instead of 27.  One panel per batch (2 rows per wave), both operands read
+// from it.  Everything else - rings, split of the batches over the groups, software pipeline, combine - as gram_block.
+constexpr int kGdTiles = 6;
+struct GramDiagRole { int8_t n, arow[2], sel[kGdTiles], tj[kGdTiles]; };
+constexpr GramDiagRole kGdRoles[4] = {{6, {0, 0}, {0, 0, 0, 0, 0, 0}, {0, 1, 2, 3, 4, 5}},
+                                      {5, {1, 1}, {0, 0, 0, 0, 0, 0}, {1, 2, 3, 4, 5, 5}},
+                                      {5, {2, 5}, {0, 0, 0, 0, 1, 1}, {2, 3, 4, 5, 5, 5}},
+                                      {5, {3, 4}, {0, 0, 0, 1, 1, 1}, {3, 4, 5, 4, 5, 5}}};
+constexpr int kGdDmaPerWave = kGpRows / 4;       // 8 panel rows per batch over 4 waves
+
+template <int ROLE>
+__device__ __forceinline__ void gram_diag_run(const GramCore a, double* pan_base, int acol0, int64_t c0, int64_t cend, int chunk,
+                                              int wave, int grp) {
+  constexpr GramDiagRole role = kGdRoles[ROLE];
+  const int lane = threadIdx.x & 63;
+  constexpr int G = kGramGroups;
+  const int col = lane & 15, kk = lane >> 4;
+  const int nbatch_all = (int)((cend - c0 + kGpRows - 1) / kGpRows);
+  const int nbatch = (nbatch_all + G - 1) / G;
+  const int nfull = (int)((cend - c0) / kGpRows) / G;
+  double* ring = pan_base + grp * kGpRingDoubles;
+  typedef double Slot[kGpRows][kGpStride];
+  Slot* pan = reinterpret_cast<Slot*>(ring);
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(__attribute__((address_space(3))) void*)(ring);
+  const int pr0 = wave * kGdDmaPerWave;
+  const bool on = lane < 48 && acol0 + 2 * lane < a.nb;    // (A and B are the same matrix here: the columns of a ragged last block
+  const double* mbase = uniform_ptr(a.A + acol0);          //  that lie past na are B's, and tiles in them are stored, too)
+  const uint32_t voff = (uint32_t)lane * 16u;
+  auto issue_full = [&](int b) {
+    const int slot = b % kGpBufs;
+    const double* src = mbase + (c0 + (int64_t)(b * G + grp) * kGpRows + pr0) * a.lda;
+    const uint32_t dst = lds0 + (uint32_t)((slot * kGpRows + pr0) * kGpStride * 8);
+    if (on) {
+#pragma unroll
+      for (int i = 0; i < kGdDmaPerWave; ++i) glds16_s(voff, src + i * a.lda, dst + (uint32_t)(i * kGpStride * 8));
+    }
+  };
+  auto issue_any = [&](int b) {
+    const int slot = b % kGpBufs;
+#pragma unroll
+    for (int i = 0; i < kGdDmaPerWave; ++i) {
+      const int64_t row = c0 + (int64_t)(b * G + grp) * kGpRows + pr0 + i;
+      const uint32_t dst = lds0 + (uint32_t)((slot * kGpRows + pr0 + i) * kGpStride * 8);
+      if (row < cend) {
+        if (on) glds16_s(voff, mbase + row * a.lda, dst);
+      } else if (lane < 48) {
+        pan[slot][pr0 + i][2 * lane] = 0.0;
+        pan[slot][pr0 + i][2 * lane + 1] = 0.0;
+      }
+    }
+  };
+  constexpr int KU = kGpRows / 4;
+  f64x4 acc[kGdTiles];
+#pragma unroll
+  for (int k = 0; k < kGdTiles; ++k) acc[k] = f64x4{0.0, 0.0, 0.0, 0.0};
+  struct Ops {
+    double a[KU][2], b[KU][kGdTiles];
+  };
+  auto fetch = [&](Ops& o, int b) {
+    const double (*ps)[kGpStride] = pan[b % kGpBufs];
+#pragma unroll
+    for (int u = 0; u < KU; ++u) {
+      o.a[u][0] = ps[4 * u + kk][16 * role.arow[0] + col];
+      if (role.arow[1] != role.arow[0]) o.a[u][1] = ps[4 * u + kk][16 * role.arow[1] + col];
+#pragma unroll
+      for (int k = 0; k < role.n; ++k)
+        if (k == 0 || role.tj[k] != role.tj[k - 1]) o.b[u][k] = ps[4 * u + kk][16 * role.tj[k] + col];
+    }
+  };
+  auto mma_one = [&](const Ops& o, int u, int k) {
+    // (a B operand shared by two consecutive tiles of the table - (2,5) (5,5) - was fetched once, for the first of them)
+    const int kb = (k > 0 && role.tj[k] == role.tj[k - 1]) ? k - 1 : k;
+    acc[k] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.a[u][role.sel[k]], o.b[u][kb], acc[k], 0, 0, 0);
+  };
+  auto step = [&](Ops& cur, Ops& nxt, int b) {
+    const bool steady = b + kGpAhead < nfull;
+    mma_one(cur, 0, 0);
+    mma_one(cur, 0, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    if (steady) issue_full(b + kGpAhead);
+    else if (b + kGpAhead < nbatch) issue_any(b + kGpAhead);
+    if (b + 1 < nbatch) fetch(nxt, b + 1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int u = 0; u < KU; ++u)
+#pragma unroll
+      for (int k = 0; k < role.n; ++k)
+        if (u || k > 1) mma_one(cur, u, k);
+    if (steady) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(kGdDmaPerWave) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  };
+  GRAM_STAMP(0);
+  for (int b = 0; b < kGpAhead && b < nbatch; ++b) issue_any(b);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  GRAM_STAMP(1);
+#ifdef HSR_GRAM_STAMPS
+  if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 8 + 6] = __builtin_readcyclecounter();
+#endif
+  {
+    Ops o0, o1;
+    fetch(o0, 0);
+#pragma unroll 1
+    for (int b = 0; b < nbatch; b += 2) {
+      step(o0, o1, b);
+      if (b + 1 < nbatch) step(o1, o0, b + 1);
+    }
+  }
+#ifdef HSR_GRAM_STAMPS
+  if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 8 + 7] = __builtin_readcyclecounter();
+#endif
+  GRAM_STAMP(2);
+  // the groups' sums, added in group order through LDS; a role sits in a different wave in every group, so the dump is
+  // indexed by role
+  if (G > 1) {
+    double* dump = pan_base + (ROLE * kGdTiles * 4) * 64 + lane;
+#pragma unroll 1
+    for (int g = 1; g < G; ++g) {
+      if (grp == g) {
+#pragma unroll
+        for (int k = 0; k < role.n; ++k)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) dump[(k * 4 + r) * 64] = acc[k][r];
+      }
+      __syncthreads();
+      if (grp == 0) {
+#pragma unroll
+        for (int k = 0; k < role.n; ++k)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[k][r] += dump[(k * 4 + r) * 64];
+      }
+      __syncthreads();
+    }
+    if (grp != 0) return;
+  }
+  GRAM_STAMP(3);
+  const int ntiles = a.tiles_i * a.tiles_j;
+#pragma unroll
+  for (int k = 0; k < role.n; ++k) {
+    const int ti = acol0 / 16 + role.arow[role.sel[k]], tj = acol0 / 16 + role.tj[k];
+    if (ti >= a.tiles_i || tj >= a.tiles_j) continue;
+    double* out = a.partials + ((size_t)chunk * ntiles + (size_t)ti * a.tiles_j + tj) * 256;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) out[(kk + 4 * g) * 16 + col] = acc[k][g];
+  }
+#ifdef HSR_GRAM_STAMPS
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  GRAM_STAMP(4);
+  if (a.stamps && threadIdx.x == 0) a.stamps[(size_t)blockIdx.x * 8 + 5] = (unsigned long long)(2 * 1000000 + nbatch);   // kind 2 = diagonal
+#endif
+}
+
+__device__ __forceinline__ void gram_diag_block(const GramCore a, double* pan_base, int acol0, int64_t c0, int64_t cend, int chunk) {
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane((tid >> 6) & 3);
+  const int grp = __builtin_amdgcn_readfirstlane(tid >> 8);
+  switch ((wave + grp) & 3) {      // wave-uniform; every role runs the same sequence of barriers
+    case 0: gram_diag_run<0>(a, pan_base, acol0, c0, cend, chunk, wave, grp); break;
+    case 1: gram_diag_run<1>(a, pan_base, acol0, c0, cend, chunk, wave, grp); break;
+    case 2: gram_diag_run<2>(a, pan_base, acol0, c0, cend, chunk, wave, grp); break;
+    default: gram_diag_run<3>(a, pan_base, acol0, c0, cend, chunk, wave, grp); break;
+  }
+}
+
 // Workgroup id -> (block, chunk): consecutive ids are the blocks of one chunk of rows, and the eight XCDs take
 // contiguous runs of ids (hardware deals workgroup w to XCD w % 8), so that the workgroups that read the same rows
 // of A sit behind the same L2.
@@ -477,8 +651,15 @@ __global__ __launch_bounds__(kGramThreads, HSR_GRAM_WGS) void gram_f64_lds_kerne
     int64_t cend = c0 + a.rows_wide;
     if (cend > a.n) cend = a.n;
     gram_block<3>(a, pan, args.blocks[k][0] * kGpCols, args.blocks[k][1] * kGpCols, kGpCols, c0, cend, chunk);
+  } else if (id < wide_ids + a.ndiag * a.chunks_diag) {
+    const int k = a.nwide + (id - wide_ids) % a.ndiag, chunk = (id - wide_ids) / a.ndiag;
+    const int64_t c0 = (int64_t)chunk * a.rows_diag;
+    int64_t cend = c0 + a.rows_diag;
+    if (cend > a.n) cend = a.n;
+    gram_diag_block(a, pan, args.blocks[k][0] * kGpCols, c0, cend, chunk);
   } else {
-    const int k = a.nwide + (id - wide_ids) % a.nnarrow, chunk = (id - wide_ids) / a.nnarrow;
+    const int nid = id - wide_ids - a.ndiag * a.chunks_diag;
+    const int k = a.nwide + a.ndiag + nid % a.nnarrow, chunk = nid / a.nnarrow;
     const int64_t c0 = (int64_t)chunk * a.rows_narrow;
     int64_t cend = c0 + a.rows_narrow;
     if (cend > a.n) cend = a.n;
@@ -486,17 +667,19 @@ __global__ __launch_bounds__(kGramThreads, HSR_GRAM_WGS) void gram_f64_lds_kerne
   }
 }
 
-// chunks summed in index order -> C[(ti*16 + r) * ldc + tj*16 + c]; tiles of skipped blocks are the
-// transposes of their mirror tiles.  Tiles from column tile `narrow_tj` on have `chunks_narrow` chunks.
+// chunks summed in index order -> C[(ti*16 + r) * ldc + tj*16 + c]; with `sym` every tile below the diagonal is the transpose
+// of its mirror tile (whole skipped blocks, and the lower tiles of diagonal blocks).  Tiles from column tile `narrow_tj` on
+// have `chunks_narrow` chunks, tiles of diagonal blocks (edge `blk` tiles) `chunks_diag` when that is > 0.
 __global__ __launch_bounds__(256) void gram_reduce_kernel(const double* __restrict__ partials, int ntiles, int chunks,
                                                           int tiles_j, int sym, int blk, int narrow_tj,
-                                                          int chunks_narrow, double* __restrict__ C, int64_t ldc) {
+                                                          int chunks_narrow, int chunks_diag, double* __restrict__ C, int64_t ldc) {
   const int tile = blockIdx.x, e = threadIdx.x;
   const int ti = tile / tiles_j, tj = tile % tiles_j;
-  const bool mirror = gram_block_skipped(ti / blk, tj / blk, sym);   // blk = tiles per skipped block edge
-  const int src_tile = mirror ? tj * tiles_j + ti : tile;
+  const bool mirror = sym && tj < ti;
+  const int si = mirror ? tj : ti, sj = mirror ? ti : tj;           // the tile that was computed
+  const int src_tile = si * tiles_j + sj;
   const int src_e = mirror ? (e & 15) * 16 + (e >> 4) : e;
-  const int nc = (src_tile % tiles_j) >= narrow_tj ? chunks_narrow : chunks;
+  const int nc = sj >= narrow_tj ? chunks_narrow : (sym && chunks_diag > 0 && si / blk == sj / blk) ? chunks_diag : chunks;
   const double* p = partials + (size_t)src_tile * 256 + src_e;
   const size_t step = (size_t)ntiles * 256;
   double s = 0.0;
@@ -982,56 +1165,60 @@ extern "C" int hsr_polyfeat_expand_f64(const float* x_dev, int64_t x_rs, int64_t
   return HSR_OK;
 }
 
-// Decomposition of the LDS-panel kernel.  Blocks: every 96 x 96 block of the result that is not below the diagonal
-// of the symmetric part, plus - when B ends in a strip of <= 32 columns - one narrow block per 96 rows of A.
-// Chunks: rows per chunk (whole batches of 16) as small as fills the resident workgroup slots in ONE round
-// (513 workgroups take as long as 1024), a narrow block taking 5/2 of the rows of a wide one; >= 256 rows per
-// chunk and <= 256 chunks, as the work buffer is sized for.
+// Decomposition of the LDS-panel kernel.  Blocks: every 96 x 96 block of the result above the diagonal of the
+// symmetric part (wide), the diagonal blocks of the symmetric part (upper tiles only), plus - when B ends in a strip
+// of <= 32 columns - one narrow block per 96 rows of A.  Chunks: rows per chunk as small as fills the resident
+// workgroup slots in ONE round (257 workgroups take as long as 512), scaled per kind for equal time; <= 256 chunks,
+// as the work buffer is sized for.
 static bool gram_lds_plan(int na, int nb, int sym, int64_t n, GramLdsArgs* g) {
   const int nbi = (na + kGpCols - 1) / kGpCols;
   const int rem = nb % kGpCols;
   const bool strip = rem > 0 && rem <= kGpNarrow;
   const int nbj = strip ? nb / kGpCols : (nb + kGpCols - 1) / kGpCols;
   int k = 0;
-  for (int bi = 0; bi < nbi; ++bi)
-    for (int bj = 0; bj < nbj; ++bj)
-      if (!(sym && bj < bi)) {
-        if (k < kGpMaxBlocks) {
-          g->blocks[k][0] = (uint8_t)bi;
-          g->blocks[k][1] = (uint8_t)bj;
-        }
-        ++k;
-      }
-  g->c.nwide = k;
-  g->c.nnarrow = strip ? nbi : 0;
-  for (int bi = 0; strip && bi < nbi; ++bi, ++k)
+  auto put = [&](int bi, int bj) {
     if (k < kGpMaxBlocks) {
       g->blocks[k][0] = (uint8_t)bi;
-      g->blocks[k][1] = (uint8_t)nbj;
+      g->blocks[k][1] = (uint8_t)bj;
     }
+    ++k;
+  };
+  for (int bi = 0; bi < nbi; ++bi)                 // wide: every launched block that is not a diagonal block of the symmetric part
+    for (int bj = 0; bj < nbj; ++bj)
+      if (!(sym && bj <= bi)) put(bi, bj);
+  g->c.nwide = k;
+  for (int bi = 0; sym && bi < nbi && bi < nbj; ++bi) put(bi, bi);
+  g->c.ndiag = k - g->c.nwide;
+  for (int bi = 0; strip && bi < nbi; ++bi) put(bi, nbj);
+  g->c.nnarrow = strip ? nbi : 0;
   if (k > kGpMaxBlocks) return false;
   g->c.narrow_col = strip ? nbj * kGpCols : nb;
   g->c.narrow_width = strip ? rem : 0;
-  // a narrow block has a third of the MFMAs of a wide one per row but the same DMA, barrier and address work:
-  // measured 0.72 us against 1.80 us per batch, so it takes 5/2 of the rows for the same time
+  // Rows per chunk by kind, for equal time per workgroup (measured per 8-row batch: wide 1.80 us, narrow 0.72 us - a third of the
+  // MFMAs but the same DMA / barrier / address work -, diagonal 1.08 us: 16 of 27 MFMAs per SIMD and k-step):
+  // narrow 5/2 and diagonal 5/3 of the rows of a wide block; rows in multiples of 48 keep all three whole batches.
   auto narrow_rows = [](int64_t rows) { return rows / 2 * 5; };
-  auto count = [&](int64_t rows, int64_t* cw, int64_t* cn) {
+  auto diag_rows = [](int64_t rows) { return rows / 3 * 5; };
+  auto count = [&](int64_t rows, int64_t* cw, int64_t* cd, int64_t* cn) {
     *cw = g->c.nwide ? (n + rows - 1) / rows : 0;
+    *cd = g->c.ndiag ? (n + diag_rows(rows) - 1) / diag_rows(rows) : 0;
     *cn = g->c.nnarrow ? (n + narrow_rows(rows) - 1) / narrow_rows(rows) : 0;
-    return g->c.nwide * *cw + g->c.nnarrow * *cn;
+    return g->c.nwide * *cw + g->c.ndiag * *cd + g->c.nnarrow * *cn;
   };
   // start from the even split and grow until the count fits
-  int64_t rows = (int64_t)((double)n * (g->c.nwide + g->c.nnarrow / 2.5) / kGramSlots);
-  rows = (rows + 15) / 16 * 16;
-  const int64_t floor_rows = g->c.nwide ? 256 : 96;   // narrow-only (nb <= 32): chunks of >= 288 rows
+  int64_t rows = (int64_t)((double)n * (g->c.nwide + g->c.ndiag * 0.6 + g->c.nnarrow / 2.5) / kGramSlots);
+  rows = (rows + 47) / 48 * 48;
+  const int64_t floor_rows = g->c.nwide ? 240 : (g->c.ndiag ? 144 : 96);   // >= 240 rows per chunk whatever the kind
   if (rows < floor_rows) rows = floor_rows;
-  int64_t cw = 0, cn = 0;
-  while (count(rows, &cw, &cn) > kGramSlots || cw > 256 || cn > 256) rows += 16;
+  int64_t cw = 0, cd = 0, cn = 0;
+  while (count(rows, &cw, &cd, &cn) > kGramSlots || cw > 256 || cd > 256 || cn > 256) rows += 48;
   g->c.rows_wide = rows;
+  g->c.rows_diag = diag_rows(rows);
   g->c.rows_narrow = narrow_rows(rows);
   g->c.chunks_wide = (int32_t)cw;
+  g->c.chunks_diag = (int32_t)cd;
   g->c.chunks_narrow = (int32_t)cn;
-  g->c.total = (int32_t)(g->c.nwide * cw + g->c.nnarrow * cn);
+  g->c.total = (int32_t)(g->c.nwide * cw + g->c.ndiag * cd + g->c.nnarrow * cn);
   g->c.per_xcd = (g->c.total + 7) / 8;
   return true;
 }
@@ -1051,7 +1238,12 @@ extern "C" size_t hsr_gram_work_bytes(int32_t na, int32_t nb, int64_t n) {
   // both kernels use at most 256 chunks; size for the larger count so that either path can run
   GramLdsArgs g{};
   int64_t c1 = gram_reg_chunks(n, nullptr), c2 = 0;
-  if (gram_lds_plan(na, nb, nb >= na, n, &g)) c2 = g.c.chunks_wide > g.c.chunks_narrow ? g.c.chunks_wide : g.c.chunks_narrow;
+  if (gram_lds_plan(na, nb, nb >= na, n, &g)) {
+    c2 = g.c.chunks_wide > g.c.chunks_narrow ? g.c.chunks_wide : g.c.chunks_narrow;
+    if (g.c.chunks_diag > c2) c2 = g.c.chunks_diag;
+  }
+  GramLdsArgs g0{};                                   // the same matrices as two different pointers: no symmetric skip
+  if (gram_lds_plan(na, nb, 0, n, &g0) && g0.c.chunks_wide > c2) c2 = g0.c.chunks_wide;
   const int64_t chunks = c1 > c2 ? c1 : c2;
   return (size_t)chunks * (na / 16) * (nb / 16) * 256 * sizeof(double);
 }
@@ -1092,7 +1284,7 @@ extern "C" int hsr_gram_f64(const double* a_dev, int64_t lda, int32_t na, const 
     hipLaunchKernelGGL(gram_f64_lds_kernel, dim3(8 * (unsigned)g.c.per_xcd), dim3(kGramThreads), lds_bytes, s, g);
     HSR_LAUNCH_CHECK("gram_f64_lds_kernel");
     hipLaunchKernelGGL(gram_reduce_kernel, dim3(ti * tj), dim3(256), 0, s, work_dev, ti * tj, g.c.chunks_wide, tj, sym,
-                       kGpCols / 16, g.c.narrow_col / 16, g.c.chunks_narrow, c_dev, ldc);
+                       kGpCols / 16, g.c.narrow_col / 16, g.c.chunks_narrow, g.c.chunks_diag, c_dev, ldc);
     HSR_LAUNCH_CHECK("gram_reduce_kernel");
     return HSR_OK;
   }
@@ -1102,7 +1294,7 @@ extern "C" int hsr_gram_f64(const double* a_dev, int64_t lda, int32_t na, const 
   hipLaunchKernelGGL(gram_f64_kernel, dim3(((ti + R - 1) / R) * ((tj + R - 1) / R), (unsigned)chunks), dim3(256), 0, s,
                      a_dev, lda, ti, b_dev, ldb, tj, n, rows, sym, work_dev);
   hipLaunchKernelGGL(gram_reduce_kernel, dim3(ti * tj), dim3(256), 0, s, work_dev, ti * tj, (int)chunks, tj, sym, R, tj,
-                     (int)chunks, c_dev, ldc);
+                     (int)chunks, 0, c_dev, ldc);
   HSR_LAUNCH_CHECK("gram_f64_kernel");
   return HSR_OK;
 }

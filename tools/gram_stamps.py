@@ -32,7 +32,7 @@ for T in (32, 285):
     for k in np.unique(kind):
         u = us[kind == k]
         nbt = s[kind == k, 5] % 1000000
-        print(f"  RY={k}: {len(u)} workgroups, local batches {nbt.min()}..{nbt.max()}")
+        print(f"  kind {k} (3 = wide 3 x 3, 1 = narrow 3 x 1, 2 = diagonal): {len(u)} workgroups, local batches {nbt.min()}..{nbt.max()}")
         for i, name in enumerate(("entry", "prologue done", "loop done", "combine done", "stored")):
             print(f"    {name:14s} min {u[:, i].min():7.1f}  median {np.median(u[:, i]):7.1f}  max {u[:, i].max():7.1f} us")
         d = u[:, 2] - u[:, 1]

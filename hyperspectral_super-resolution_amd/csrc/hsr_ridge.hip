@@ -1321,14 +1321,28 @@ __global__ __launch_bounds__(256) void ridge_stats_partial_kernel(const float* _
     s1[c] = s2[c] = 0.0;
     K[c] = c < n_in ? (double)x[c * x_cs] : 0.0;
   }
-  for (int64_t r = r0 + t; r < r1; r += 256) {
+  // four rows per pass with all their loads issued before the first sum (a block walks <= 1024 rows: one exposed round trip
+  // instead of four; r03 trace: 11.9 us for 1.2 MB); the sums keep their row order
+  for (int64_t rb = r0 + t; rb < r1; rb += 4 * 256) {
+    float v[4][16];
 #pragma unroll
-    for (int c = 0; c < 16; ++c)
-      if (c < n_in) {
-        const double d = (double)x[r * x_rs + c * x_cs] - K[c];
-        s1[c] += d;
-        s2[c] += d * d;
-      }
+    for (int q = 0; q < 4; ++q) {
+      const int64_t r = rb + q * 256;
+#pragma unroll
+      for (int c = 0; c < 16; ++c)
+        if (c < n_in && r < r1) v[q][c] = x[r * x_rs + c * x_cs];
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      if (rb + q * 256 >= r1) break;
+#pragma unroll
+      for (int c = 0; c < 16; ++c)
+        if (c < n_in) {
+          const double d = (double)v[q][c] - K[c];
+          s1[c] += d;
+          s2[c] += d * d;
+        }
+    }
   }
 #pragma unroll
   for (int c = 0; c < 16; ++c) {

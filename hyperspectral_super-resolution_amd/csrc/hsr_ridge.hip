@@ -886,8 +886,11 @@ __device__ __forceinline__ void mfma_steps103(const float (&z)[11], int kh, cons
 }
 
 
+#ifndef HSR_PRED_OCC1
+#define HSR_PRED_OCC1 4
+#endif
 template <int TT, bool WHOLE>
-__global__ __launch_bounds__(256, 2) void predict103_kernel(const PredArgs a) {
+__global__ __launch_bounds__(256, TT == 1 ? HSR_PRED_OCC1 : 2) void predict103_kernel(const PredArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* wl = reinterpret_cast<float*>(smem);
   constexpr int Tp = TT * 32;                       // padded target count held by every wave
@@ -1088,7 +1091,8 @@ static void launch_predict103(const PredArgs& a, hipStream_t s) {
     configured = true;
   }
   int64_t tiles = (a.npix + 127) / 128;
-  const int grid = (int)(tiles < 512 ? tiles : 512);
+  const int resident = 256 * (TT == 1 ? HSR_PRED_OCC1 : 2);
+  const int grid = (int)(tiles < resident ? tiles : resident);
   hipLaunchKernelGGL((predict103_kernel<TT, WHOLE>), dim3(grid), dim3(256), lds, s, a);
 }
 

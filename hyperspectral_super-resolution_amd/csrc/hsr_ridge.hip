@@ -886,11 +886,18 @@ __device__ __forceinline__ void mfma_steps103(const float (&z)[11], int kh, cons
 }
 
 
+// workgroups per CU: a wave of the T <= 32 kernel carries ONE accumulator chain (143 dependent MFMAs per tile) and a 16-value
+// sigmoid epilogue; with four waves per SIMD instead of two the matrix pipe has something to run while a wave is in its
+// epilogue or waits for its next operand (r03: 0.214 -> 0.199 ms per Mpixel, 111 VGPRs, W resident in 36.6 KB of LDS)
 #ifndef HSR_PRED_OCC1
 #define HSR_PRED_OCC1 4
 #endif
+#ifndef HSR_PRED_OCC2
+#define HSR_PRED_OCC2 2
+#endif
+constexpr int pred103_occupancy(int tt) { return tt == 1 ? HSR_PRED_OCC1 : tt == 2 ? HSR_PRED_OCC2 : 2; }
 template <int TT, bool WHOLE>
-__global__ __launch_bounds__(256, TT == 1 ? HSR_PRED_OCC1 : 2) void predict103_kernel(const PredArgs a) {
+__global__ __launch_bounds__(256, pred103_occupancy(TT)) void predict103_kernel(const PredArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* wl = reinterpret_cast<float*>(smem);
   constexpr int Tp = TT * 32;                       // padded target count held by every wave
@@ -1091,7 +1098,7 @@ static void launch_predict103(const PredArgs& a, hipStream_t s) {
     configured = true;
   }
   int64_t tiles = (a.npix + 127) / 128;
-  const int resident = 256 * (TT == 1 ? HSR_PRED_OCC1 : 2);
+  const int resident = 256 * pred103_occupancy(TT);
   const int grid = (int)(tiles < resident ? tiles : resident);
   hipLaunchKernelGGL((predict103_kernel<TT, WHOLE>), dim3(grid), dim3(256), lds, s, a);
 }

@@ -999,19 +999,24 @@ __global__ __launch_bounds__(256, pred103_occupancy(TT)) void predict103_kernel(
 // Many targets (T > 96, e.g. EMIT's 285 bands): the chunked path above re-stages the whole 329 KB of W through LDS for
 // every 128-pixel tile, with nine barriers per tile, and sat at 39 % of the f32-MFMA peak against 50 % for T <= 32 where
 // W is resident.  W does not fit one LDS, but a SLICE of 96 targets does (286 x 96 x 4 = 110 KB): blockIdx.y picks the
-// slice, the slice is staged once per workgroup and stays for the whole launch, and the workgroup (8 waves = 2 per
+// slice, the slice is staged once per workgroup and stays for the whole launch, and the workgroup (12 waves = 3 per
 // SIMD, each wave its own 32 pixels) walks the pixel tiles with no staging and no barrier in the loop.  The monomials
 // of a pixel are recomputed once per slice (2-4 v_mul per MFMA step of 3 x 64 cycles: free) and its 10 inputs re-read
 // (40 B per slice: nothing).  3 accumulator tiles per wave instead of 9.
 constexpr int kSliceTT = 3;
-__global__ __launch_bounds__(512, 2) void predict103_slice_kernel(const PredArgs a) {
+#ifndef HSR_SLICE_WAVES
+#define HSR_SLICE_WAVES 12       // r03: 8 -> 12 waves on the one slice a CU holds (3 per SIMD, 168 VGPRs, no spill): 1.675 -> 1.603 ms
+#endif                           // at T = 285 on one box; 16 waves (128 VGPRs) spill
+constexpr int kSliceThreads = 64 * HSR_SLICE_WAVES;      // waves per workgroup = waves per CU (one workgroup per CU)
+constexpr int kSlicePix = 32 * HSR_SLICE_WAVES;          // pixels per tile: 32 per wave
+__global__ __launch_bounds__(kSliceThreads, HSR_SLICE_WAVES / 4) void predict103_slice_kernel(const PredArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* wl = reinterpret_cast<float*>(smem);
   constexpr int TT = kSliceTT, Tp = TT * 32;
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int j = lane & 31, kh = lane >> 5;
   const int t0 = blockIdx.y * Tp;                   // first target of this workgroup's slice
-  for (int i = t; i < 286 * Tp; i += 512) {
+  for (int i = t; i < 286 * Tp; i += kSliceThreads) {
     const int r = i / Tp, c = i % Tp;
     wl[i] = t0 + c < a.T ? a.W[(size_t)r * a.ldw + t0 + c] : 0.0f;
   }
@@ -1026,14 +1031,14 @@ __global__ __launch_bounds__(512, 2) void predict103_slice_kernel(const PredArgs
     }
   float xn[10];                                        // inputs of the next tile, loaded under this tile's MFMA chain
   auto load_inputs = [&](int64_t tile_) {
-    const int64_t p_ = tile_ * 256 + wave * 32 + j;
+    const int64_t p_ = tile_ * kSlicePix + wave * 32 + j;
     const int64_t pc_ = p_ < a.npix ? p_ : a.npix - 1;
 #pragma unroll
     for (int c = 0; c < 10; ++c) xn[c] = a.x[pc_ * a.x_ps + c * a.x_cs];
   };
-  if ((int64_t)blockIdx.x * 256 < a.npix) load_inputs(blockIdx.x);
-  for (int64_t tile = blockIdx.x; tile * 256 < a.npix; tile += gridDim.x) {
-    const int64_t p = tile * 256 + wave * 32 + j;
+  if ((int64_t)blockIdx.x * kSlicePix < a.npix) load_inputs(blockIdx.x);
+  for (int64_t tile = blockIdx.x; tile * kSlicePix < a.npix; tile += gridDim.x) {
+    const int64_t p = tile * kSlicePix + wave * 32 + j;
     float z[11];
     bool bad = false;
 #pragma unroll
@@ -1044,7 +1049,7 @@ __global__ __launch_bounds__(512, 2) void predict103_slice_kernel(const PredArgs
     }
     bad = bad && a.nan_bad != 0;
     z[10] = 1.0f;
-    if ((tile + gridDim.x) * 256 < a.npix) load_inputs(tile + gridDim.x);
+    if ((tile + gridDim.x) * kSlicePix < a.npix) load_inputs(tile + gridDim.x);
     f32x16 acc[TT];
 #pragma unroll
     for (int q = 0; q < TT; ++q)
@@ -1080,11 +1085,11 @@ static void launch_predict103_slices(const PredArgs& a, hipStream_t s) {
     configured = true;
   }
   const int slices = (a.T + kSliceTT * 32 - 1) / (kSliceTT * 32);
-  int64_t tiles = (a.npix + 255) / 256;
+  int64_t tiles = (a.npix + kSlicePix - 1) / kSlicePix;
   int gx = 256 / slices;                       // one workgroup per CU in all (110 KB of LDS each)
   if (gx < 1) gx = 1;
   if (tiles < gx) gx = (int)tiles;
-  hipLaunchKernelGGL(predict103_slice_kernel, dim3(gx, slices), dim3(512), lds, s, a);
+  hipLaunchKernelGGL(predict103_slice_kernel, dim3(gx, slices), dim3(kSliceThreads), lds, s, a);
 }
 
 template <int TT, bool WHOLE>

@@ -1003,16 +1003,25 @@ __global__ __launch_bounds__(256, pred103_occupancy(TT)) void predict103_kernel(
 // SIMD, each wave its own 32 pixels) walks the pixel tiles with no staging and no barrier in the loop.  The monomials
 // of a pixel are recomputed once per slice (2-4 v_mul per MFMA step of 3 x 64 cycles: free) and its 10 inputs re-read
 // (40 B per slice: nothing).  3 accumulator tiles per wave instead of 9.
-constexpr int kSliceTT = 3;
+// r03: (a) 8 -> 12 waves on the one 96-target slice a CU holds (3 per SIMD, 168 VGPRs, no spill; 16 waves = 128 VGPRs spill):
+// 1.675 -> 1.603 ms at T = 285 on one box; (b) the kernel is a template on the slice width, and it also serves 33 <= T <= 96 with
+// ONE slice: the chunked predict103_kernel<2 / 3, false> (nine barriers and a re-staged W per 128-pixel tile) took 0.83-0.87 ms
+// per Mpixel for 65-96 targets, the 96-wide slice kernel 0.51-0.52 ms; (c) slices are as narrow as the target count allows
+// (T = 97: two slices of 64 instead of two of 96).  64-target slices run 16 waves (4 per SIMD) on their 73 KB of W.
 #ifndef HSR_SLICE_WAVES
-#define HSR_SLICE_WAVES 12       // r03: 8 -> 12 waves on the one slice a CU holds (3 per SIMD, 168 VGPRs, no spill): 1.675 -> 1.603 ms
-#endif                           // at T = 285 on one box; 16 waves (128 VGPRs) spill
-constexpr int kSliceThreads = 64 * HSR_SLICE_WAVES;      // waves per workgroup = waves per CU (one workgroup per CU)
-constexpr int kSlicePix = 32 * HSR_SLICE_WAVES;          // pixels per tile: 32 per wave
-__global__ __launch_bounds__(kSliceThreads, HSR_SLICE_WAVES / 4) void predict103_slice_kernel(const PredArgs a) {
+#define HSR_SLICE_WAVES 12
+#endif
+#ifndef HSR_SLICE2_WAVES
+#define HSR_SLICE2_WAVES 16
+#endif
+constexpr int slice_waves(int tt) { return tt == 3 ? HSR_SLICE_WAVES : HSR_SLICE2_WAVES; }
+template <int TT>
+__global__ __launch_bounds__(64 * slice_waves(TT), slice_waves(TT) / 4) void predict103_slice_kernel(const PredArgs a) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   float* wl = reinterpret_cast<float*>(smem);
-  constexpr int TT = kSliceTT, Tp = TT * 32;
+  constexpr int Tp = TT * 32;
+  constexpr int kSliceThreads = 64 * slice_waves(TT);      // waves per workgroup = waves per CU (one workgroup per CU)
+  constexpr int kSlicePix = 32 * slice_waves(TT);          // pixels per tile: 32 per wave
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int j = lane & 31, kh = lane >> 5;
   const int t0 = blockIdx.y * Tp;                   // first target of this workgroup's slice
@@ -1076,20 +1085,21 @@ __global__ __launch_bounds__(kSliceThreads, HSR_SLICE_WAVES / 4) void predict103
   }
 }
 
-static void launch_predict103_slices(const PredArgs& a, hipStream_t s) {
-  const size_t lds = (size_t)286 * kSliceTT * 32 * 4;
+template <int TT>
+static void launch_predict103_slices(const PredArgs& a, int slices, hipStream_t s) {
+  const size_t lds = (size_t)286 * TT * 32 * 4;
   static thread_local bool configured = false;
   if (!configured) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(predict103_slice_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(predict103_slice_kernel<TT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     (void)hipGetLastError();
     configured = true;
   }
-  const int slices = (a.T + kSliceTT * 32 - 1) / (kSliceTT * 32);
-  int64_t tiles = (a.npix + kSlicePix - 1) / kSlicePix;
-  int gx = 256 / slices;                       // one workgroup per CU in all (110 KB of LDS each)
+  constexpr int pix = 32 * slice_waves(TT);
+  int64_t tiles = (a.npix + pix - 1) / pix;
+  int gx = 256 / slices;                       // one workgroup per CU in all (73 / 110 KB of LDS each)
   if (gx < 1) gx = 1;
   if (tiles < gx) gx = (int)tiles;
-  hipLaunchKernelGGL(predict103_slice_kernel, dim3(gx, slices), dim3(kSliceThreads), lds, s, a);
+  hipLaunchKernelGGL(predict103_slice_kernel<TT>, dim3(gx, slices), dim3(64 * slice_waves(TT)), lds, s, a);
 }
 
 template <int TT, bool WHOLE>
@@ -1113,9 +1123,16 @@ static bool try_predict103(const PredArgs& a, hipStream_t s) {
   if (a.n_in != 10 || a.nfeat != 285) return false;
   const int tt = a.ttiles;
   if (tt == 1) launch_predict103<1, true>(a, s);          // T <= 32: W resident (36.6 KB)
-  else if (tt == 2) launch_predict103<2, false>(a, s);
-  else if (tt <= 3) launch_predict103<3, false>(a, s);
-  else if (tt <= 16) launch_predict103_slices(a, s);       // T <= 512 (EMIT's 285 bands: three slices of 96)
+#ifdef HSR_PRED_CHUNKED
+  else if (tt == 2) launch_predict103<2, false>(a, s);    // diagnostic builds: the chunked kernels of rounds 1-2
+  else if (tt == 3) launch_predict103<3, false>(a, s);
+#endif
+  else if (tt <= 16) {                                    // T <= 512: slices of 64 or 96 targets, as few and as narrow as T allows
+    const int slices = (tt + 2) / 3;
+    const int per = (tt + slices - 1) / slices;           // 32-target tiles per slice: 2 or 3 (1 only for tt == 1)
+    if (per <= 2) launch_predict103_slices<2>(a, slices, s);
+    else launch_predict103_slices<3>(a, slices, s);
+  }
   else return false;
   return true;
 }

@@ -181,6 +181,9 @@ def main():
     cs_ = os.path.join(src, "chol_stamps.log")
     if os.path.isfile(cs_):
         out += ["\nWhere the one-workgroup Cholesky factorisation spends its cycles (`tools/chol_stamps`, n = 288):\n", "```"] + [l.rstrip() for l in open(cs_)] + ["```"]
+    tp_ = os.path.join(src, "time_predict.log")
+    if os.path.exists(tp_):
+        out += ["\n`tools/time_predict.py` (predict_cube over 1024 x 1024 pixels, random degree-3 model):\n", "```"] + [l.rstrip() for l in open(tp_) if l.startswith("T=")] + ["```"]
     gs_ = os.path.join(src, "gram_stamps.log")
     if os.path.exists(gs_):
         out += ["\nPhase timeline of `gram_f64_lds_kernel` (`tools/gram_stamps.py`: s_memrealtime at the phase boundaries of every workgroup, "

@@ -886,6 +886,23 @@ __device__ __forceinline__ void mfma_steps103(const float (&z)[11], int kh, cons
 }
 
 
+// the 10 inputs of one pixel.  Pixel-major rows (x_cs == 1, the (N, 10) arrays of predict()) with an even pitch and an 8-byte
+// aligned base are read as five float2 instead of ten scalars: a wave's 32 pixels then touch their 40-byte rows once per 8 bytes
+__device__ __forceinline__ void pred_load10(const PredArgs& a, int64_t pc, float (&x)[10]) {
+  if (a.x_cs == 1 && (a.x_ps & 1) == 0 && (((uintptr_t)a.x) & 7) == 0) {       // launch-uniform
+    const float2* r = reinterpret_cast<const float2*>(a.x + pc * a.x_ps);
+#pragma unroll
+    for (int c = 0; c < 5; ++c) {
+      const float2 v = r[c];
+      x[2 * c] = v.x;
+      x[2 * c + 1] = v.y;
+    }
+  } else {
+#pragma unroll
+    for (int c = 0; c < 10; ++c) x[c] = a.x[pc * a.x_ps + c * a.x_cs];
+  }
+}
+
 // workgroups per CU: a wave of the T <= 32 kernel carries ONE accumulator chain (143 dependent MFMAs per tile) and a 16-value
 // sigmoid epilogue; with four waves per SIMD instead of two the matrix pipe has something to run while a wave is in its
 // epilogue or waits for its next operand (r03: 0.214 -> 0.199 ms per Mpixel, 111 VGPRs, W resident in 36.6 KB of LDS)
@@ -924,8 +941,7 @@ __global__ __launch_bounds__(256, pred103_occupancy(TT)) void predict103_kernel(
   auto load_inputs = [&](int64_t tile_) {
     const int64_t p_ = tile_ * 128 + wave * 32 + j;
     const int64_t pc_ = p_ < a.npix ? p_ : a.npix - 1;
-#pragma unroll
-    for (int c = 0; c < 10; ++c) xn[c] = a.x[pc_ * a.x_ps + c * a.x_cs];
+    pred_load10(a, pc_, xn);
   };
   if ((int64_t)blockIdx.x * 128 < a.npix) load_inputs(blockIdx.x);
   for (int64_t tile = blockIdx.x; tile * 128 < a.npix; tile += gridDim.x) {
@@ -1042,8 +1058,7 @@ __global__ __launch_bounds__(64 * slice_waves(TT), slice_waves(TT) / 4) void pre
   auto load_inputs = [&](int64_t tile_) {
     const int64_t p_ = tile_ * kSlicePix + wave * 32 + j;
     const int64_t pc_ = p_ < a.npix ? p_ : a.npix - 1;
-#pragma unroll
-    for (int c = 0; c < 10; ++c) xn[c] = a.x[pc_ * a.x_ps + c * a.x_cs];
+    pred_load10(a, pc_, xn);
   };
   if ((int64_t)blockIdx.x * kSlicePix < a.npix) load_inputs(blockIdx.x);
   for (int64_t tile = blockIdx.x; tile * kSlicePix < a.npix; tile += gridDim.x) {

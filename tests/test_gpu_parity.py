@@ -620,11 +620,12 @@ def _a9_problem(rng, N, Cin, T):
     return X, Y
 
 
-@pytest.mark.parametrize("T", [33, 64, 96, 97, 192, 285])
+@pytest.mark.parametrize("T", [33, 64, 96, 97, 128, 130, 192, 285])
 def test_predict103_kernel_families_vs_oracle(torch_gpu, T):
     """Every many-target predict kernel of the notebook's shape (10 inputs, degree 3; Spectral_matching.ipynb raw :192-213,
-    :475-490 generalised to T targets) against the float64 oracle, NOT against itself: T 33-96 runs the chunked
-    predict103_kernel<2/3, false>, T 97-512 the sliced predict103_slice_kernel (hsr_ridge.hip).  Two views:
+    :475-490 generalised to T targets) against the float64 oracle, NOT against itself: T 33-64 runs one 64-target slice of
+    predict103_slice_kernel<2>, 65-96 one 96-target slice of <3>, above that as few and as narrow slices as T allows (97 and
+    128: two of 64; 130, 192: two of 96; 285: three of 96) (hsr_ridge.hip).  Two views:
       (a) the kernels alone - the ORACLE'S model loaded with from_params, so a wrong W-slice offset or target-tile epilogue
           cannot hide behind a consistent fit;
       (b) fit + predict end to end.

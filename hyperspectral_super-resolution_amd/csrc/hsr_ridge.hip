@@ -1137,7 +1137,11 @@ static void launch_predict103(const PredArgs& a, hipStream_t s) {
 static bool try_predict103(const PredArgs& a, hipStream_t s) {
   if (a.n_in != 10 || a.nfeat != 285) return false;
   const int tt = a.ttiles;
-  if (tt == 1) launch_predict103<1, true>(a, s);          // T <= 32: W resident (36.6 KB)
+#ifdef HSR_PRED_CHUNKED
+  if (tt == 1) launch_predict103<1, true>(a, s);          // diagnostic builds: four 4-wave workgroups per CU, each with its own copy of W
+#else
+  if (tt == 1) launch_predict103_slices<1>(a, 1, s);      // T <= 32: one 16-wave workgroup per CU, W (36.6 KB) staged once per CU (0.209 -> 0.199 ms)
+#endif
 #ifdef HSR_PRED_CHUNKED
   else if (tt == 2) launch_predict103<2, false>(a, s);    // diagnostic builds: the chunked kernels of rounds 1-2
   else if (tt == 3) launch_predict103<3, false>(a, s);

@@ -43,6 +43,20 @@ __device__ __forceinline__ float key_f32(uint32_t k) {
 }
 
 constexpr uint32_t kNoBin = 0xffffffffu;
+// r03: 1024-thread workgroups (were 256 / 512).  Every workgroup ends by adding its LDS histogram to the global one with
+// integer atomics - in pass 2 a few thousand non-zero bins each, all workgroups on the same addresses; the same number of
+// resident waves in a quarter / half of the workgroups: 404 -> 367 us (three 6144 x 6144 planes), 86 -> 60 us (1024 x 1024).
+#ifndef HSR_SEL_THREADS
+#define HSR_SEL_THREADS 1024
+#endif
+#ifndef HSR_ROWS_THREADS
+#define HSR_ROWS_THREADS 1024
+#endif
+constexpr int kSelThreads = HSR_SEL_THREADS;      // workgroup of select_hist_kernel
+constexpr int kRowsThreads = HSR_ROWS_THREADS;    // workgroup of select_hist_rows4_kernel
+// resident waves stay the same whatever the workgroup size: the caps below count workgroups of 256 / 512 threads
+#define HSR_SEL_PLANE_WGS (1024 * 256 / HSR_SEL_THREADS)
+#define HSR_SEL_ROWS4_WGS (1024 * 512 / HSR_ROWS_THREADS)
 
 // Pass-1 increments.  Reflectance images put most of a wave's 64 samples into two or three of the 2048
 // top-bit bins, and same-address LDS atomics serialise lane by lane; so the two most common bins of the wave are
@@ -63,25 +77,50 @@ __device__ __forceinline__ void hist_add_wave(uint32_t* h, uint32_t bin) {
   if (bin != kNoBin) atomicAdd(&h[bin], 1u);
 }
 
+// The prev / next ranks of a percentile nearly always share their prefix (and on short-range data both percentiles do): a
+// query whose prefix equals its predecessor's is not histogrammed a second time - its slot is parked on a key no sample has -
+// and the scan reads the predecessor's histogram for it (select_scan_kernel).  r03 trace: pass 2 was the slowest of the three
+// (168 us against 142 / 88 us on three 6144 x 6144 planes), every matching sample paying two LDS atomics.
+constexpr uint32_t kNoPrefix = 0xffffffffu;      // prefixes have 11 or 22 bits
+__device__ __forceinline__ void dedupe_prefixes(uint32_t (&pre)[kQ]) {
+  const uint32_t p0 = pre[0], p1 = pre[1], p2 = pre[2], p3 = pre[3];
+  pre[1] = p1 == p0 ? kNoPrefix : p1;
+  pre[2] = p2 == p1 ? kNoPrefix : p2;
+  pre[3] = p3 == p2 ? kNoPrefix : p3;
+}
+
+// LDS holds the histograms of TWO queries in passes 2 and 3 (kLdsQ): query 0 and the next query with a prefix of its own
+// (`second`, 1..3; 0 = none).  A third / fourth distinct prefix - the prev / next ranks of a percentile straddling a bin
+// boundary - is rare and counts straight into the global histogram.  With all four in LDS pass 2 needed 32 KB per channel
+// (96 KB for the three channels of the band-last kernel: one workgroup per CU) and was the slowest pass for lack of waves in
+// flight, not for its atomics.
+constexpr int kLdsQ = 2;
 template <int PASS>
-__device__ __forceinline__ void hist_sample(uint32_t* h, uint32_t* nanc, const uint32_t (&pre)[kQ], float v, bool use) {
+__device__ __forceinline__ void hist_sample(uint32_t* h, uint32_t* nanc, const uint32_t (&pre)[kQ], int second, uint32_t* g,
+                                            float v, bool use) {
   const uint32_t k = f32_key(v);
   if (PASS == 1) {
     hist_add_wave(h, use ? (k >> 21) : kNoBin);
     if (use && v != v) atomicAdd(nanc, 1u);
-  } else if (PASS == 2) {
-    if (use) {
-#pragma unroll
-      for (int q = 0; q < kQ; ++q)
-        if ((k >> 21) == pre[q]) atomicAdd(&h[q * kBins2 + ((k >> 10) & 2047u)], 1u);
-    }
   } else {
+    constexpr int NBINS = PASS == 2 ? kBins2 : kBins3;
+    const uint32_t key = PASS == 2 ? (k >> 21) : (k >> 10);
+    const uint32_t bin = PASS == 2 ? ((k >> 10) & 2047u) : (k & 1023u);
     if (use) {
+      if (key == pre[0]) atomicAdd(&h[bin], 1u);
 #pragma unroll
-      for (int q = 0; q < kQ; ++q)
-        if ((k >> 10) == pre[q]) atomicAdd(&h[q * kBins3 + (k & 1023u)], 1u);
+      for (int q = 1; q < kQ; ++q)
+        if (key == pre[q]) {
+          if (q == second) atomicAdd(&h[NBINS + bin], 1u);
+          else atomicAdd(&g[q * NBINS + bin], 1u);
+        }
     }
   }
+}
+
+// first query after 0 whose prefix is its own (after dedupe_prefixes); 0 if there is none
+__device__ __forceinline__ int second_query(const uint32_t (&pre)[kQ]) {
+  return pre[1] != kNoPrefix ? 1 : (pre[2] != kNoPrefix ? 2 : (pre[3] != kNoPrefix ? 3 : 0));
 }
 
 // VEC: band-major planes whose rows start 16-byte aligned (and a 4-byte aligned mask): 4 samples + 4 mask bytes
@@ -89,28 +128,33 @@ __device__ __forceinline__ void hist_sample(uint32_t* h, uint32_t* nanc, const u
 // dependent mask-byte load and ran at 1.4 TB/s.
 // MODE 0: any strides, one sample per load.  MODE 1: VEC above.  (Band-last rows of 4 floats: select_hist_rows4_kernel.)
 template <int PASS, int MODE>
-__global__ __launch_bounds__(256) void select_hist_kernel(const SelArgs a) {
+__global__ __launch_bounds__(kSelThreads) void select_hist_kernel(const SelArgs a) {
   constexpr bool VEC = MODE == 1;
-  constexpr int NB = PASS == 1 ? kBins1 : (PASS == 2 ? kBins2 * kQ : kBins3 * kQ);
+  constexpr int NBINS = PASS == 1 ? kBins1 : (PASS == 2 ? kBins2 : kBins3);
+  constexpr int NB = PASS == 1 ? kBins1 : NBINS * kLdsQ;
   __shared__ uint32_t h[NB];
   __shared__ uint32_t nanc;
   const int c = blockIdx.y;
-  for (int i = threadIdx.x; i < NB; i += 256) h[i] = 0u;
+  for (int i = threadIdx.x; i < NB; i += kSelThreads) h[i] = 0u;
   if (threadIdx.x == 0) nanc = 0u;
   uint32_t pre[kQ] = {0u, 0u, 0u, 0u};
   if (PASS > 1) {
 #pragma unroll
     for (int q = 0; q < kQ; ++q) pre[q] = a.state[c].prefix[q];
+    dedupe_prefixes(pre);
   }
+  const int second = PASS > 1 ? second_query(pre) : 0;
+  uint32_t* g = PASS == 1 ? a.hist1 + (size_t)c * kHist1
+                          : (PASS == 2 ? a.hist2 + (size_t)c * kQ * kBins2 : a.hist3 + (size_t)c * kQ * kBins3);
   __syncthreads();
   const float* x = a.x + (size_t)c * a.cs;
-  const int64_t stride = (int64_t)gridDim.x * 256;
+  const int64_t stride = (int64_t)gridDim.x * kSelThreads;
   if (VEC) {
     const int64_t n4 = a.npix >> 2;
     const float4* x4 = reinterpret_cast<const float4*>(x);
     const uint32_t* m4 = reinterpret_cast<const uint32_t*>(a.mask);
     // whole-wave trip count: hist_add_wave uses ballots, so every lane of a wave runs every iteration
-    const int64_t first = (int64_t)blockIdx.x * 256 + (threadIdx.x & ~63);
+    const int64_t first = (int64_t)blockIdx.x * kSelThreads + (threadIdx.x & ~63);
     for (int64_t base = first; base < n4; base += 2 * stride) {
       const int64_t i0 = base + (threadIdx.x & 63), i1 = i0 + stride;
       const bool on0 = i0 < n4, on1 = i1 < n4;
@@ -124,35 +168,35 @@ __global__ __launch_bounds__(256) void select_hist_kernel(const SelArgs a) {
         v1 = ld_stream(x4 + i1);
         mk1 = m4 ? m4[i1] : 0x01010101u;
       }
-      hist_sample<PASS>(h, &nanc, pre, v0.x, (mk0 & 0x000000ffu) != 0u);
-      hist_sample<PASS>(h, &nanc, pre, v0.y, (mk0 & 0x0000ff00u) != 0u);
-      hist_sample<PASS>(h, &nanc, pre, v0.z, (mk0 & 0x00ff0000u) != 0u);
-      hist_sample<PASS>(h, &nanc, pre, v0.w, (mk0 & 0xff000000u) != 0u);
-      hist_sample<PASS>(h, &nanc, pre, v1.x, (mk1 & 0x000000ffu) != 0u);
-      hist_sample<PASS>(h, &nanc, pre, v1.y, (mk1 & 0x0000ff00u) != 0u);
-      hist_sample<PASS>(h, &nanc, pre, v1.z, (mk1 & 0x00ff0000u) != 0u);
-      hist_sample<PASS>(h, &nanc, pre, v1.w, (mk1 & 0xff000000u) != 0u);
+      hist_sample<PASS>(h, &nanc, pre, second, g, v0.x, (mk0 & 0x000000ffu) != 0u);
+      hist_sample<PASS>(h, &nanc, pre, second, g, v0.y, (mk0 & 0x0000ff00u) != 0u);
+      hist_sample<PASS>(h, &nanc, pre, second, g, v0.z, (mk0 & 0x00ff0000u) != 0u);
+      hist_sample<PASS>(h, &nanc, pre, second, g, v0.w, (mk0 & 0xff000000u) != 0u);
+      hist_sample<PASS>(h, &nanc, pre, second, g, v1.x, (mk1 & 0x000000ffu) != 0u);
+      hist_sample<PASS>(h, &nanc, pre, second, g, v1.y, (mk1 & 0x0000ff00u) != 0u);
+      hist_sample<PASS>(h, &nanc, pre, second, g, v1.z, (mk1 & 0x00ff0000u) != 0u);
+      hist_sample<PASS>(h, &nanc, pre, second, g, v1.w, (mk1 & 0xff000000u) != 0u);
     }
     if (blockIdx.x == 0 && threadIdx.x < 64) {   // up to 3 tail samples, one wave (ballots need the whole wave)
       const int64_t p = n4 * 4 + threadIdx.x;
       const bool on = p < a.npix;
       const float v = on ? x[p] : 0.0f;
-      hist_sample<PASS>(h, &nanc, pre, v, on && (!a.mask || a.mask[p] != 0));
+      hist_sample<PASS>(h, &nanc, pre, second, g, v, on && (!a.mask || a.mask[p] != 0));
     }
   } else {
-    const int64_t first = (int64_t)blockIdx.x * 256 + (threadIdx.x & ~63);
+    const int64_t first = (int64_t)blockIdx.x * kSelThreads + (threadIdx.x & ~63);
     for (int64_t base = first; base < a.npix; base += stride) {
       const int64_t p = base + (threadIdx.x & 63);
       const bool on = p < a.npix && (!a.mask || a.mask[p] != 0);
       const float v = on ? ld_stream(x + p * a.ps) : 0.0f;
-      hist_sample<PASS>(h, &nanc, pre, v, on);
+      hist_sample<PASS>(h, &nanc, pre, second, g, v, on);
     }
   }
   __syncthreads();
-  uint32_t* g = PASS == 1 ? a.hist1 + (size_t)c * kHist1
-                          : (PASS == 2 ? a.hist2 + (size_t)c * kQ * kBins2 : a.hist3 + (size_t)c * kQ * kBins3);
-  for (int i = threadIdx.x; i < NB; i += 256)
+  for (int i = threadIdx.x; i < NBINS; i += kSelThreads) {
     if (h[i]) atomicAdd(&g[i], h[i]);
+    if (PASS > 1 && second && h[NBINS + i]) atomicAdd(&g[second * NBINS + i], h[NBINS + i]);
+  }
   if (PASS == 1 && threadIdx.x == 0 && nanc) atomicAdd(&a.hist1[(size_t)c * kHist1 + kBins1], nanc);
 }
 
@@ -162,13 +206,14 @@ __global__ __launch_bounds__(256) void select_hist_kernel(const SelArgs a) {
 // 6144 x 6144 x 4 image and was half of match_pair's time; loading whole rows once per channel was worse still
 // (the channel passes do not share L2 lines in time: 3x the traffic).
 template <int PASS>
-__global__ __launch_bounds__(512) void select_hist_rows4_kernel(const SelArgs a) {
-  constexpr int NB = PASS == 1 ? kBins1 : (PASS == 2 ? kBins2 * kQ : kBins3 * kQ);
+__global__ __launch_bounds__(kRowsThreads) void select_hist_rows4_kernel(const SelArgs a) {
+  constexpr int NBINS = PASS == 1 ? kBins1 : (PASS == 2 ? kBins2 : kBins3);
+  constexpr int NB = PASS == 1 ? kBins1 : NBINS * kLdsQ;
   extern __shared__ uint32_t hall[];          // [nb][NB]
   __shared__ uint32_t nanc[4];
   __shared__ uint32_t pre_s[4][kQ];
   const int nb = a.nb;
-  for (int i = threadIdx.x; i < nb * NB; i += 512) hall[i] = 0u;
+  for (int i = threadIdx.x; i < nb * NB; i += kRowsThreads) hall[i] = 0u;
   if (threadIdx.x < 4) nanc[threadIdx.x] = 0u;
   if (PASS > 1 && threadIdx.x < nb * kQ) pre_s[threadIdx.x / kQ][threadIdx.x % kQ] = a.state[threadIdx.x / kQ].prefix[threadIdx.x % kQ];
   __syncthreads();
@@ -177,10 +222,22 @@ __global__ __launch_bounds__(512) void select_hist_rows4_kernel(const SelArgs a)
   for (int c = 0; c < 4; ++c)
 #pragma unroll
     for (int q = 0; q < kQ; ++q) pre[c][q] = (PASS > 1 && c < nb) ? pre_s[c][q] : 0u;
+  if (PASS > 1) {
+#pragma unroll
+    for (int c = 0; c < 4; ++c) dedupe_prefixes(pre[c]);
+  }
+  int second[4];
+  uint32_t* gq[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    second[c] = PASS > 1 ? second_query(pre[c]) : 0;
+    gq[c] = PASS == 1 ? a.hist1 + (size_t)c * kHist1
+                      : (PASS == 2 ? a.hist2 + (size_t)c * kQ * kBins2 : a.hist3 + (size_t)c * kQ * kBins3);
+  }
   const float4* rows = reinterpret_cast<const float4*>(a.x);
   constexpr int U = 4;
-  const int64_t stride = (int64_t)gridDim.x * 512;
-  const int64_t first = (int64_t)blockIdx.x * 512 + (threadIdx.x & ~63);
+  const int64_t stride = (int64_t)gridDim.x * kRowsThreads;
+  const int64_t first = (int64_t)blockIdx.x * kRowsThreads + (threadIdx.x & ~63);
   for (int64_t base = first; base < a.npix; base += U * stride) {   // wave-uniform trip count (ballots inside)
     float4 v[U];
     bool on[U];
@@ -197,22 +254,28 @@ __global__ __launch_bounds__(512) void select_hist_rows4_kernel(const SelArgs a)
       const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #pragma unroll
       for (int c = 0; c < 4; ++c)
-        if (c < nb) hist_sample<PASS>(hall + c * NB, &nanc[c], pre[c], e[c], on[u]);   // c < nb is block-uniform
+        if (c < nb) hist_sample<PASS>(hall + c * NB, &nanc[c], pre[c], second[c], gq[c], e[c], on[u]);   // c < nb is block-uniform
     }
   }
   __syncthreads();
   for (int c = 0; c < nb; ++c) {
     uint32_t* g = PASS == 1 ? a.hist1 + (size_t)c * kHist1
                             : (PASS == 2 ? a.hist2 + (size_t)c * kQ * kBins2 : a.hist3 + (size_t)c * kQ * kBins3);
-    for (int i = threadIdx.x; i < NB; i += 512)
+    int sec = 0;                                 // (second[c] with a run-time c)
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc)
+      if (cc == c) sec = second[cc];
+    for (int i = threadIdx.x; i < NBINS; i += kRowsThreads) {
       if (hall[c * NB + i]) atomicAdd(&g[i], hall[c * NB + i]);
+      if (PASS > 1 && sec && hall[c * NB + NBINS + i]) atomicAdd(&g[sec * NBINS + i], hall[c * NB + NBINS + i]);
+    }
     if (PASS == 1 && threadIdx.x == 0 && nanc[c]) atomicAdd(&a.hist1[(size_t)c * kHist1 + kBins1], nanc[c]);
   }
 }
 
 template <int PASS>
 static void launch_rows4(const SelArgs& a, hipStream_t s) {
-  constexpr int NB = PASS == 1 ? kBins1 : (PASS == 2 ? kBins2 * kQ : kBins3 * kQ);
+  constexpr int NB = PASS == 1 ? kBins1 : (PASS == 2 ? kBins2 * kLdsQ : kBins3 * kLdsQ);
   const size_t lds = (size_t)a.nb * NB * sizeof(uint32_t);
   static thread_local size_t configured = 0;
   if (lds > configured) {
@@ -221,9 +284,9 @@ static void launch_rows4(const SelArgs& a, hipStream_t s) {
     (void)hipGetLastError();
     configured = lds;
   }
-  int64_t gx = (a.npix + 512 * 4 - 1) / (512 * 4);
-  if (gx > 1024) gx = 1024;
-  hipLaunchKernelGGL(select_hist_rows4_kernel<PASS>, dim3((unsigned)gx), dim3(512), lds, s, a);
+  int64_t gx = (a.npix + kRowsThreads * 4 - 1) / (kRowsThreads * 4);
+  if (gx > HSR_SEL_ROWS4_WGS) gx = HSR_SEL_ROWS4_WGS;
+  hipLaunchKernelGGL(select_hist_rows4_kernel<PASS>, dim3((unsigned)gx), dim3(kRowsThreads), lds, s, a);
 }
 
 // Locate, for one histogram of `nbins` (multiple of 256) bins, the bin holding 0-based rank r:
@@ -320,7 +383,9 @@ __global__ __launch_bounds__(256) void select_scan_kernel(const SelArgs a, doubl
     constexpr int SHIFT = PASS == 2 ? 11 : 10;
     const uint32_t* hist = PASS == 2 ? a.hist2 + (size_t)c * kQ * kBins2 : a.hist3 + (size_t)c * kQ * kBins3;
     for (int q = 0; q < kQ; ++q) {
-      block_locate(hist + (size_t)q * NBINS, NBINS, st->rem[q], scratch, &bins[q], &rems[q]);
+      int src = q;                                   // the first query of the run of equal prefixes: the one that was histogrammed
+      while (src > 0 && st->prefix[src - 1] == st->prefix[q]) --src;
+      block_locate(hist + (size_t)src * NBINS, NBINS, st->rem[q], scratch, &bins[q], &rems[q]);
       __syncthreads();
     }
     if (threadIdx.x == 0) {
@@ -380,8 +445,8 @@ static int select_setup(SelArgs& a, const float* x_dev, int64_t x_bs, int64_t x_
 }
 
 static dim3 select_grid(int64_t npix, int nb) {
-  int64_t gx = (npix + 256 * 8 - 1) / (256 * 8);
-  if (gx > 1024) gx = 1024;
+  int64_t gx = (npix + kSelThreads * 8 - 1) / (kSelThreads * 8);
+  if (gx > HSR_SEL_PLANE_WGS) gx = HSR_SEL_PLANE_WGS;
   return dim3((unsigned)gx, nb);
 }
 
@@ -413,7 +478,7 @@ extern "C" int hsr_percentile_hist(int32_t pass, const float* x_dev, int64_t x_b
   if (rc != HSR_OK) return rc;
   if (npix == 0) return HSR_OK;
   hipStream_t s = (hipStream_t)stream;
-  const dim3 grid = select_grid(npix, nb), block(256);
+  const dim3 grid = select_grid(npix, nb), block(kSelThreads);
   // band-major planes with 16-byte aligned rows (and a 4-byte aligned mask) take the 4-samples-per-load path
   const bool vec = x_ps == 1 && (x_bs & 3) == 0 && (((uintptr_t)x_dev) & 15) == 0 && (((uintptr_t)mask_dev) & 3) == 0;
   const bool rows4 = x_bs == 1 && x_ps == 4 && nb <= 4 && (((uintptr_t)x_dev) & 15) == 0;

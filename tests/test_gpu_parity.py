@@ -330,6 +330,18 @@ def test_percentile_limits_random_planes(torch_gpu):
             np.testing.assert_array_equal(got, ref)
     got = eng.percentile_limits(torch.from_numpy(planes).cuda(), None, 2, 98).cpu().numpy()
     np.testing.assert_array_equal(got, np.array([np.percentile(p, [2, 98]) for p in planes]))
+    # band-last rows of 4 floats (select_hist_rows4_kernel), three channels; sparse masks put the four ranks of a channel into
+    # different radix bins (r03: only two of them are histogrammed in LDS, the others count into global memory)
+    rows = np.zeros((npix, 4), np.float32)
+    rows[:, :3] = planes[[1, 0, 3]].T
+    for frac in (0.6, 0.0007, 1.0):
+        mask = rng.random(npix) < frac
+        mask[:2] = True
+        for pmin, pmax in ((2, 98), (0, 100), (33.3, 66.6)):
+            got = eng.percentile_limits(torch.from_numpy(rows).cuda(), torch.from_numpy(mask.view(np.uint8)).cuda(), pmin, pmax,
+                                        "pixmajor", nb=3).cpu().numpy()
+            ref = np.array([np.percentile(rows[mask, c], [pmin, pmax]) for c in range(3)])
+            np.testing.assert_array_equal(got, ref)
     pn = planes.copy()
     pn[0, 10] = np.nan
     got = eng.percentile_limits(torch.from_numpy(pn).cuda(), None, 2, 98).cpu().numpy()

@@ -127,6 +127,13 @@ def main():
         t["source_u16_fused"] = f"profiles/{tag}_u16_tiles.md (separate --pmc passes of bench.py --cube u16, fused pipeline)"
     json.dump(t, open(tf, "w"), indent=1)
     open(os.path.join(P, f"{tag}_u16_tiles.md"), "w").write("\n".join(out) + "\n")
+    # ---- auxiliary kernels
+    ax = os.path.join(src, "aux.log")
+    if os.path.exists(ax):
+        lines = [l.rstrip() for l in open(ax) if l.startswith("|")]
+        open(os.path.join(P, f"{tag}_aux_kernels.md"), "w").write(
+            f"# {tag}: auxiliary kernels of the path (`tools/bench_aux.py`, HIP events, MI355X) - resamplers (f1), exact masked percentiles (a4), "
+            "validity mask, K3 alone\n\n" + "\n".join(lines) + "\n")
     # ---- rehearsals
     out = [f"# {tag}: multi-rank control flow rehearsed on one GPU - the JSON lines (bench.py started WITHOUT a launcher: it starts its own ranks)\n"]
     d = jload(os.path.join(src, "bench_gloo4.json"))

@@ -109,36 +109,66 @@ __device__ __forceinline__ void up_tap(int i, int f, int n, int* i0, int* i1, do
 constexpr int kUpRows = 8;
 constexpr int kUpMaxVec = 4;   // band-last rows of 4 floats are stored with one 16-byte store
 
-template <bool VEC4>
+// r03 (rocprofv3 of the reference driver: 260 us for 1024^2 x 3 -> 6144^2 x 4, the largest kernel of the least-squares variant):
+// the ROW taps - a float64 division, a floor and two clamps, ~40 instructions - were recomputed by every thread for every
+// output pixel although they are the same for the whole row: the first kUpRows threads compute them once per workgroup
+// into LDS; and a band-last input row of 4 floats (IN4) is read with one 16-byte load per tap instead of one 4-byte load
+// per tap and band.  Same expressions on the same operands, same bits.
+template <bool VEC4, bool IN4>
 __global__ __launch_bounds__(256) void bilinear_up_kernel(const float* __restrict__ in, int64_t in_bs, int64_t in_ps,
                                                           int Hc, int Wc, int f, int nb, float* __restrict__ out,
                                                           int64_t out_bs, int64_t out_ps) {
+  __shared__ int ry0[kUpRows], ry1[kUpRows];
+  __shared__ double rty[kUpRows];
   const int Hf = Hc * f, Wf = Wc * f;
+  const int ybeg = blockIdx.y * kUpRows;
+  const int yend = ybeg + kUpRows < Hf ? ybeg + kUpRows : Hf;
+  if (threadIdx.x < kUpRows && ybeg + (int)threadIdx.x < yend) {
+    int a, b;
+    double t;
+    up_tap(ybeg + threadIdx.x, f, Hc, &a, &b, &t);
+    ry0[threadIdx.x] = a;
+    ry1[threadIdx.x] = b;
+    rty[threadIdx.x] = t;
+  }
+  __syncthreads();
   const int x = blockIdx.x * 256 + threadIdx.x;
   if (x >= Wf) return;
   int x0, x1;
   double tx;
   up_tap(x, f, Wc, &x0, &x1, &tx);
   const double ux = 1.0 - tx;
-  const int ybeg = blockIdx.y * kUpRows;
-  const int yend = ybeg + kUpRows < Hf ? ybeg + kUpRows : Hf;
   for (int y = ybeg; y < yend; ++y) {
-    int y0, y1;
-    double ty;
-    up_tap(y, f, Hc, &y0, &y1, &ty);
+    const int y0 = ry0[y - ybeg], y1 = ry1[y - ybeg];
+    const double ty = rty[y - ybeg];
     const double uy = 1.0 - ty;
     const int64_t i00 = ((int64_t)y0 * Wc + x0) * in_ps, i01 = ((int64_t)y0 * Wc + x1) * in_ps;
     const int64_t i10 = ((int64_t)y1 * Wc + x0) * in_ps, i11 = ((int64_t)y1 * Wc + x1) * in_ps;
     const int64_t p = (int64_t)y * Wf + x;
     if (VEC4) {
       float r[kUpMaxVec] = {0.0f, 0.0f, 0.0f, 0.0f};
+      if (IN4) {                                   // in_bs == 1, in_ps == 4, 16-byte aligned: the four taps as whole rows
+        const float4 q00 = *reinterpret_cast<const float4*>(in + i00), q01 = *reinterpret_cast<const float4*>(in + i01);
+        const float4 q10 = *reinterpret_cast<const float4*>(in + i10), q11 = *reinterpret_cast<const float4*>(in + i11);
+        const float a00[4] = {q00.x, q00.y, q00.z, q00.w}, a01[4] = {q01.x, q01.y, q01.z, q01.w};
+        const float a10[4] = {q10.x, q10.y, q10.z, q10.w}, a11[4] = {q11.x, q11.y, q11.z, q11.w};
 #pragma unroll
-      for (int b = 0; b < kUpMaxVec; ++b) {
-        if (b < nb) {
-          const float* src = in + (size_t)b * in_bs;
-          const double v00 = src[i00], v01 = src[i01], v10 = src[i10], v11 = src[i11];
-          const double top = v00 * ux + v01 * tx, bot = v10 * ux + v11 * tx;
-          r[b] = (float)(top * uy + bot * ty);
+        for (int b = 0; b < kUpMaxVec; ++b) {
+          if (b < nb) {
+            const double v00 = a00[b], v01 = a01[b], v10 = a10[b], v11 = a11[b];
+            const double top = v00 * ux + v01 * tx, bot = v10 * ux + v11 * tx;
+            r[b] = (float)(top * uy + bot * ty);
+          }
+        }
+      } else {
+#pragma unroll
+        for (int b = 0; b < kUpMaxVec; ++b) {
+          if (b < nb) {
+            const float* src = in + (size_t)b * in_bs;
+            const double v00 = src[i00], v01 = src[i01], v10 = src[i10], v11 = src[i11];
+            const double top = v00 * ux + v01 * tx, bot = v10 * ux + v11 * tx;
+            r[b] = (float)(top * uy + bot * ty);
+          }
         }
       }
       st_stream(reinterpret_cast<float4*>(out + p * 4), make_float4(r[0], r[1], r[2], r[3]));
@@ -202,11 +232,15 @@ extern "C" int hsr_bilinear_upsample(const float* in_dev, int64_t in_bs, int64_t
   const dim3 grid((unsigned)(((int64_t)Wc * factor + 255) / 256), (unsigned)(((int64_t)Hc * factor + kUpRows - 1) / kUpRows));
   HSR_REQUIRE(grid.y <= 65535u * 16u, HSR_ERR_UNSUPPORTED, "hsr_bilinear_upsample: fine grid too tall");
   const bool vec4 = out_bs == 1 && out_ps == 4 && nb <= kUpMaxVec && (((uintptr_t)out_dev) & 15) == 0;
-  if (vec4)
-    hipLaunchKernelGGL(bilinear_up_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, in_dev, in_bs, in_ps, Hc, Wc,
+  const bool in4 = in_bs == 1 && in_ps == 4 && (((uintptr_t)in_dev) & 15) == 0;
+  if (vec4 && in4)
+    hipLaunchKernelGGL((bilinear_up_kernel<true, true>), grid, dim3(256), 0, (hipStream_t)stream, in_dev, in_bs, in_ps, Hc, Wc,
+                       factor, nb, out_dev, out_bs, out_ps);
+  else if (vec4)
+    hipLaunchKernelGGL((bilinear_up_kernel<true, false>), grid, dim3(256), 0, (hipStream_t)stream, in_dev, in_bs, in_ps, Hc, Wc,
                        factor, nb, out_dev, out_bs, out_ps);
   else
-    hipLaunchKernelGGL(bilinear_up_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, in_dev, in_bs, in_ps, Hc, Wc,
+    hipLaunchKernelGGL((bilinear_up_kernel<false, false>), grid, dim3(256), 0, (hipStream_t)stream, in_dev, in_bs, in_ps, Hc, Wc,
                        factor, nb, out_dev, out_bs, out_ps);
   HSR_LAUNCH_CHECK("bilinear_up_kernel");
   return HSR_OK;

@@ -30,6 +30,7 @@ step force_exchange 200 python bench.py --force-exchange --steps 50 --no-cpu-bas
 step "trace batch" 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_batch -o batch -- python3 tools/bench_batch.py --tiles 256 --no-loop --rounds 2 > $O/batch_under_rocprof.json 2> $O/trace_batch.log
 for c in f32 u16; do timeout -k 10 200 python tools/bench_batch.py --tiles 256 --cube $c > $O/batch_$c.json 2>/dev/null; done
 timeout -k 10 200 python tools/bench_aux.py > $O/aux.log 2>&1
+timeout -k 10 200 python tools/bench_match_pair.py > $O/match_pair.log 2>&1
 echo "== a9"; timeout -k 10 200 python tools/bench_ridge.py > $O/ridge.log 2>&1
 timeout -k 10 200 python tools/time_predict.py > $O/time_predict.log 2>&1
 step "trace ridge" 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/trace_ridge -o p -- python3 tools/bench_ridge.py > /dev/null 2> $O/trace_ridge.log

@@ -133,7 +133,10 @@ def main():
         lines = [l.rstrip() for l in open(ax) if l.startswith("|")]
         open(os.path.join(P, f"{tag}_aux_kernels.md"), "w").write(
             f"# {tag}: auxiliary kernels of the path (`tools/bench_aux.py`, HIP events, MI355X) - resamplers (f1), exact masked percentiles (a4), "
-            "validity mask, K3 alone\n\n" + "\n".join(lines) + "\n")
+            "validity mask, K3 alone\n\n" + "\n".join(lines) + "\n" +
+            ("\nThe reference driver end to end (`tools/bench_match_pair.py`, device-resident inputs, host-timed with a synchronisation):\n\n```\n" +
+             "".join(l for l in open(os.path.join(src, "match_pair.log")) if l.startswith("match_pair")) + "```\n"
+             if os.path.exists(os.path.join(src, "match_pair.log")) else ""))
     # ---- rehearsals
     out = [f"# {tag}: multi-rank control flow rehearsed on one GPU - the JSON lines (bench.py started WITHOUT a launcher: it starts its own ranks)\n"]
     d = jload(os.path.join(src, "bench_gloo4.json"))

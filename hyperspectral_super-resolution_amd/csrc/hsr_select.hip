@@ -62,6 +62,10 @@ constexpr int kRowsThreads = HSR_ROWS_THREADS;    // workgroup of select_hist_ro
 // top-bit bins, and same-address LDS atomics serialise lane by lane; so the two most common bins of the wave are
 // peeled off with a ballot + one add of the population count each, and only what is left goes out as plain
 // atomics (spread-out data loses a dozen instructions and keeps its parallel atomics).
+// `copies` > 1: what is left after the peel goes to the copy of the histogram chosen by the lane's low bits
+// (h[copy * kBins1 + bin]) - lanes that still share a bin then hit different LDS words (spread-out data: ~20 distinct
+// bins per wave, up to 8 lanes each, serialised lane by lane on one word).  The copies are added when the workgroup flushes.
+template <int COPIES>
 __device__ __forceinline__ void hist_add_wave(uint32_t* h, uint32_t bin) {
   const int lane = threadIdx.x & 63;
 #pragma unroll
@@ -74,7 +78,7 @@ __device__ __forceinline__ void hist_add_wave(uint32_t* h, uint32_t bin) {
     if (lane == leader) atomicAdd(&h[lb], (uint32_t)__popcll(same));
     if (bin == lb) bin = kNoBin;
   }
-  if (bin != kNoBin) atomicAdd(&h[bin], 1u);
+  if (bin != kNoBin) atomicAdd(&h[(COPIES > 1 ? (lane & (COPIES - 1)) * kBins1 : 0) + bin], 1u);
 }
 
 // The prev / next ranks of a percentile nearly always share their prefix (and on short-range data both percentiles do): a
@@ -95,12 +99,16 @@ __device__ __forceinline__ void dedupe_prefixes(uint32_t (&pre)[kQ]) {
 // (96 KB for the three channels of the band-last kernel: one workgroup per CU) and was the slowest pass for lack of waves in
 // flight, not for its atomics.
 constexpr int kLdsQ = 2;
-template <int PASS>
+#ifndef HSR_SEL_COPIES
+#define HSR_SEL_COPIES 4
+#endif
+constexpr int kPass1Copies = HSR_SEL_COPIES;   // pass-1 histogram copies of select_hist_kernel (planes)
+template <int PASS, int COPIES = 1>
 __device__ __forceinline__ void hist_sample(uint32_t* h, uint32_t* nanc, const uint32_t (&pre)[kQ], int second, uint32_t* g,
                                             float v, bool use) {
   const uint32_t k = f32_key(v);
   if (PASS == 1) {
-    hist_add_wave(h, use ? (k >> 21) : kNoBin);
+    hist_add_wave<COPIES>(h, use ? (k >> 21) : kNoBin);
     if (use && v != v) atomicAdd(nanc, 1u);
   } else {
     constexpr int NBINS = PASS == 2 ? kBins2 : kBins3;
@@ -131,7 +139,8 @@ template <int PASS, int MODE>
 __global__ __launch_bounds__(kSelThreads) void select_hist_kernel(const SelArgs a) {
   constexpr bool VEC = MODE == 1;
   constexpr int NBINS = PASS == 1 ? kBins1 : (PASS == 2 ? kBins2 : kBins3);
-  constexpr int NB = PASS == 1 ? kBins1 : NBINS * kLdsQ;
+  constexpr int CP = PASS == 1 ? kPass1Copies : 1;
+  constexpr int NB = PASS == 1 ? kBins1 * CP : NBINS * kLdsQ;
   __shared__ uint32_t h[NB];
   __shared__ uint32_t nanc;
   const int c = blockIdx.y;
@@ -168,20 +177,20 @@ __global__ __launch_bounds__(kSelThreads) void select_hist_kernel(const SelArgs 
         v1 = ld_stream(x4 + i1);
         mk1 = m4 ? m4[i1] : 0x01010101u;
       }
-      hist_sample<PASS>(h, &nanc, pre, second, g, v0.x, (mk0 & 0x000000ffu) != 0u);
-      hist_sample<PASS>(h, &nanc, pre, second, g, v0.y, (mk0 & 0x0000ff00u) != 0u);
-      hist_sample<PASS>(h, &nanc, pre, second, g, v0.z, (mk0 & 0x00ff0000u) != 0u);
-      hist_sample<PASS>(h, &nanc, pre, second, g, v0.w, (mk0 & 0xff000000u) != 0u);
-      hist_sample<PASS>(h, &nanc, pre, second, g, v1.x, (mk1 & 0x000000ffu) != 0u);
-      hist_sample<PASS>(h, &nanc, pre, second, g, v1.y, (mk1 & 0x0000ff00u) != 0u);
-      hist_sample<PASS>(h, &nanc, pre, second, g, v1.z, (mk1 & 0x00ff0000u) != 0u);
-      hist_sample<PASS>(h, &nanc, pre, second, g, v1.w, (mk1 & 0xff000000u) != 0u);
+      hist_sample<PASS, CP>(h, &nanc, pre, second, g, v0.x, (mk0 & 0x000000ffu) != 0u);
+      hist_sample<PASS, CP>(h, &nanc, pre, second, g, v0.y, (mk0 & 0x0000ff00u) != 0u);
+      hist_sample<PASS, CP>(h, &nanc, pre, second, g, v0.z, (mk0 & 0x00ff0000u) != 0u);
+      hist_sample<PASS, CP>(h, &nanc, pre, second, g, v0.w, (mk0 & 0xff000000u) != 0u);
+      hist_sample<PASS, CP>(h, &nanc, pre, second, g, v1.x, (mk1 & 0x000000ffu) != 0u);
+      hist_sample<PASS, CP>(h, &nanc, pre, second, g, v1.y, (mk1 & 0x0000ff00u) != 0u);
+      hist_sample<PASS, CP>(h, &nanc, pre, second, g, v1.z, (mk1 & 0x00ff0000u) != 0u);
+      hist_sample<PASS, CP>(h, &nanc, pre, second, g, v1.w, (mk1 & 0xff000000u) != 0u);
     }
     if (blockIdx.x == 0 && threadIdx.x < 64) {   // up to 3 tail samples, one wave (ballots need the whole wave)
       const int64_t p = n4 * 4 + threadIdx.x;
       const bool on = p < a.npix;
       const float v = on ? x[p] : 0.0f;
-      hist_sample<PASS>(h, &nanc, pre, second, g, v, on && (!a.mask || a.mask[p] != 0));
+      hist_sample<PASS, CP>(h, &nanc, pre, second, g, v, on && (!a.mask || a.mask[p] != 0));
     }
   } else {
     const int64_t first = (int64_t)blockIdx.x * kSelThreads + (threadIdx.x & ~63);
@@ -189,12 +198,17 @@ __global__ __launch_bounds__(kSelThreads) void select_hist_kernel(const SelArgs 
       const int64_t p = base + (threadIdx.x & 63);
       const bool on = p < a.npix && (!a.mask || a.mask[p] != 0);
       const float v = on ? ld_stream(x + p * a.ps) : 0.0f;
-      hist_sample<PASS>(h, &nanc, pre, second, g, v, on);
+      hist_sample<PASS, CP>(h, &nanc, pre, second, g, v, on);
     }
   }
   __syncthreads();
   for (int i = threadIdx.x; i < NBINS; i += kSelThreads) {
-    if (h[i]) atomicAdd(&g[i], h[i]);
+    uint32_t cnt = h[i];
+    if (PASS == 1) {
+#pragma unroll
+      for (int cp = 1; cp < CP; ++cp) cnt += h[cp * kBins1 + i];
+    }
+    if (cnt) atomicAdd(&g[i], cnt);
     if (PASS > 1 && second && h[NBINS + i]) atomicAdd(&g[second * NBINS + i], h[NBINS + i]);
   }
   if (PASS == 1 && threadIdx.x == 0 && nanc) atomicAdd(&a.hist1[(size_t)c * kHist1 + kBins1], nanc);

@@ -566,6 +566,17 @@ def test_gram_f64_mfma_layout_exact(torch_gpu):
         Cd = torch.full((na, nb_), -1.0, dtype=torch.float64, device="cuda")
         nat.check(lib.hsr_gram_f64(_ptr(Ad), na, na, _ptr(Bd), nb_, nb_, n, _ptr(work), _ptr(Cd), nb_, _stream(torch)))
         np.testing.assert_array_equal(Cd.cpu().numpy(), A.T @ B)
+    # odd leading dimensions cannot be moved by 16-byte LDS-DMA: the register-operand kernel (and the tile-level mirror of the
+    # shared reduction) takes over, for two matrices and for one matrix with itself
+    for n, na, nb_, lda, ldb in ((300, 32, 48, 33, 49), (1029, 48, 80, 81, 81)):
+        A = rng.integers(-4, 5, (n, lda)).astype(np.float64)
+        B = A if lda == ldb and nb_ >= na else rng.integers(-4, 5, (n, ldb)).astype(np.float64)
+        Ad = torch.from_numpy(A).cuda()
+        Bd = Ad if B is A else torch.from_numpy(B).cuda()
+        work = torch.empty(max(1, lib.hsr_gram_work_bytes(na, nb_, n) // 8), dtype=torch.float64, device="cuda")
+        Cd = torch.full((na, nb_), -1.0, dtype=torch.float64, device="cuda")
+        nat.check(lib.hsr_gram_f64(_ptr(Ad), lda, na, _ptr(Bd), ldb, nb_, n, _ptr(work), _ptr(Cd), nb_, _stream(torch)))
+        np.testing.assert_array_equal(Cd.cpu().numpy(), A[:, :na].T @ B[:, :nb_])
     # the Gram of one matrix with itself takes the symmetric path (blocks below the diagonal mirrored):
     # [first na columns]^T [all columns], shapes that leave ragged 3 x 3 tile blocks on both axes
     # r03: a last strip of <= 32 columns becomes narrow blocks (96 x 32, chunks 5/2 as long), every workgroup splits its

@@ -6,6 +6,7 @@
 // separable bilinear upsampling.  GDAL's edge / nodata conventions are PARITY UNPINNED (rasterio absent).
 // Both kernels are trivially HBM-bound streams; images use (band_stride, pixel_stride) addressing.
 #include "hsr_common.h"
+#include "hsr_select_dev.h"
 
 namespace hsr {
 
@@ -183,6 +184,90 @@ __global__ __launch_bounds__(256) void bilinear_up_kernel(const float* __restric
   }
 }
 
+// The upsampler as a PRODUCER for what the reference's driver does next with its output (poly_regression.py:159 ff.: finite
+// mask, percentile stretch): while a workgroup still holds a pixel's values in registers it also writes the pixel's byte of
+// the "all bands finite" mask and counts the values into the pass-1 histogram of the exact percentile select
+// (csrc/hsr_select.hip; LDS histogram per channel, ballot-aggregated increments, integer atomics to the select's workspace at
+// the end).  That removes two full reads of the fine image - 604 MB each at 6144 x 6144 x 4 - from the chain upsample ->
+// valid_mask -> percentile_limits: r03 trace of match_pair, 145 us + 144 us of 1.7 ms.  Same values, same mask rule as
+// valid_mask_kernel (no positivity test), same bins as select_hist_rows4_kernel<1>: the results are bit-identical.
+constexpr int kUpHistRows = 32;      // rows per workgroup: the LDS histogram is zeroed and flushed once per 32 x 256 pixels
+
+template <bool IN4>
+__global__ __launch_bounds__(256) void bilinear_up_hist_kernel(const float* __restrict__ in, int64_t in_bs, int64_t in_ps,
+                                                               int Hc, int Wc, int f, int nb, float* __restrict__ out,
+                                                               uint8_t* __restrict__ mask_out, uint32_t* __restrict__ hist1) {
+  extern __shared__ uint32_t uh[];            // [nb][kBins1]
+  __shared__ int ry0[kUpHistRows], ry1[kUpHistRows];
+  __shared__ double rty[kUpHistRows];
+  const int Hf = Hc * f, Wf = Wc * f;
+  const int ybeg = blockIdx.y * kUpHistRows;
+  const int yend = ybeg + kUpHistRows < Hf ? ybeg + kUpHistRows : Hf;
+  for (int i = threadIdx.x; i < nb * kBins1; i += 256) uh[i] = 0u;
+  if (threadIdx.x < kUpHistRows && ybeg + (int)threadIdx.x < yend) {
+    int a, b;
+    double t;
+    up_tap(ybeg + threadIdx.x, f, Hc, &a, &b, &t);
+    ry0[threadIdx.x] = a;
+    ry1[threadIdx.x] = b;
+    rty[threadIdx.x] = t;
+  }
+  __syncthreads();
+  const int x = blockIdx.x * 256 + threadIdx.x;
+  const bool on = x < Wf;                     // no early exit: the histogram increments are wave-wide ballots
+  int x0, x1;
+  double tx;
+  up_tap(on ? x : Wf - 1, f, Wc, &x0, &x1, &tx);
+  const double ux = 1.0 - tx;
+  for (int y = ybeg; y < yend; ++y) {
+    const int y0 = ry0[y - ybeg], y1 = ry1[y - ybeg];
+    const double ty = rty[y - ybeg];
+    const double uy = 1.0 - ty;
+    const int64_t i00 = ((int64_t)y0 * Wc + x0) * in_ps, i01 = ((int64_t)y0 * Wc + x1) * in_ps;
+    const int64_t i10 = ((int64_t)y1 * Wc + x0) * in_ps, i11 = ((int64_t)y1 * Wc + x1) * in_ps;
+    float r[kUpMaxVec] = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (IN4) {
+      const float4 q00 = *reinterpret_cast<const float4*>(in + i00), q01 = *reinterpret_cast<const float4*>(in + i01);
+      const float4 q10 = *reinterpret_cast<const float4*>(in + i10), q11 = *reinterpret_cast<const float4*>(in + i11);
+      const float a00[4] = {q00.x, q00.y, q00.z, q00.w}, a01[4] = {q01.x, q01.y, q01.z, q01.w};
+      const float a10[4] = {q10.x, q10.y, q10.z, q10.w}, a11[4] = {q11.x, q11.y, q11.z, q11.w};
+#pragma unroll
+      for (int b = 0; b < kUpMaxVec; ++b) {
+        if (b < nb) {
+          const double v00 = a00[b], v01 = a01[b], v10 = a10[b], v11 = a11[b];
+          const double top = v00 * ux + v01 * tx, bot = v10 * ux + v11 * tx;
+          r[b] = (float)(top * uy + bot * ty);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int b = 0; b < kUpMaxVec; ++b) {
+        if (b < nb) {
+          const float* src = in + (size_t)b * in_bs;
+          const double v00 = src[i00], v01 = src[i01], v10 = src[i10], v11 = src[i11];
+          const double top = v00 * ux + v01 * tx, bot = v10 * ux + v11 * tx;
+          r[b] = (float)(top * uy + bot * ty);
+        }
+      }
+    }
+    bool fin = true;
+#pragma unroll
+    for (int b = 0; b < kUpMaxVec; ++b)
+      if (b < nb) fin = fin && finite_f32(r[b]);
+    if (on) {
+      const int64_t p = (int64_t)y * Wf + x;
+      st_stream(reinterpret_cast<float4*>(out + p * 4), make_float4(r[0], r[1], r[2], r[3]));
+      mask_out[p] = fin ? 1 : 0;
+    }
+#pragma unroll
+    for (int b = 0; b < kUpMaxVec; ++b)
+      if (b < nb) hist_add_wave<1>(uh + b * kBins1, (on && fin) ? (f32_key(r[b]) >> 21) : kNoBin);   // b < nb is launch-uniform
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < nb * kBins1; i += 256)
+    if (uh[i]) atomicAdd(&hist1[(size_t)(i / kBins1) * kHist1 + (i % kBins1)], uh[i]);
+}
+
 static int grid_for(int64_t n) {
   int64_t g = (n + 255) / 256;
   return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g));
@@ -243,5 +328,30 @@ extern "C" int hsr_bilinear_upsample(const float* in_dev, int64_t in_bs, int64_t
     hipLaunchKernelGGL((bilinear_up_kernel<false, false>), grid, dim3(256), 0, (hipStream_t)stream, in_dev, in_bs, in_ps, Hc, Wc,
                        factor, nb, out_dev, out_bs, out_ps);
   HSR_LAUNCH_CHECK("bilinear_up_kernel");
+  return HSR_OK;
+}
+
+extern "C" int hsr_bilinear_upsample_mask_hist(const float* in_dev, int64_t in_bs, int64_t in_ps, int32_t nb, int32_t Hc,
+                                               int32_t Wc, int32_t factor, float* out_dev, uint8_t* mask_out_dev,
+                                               void* percentile_work_dev, hsr_stream_t stream) {
+  HSR_REQUIRE(in_dev && out_dev && mask_out_dev && percentile_work_dev, HSR_ERR_INVALID, "hsr_bilinear_upsample_mask_hist: NULL pointer");
+  HSR_REQUIRE(nb >= 1 && nb <= kUpMaxVec && Hc >= 1 && Wc >= 1 && factor >= 1 && factor <= 64, HSR_ERR_UNSUPPORTED,
+              "hsr_bilinear_upsample_mask_hist: 1 <= nb <= 4 bands into band-last rows of 4 floats");
+  HSR_REQUIRE((((uintptr_t)out_dev) & 15) == 0 && (int64_t)Hc * factor * Wc * factor < ((int64_t)1 << 31), HSR_ERR_UNSUPPORTED,
+              "hsr_bilinear_upsample_mask_hist: output not 16-byte aligned or fine grid too large");
+  int64_t off = 0, cnt = 0;
+  int rc = hsr_percentile_hist_region(1, nb, &off, &cnt);
+  if (rc != HSR_OK) return rc;
+  uint32_t* hist1 = reinterpret_cast<uint32_t*>(static_cast<unsigned char*>(percentile_work_dev) + off);
+  const dim3 grid((unsigned)(((int64_t)Wc * factor + 255) / 256), (unsigned)(((int64_t)Hc * factor + kUpHistRows - 1) / kUpHistRows));
+  const size_t lds = (size_t)nb * kBins1 * sizeof(uint32_t);
+  const bool in4 = in_bs == 1 && in_ps == 4 && (((uintptr_t)in_dev) & 15) == 0;
+  if (in4)
+    hipLaunchKernelGGL(bilinear_up_hist_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, in_dev, in_bs, in_ps, Hc, Wc, factor,
+                       nb, out_dev, mask_out_dev, hist1);
+  else
+    hipLaunchKernelGGL(bilinear_up_hist_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, in_dev, in_bs, in_ps, Hc, Wc, factor,
+                       nb, out_dev, mask_out_dev, hist1);
+  HSR_LAUNCH_CHECK("bilinear_up_hist_kernel");
   return HSR_OK;
 }

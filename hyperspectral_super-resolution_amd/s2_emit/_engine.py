@@ -809,6 +809,33 @@ def bilinear_upsample(coarse, Hc: int, Wc: int, factor: int, layout: str = PLANA
     return out
 
 
+def bilinear_upsample_mask_limits(coarse, Hc: int, Wc: int, factor: int, pmin=2.0, pmax=98.0, nb: Optional[int] = None):
+    """bilinear_upsample (band-last rows of 4 floats) + valid_mask(all bands finite) + percentile_limits of the masked fine
+    image in one chain that reads the fine image twice instead of four times: the upsampling kernel writes the mask and
+    counts the first radix pass of the percentile select while it still holds the values (hsr_bilinear_upsample_mask_hist).
+    Returns (fine (npix, 4) float32, mask (npix,) uint8, lohi (nb, 2) float64) - the bits of the three separate operators."""
+    torch = nat.require_gpu()
+    lib = nat.load()
+    ibs, ips, n, npc = _img(coarse, PIXMAJOR, nb)
+    if npc != Hc * Wc or coarse.dtype != torch.float32 or n > 4:
+        raise ValueError("bilinear_upsample_mask_limits: coarse must be a float32 band-last image of Hc*Wc pixels, <= 4 bands")
+    npf = Hc * factor * Wc * factor
+    out = alloc_image(torch, n, npf, PIXMAJOR, coarse.device)
+    mask = torch.empty(npf, dtype=torch.uint8, device=coarse.device)
+    work = torch.empty(lib.hsr_percentile_work_bytes(n) // 8 + 1, dtype=torch.int64, device=coarse.device)
+    lohi = torch.empty((n, 2), dtype=torch.float64, device=coarse.device)
+    obs, ops, _, _ = _img(out, PIXMAJOR, n)
+    with _launch(coarse) as st:
+        nat.check(lib.hsr_percentile_begin(_ptr(work), n, st), "hsr_percentile_begin")
+        nat.check(lib.hsr_bilinear_upsample_mask_hist(_ptr(coarse), ibs, ips, n, Hc, Wc, factor, _ptr(out), _ptr(mask),
+                                                      _ptr(work), st), "hsr_bilinear_upsample_mask_hist")
+        nat.check(lib.hsr_percentile_scan(1, n, float(pmin), float(pmax), _ptr(work), _ptr(lohi), st), "hsr_percentile_scan")
+        for p in (2, 3):
+            nat.check(lib.hsr_percentile_hist(p, _ptr(out), obs, ops, _ptr(mask), npf, n, _ptr(work), st), "hsr_percentile_hist")
+            nat.check(lib.hsr_percentile_scan(p, n, float(pmin), float(pmax), _ptr(work), _ptr(lohi), st), "hsr_percentile_scan")
+    return out, mask, lohi
+
+
 def probe_read_bandwidth(nbytes: int = 1 << 30, iters: int = 10, device="cuda:0", mode: int = 0) -> float:
     """Measured pure-read HBM rate of this box in bytes/s (diagnostic for the roofline report).
     mode 0: K1's own load shape (non-temporal LDS-DMA, 72 KiB slabs, 512 persistent workgroups) - a ceiling for K1;

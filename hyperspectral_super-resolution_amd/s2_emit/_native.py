@@ -145,6 +145,7 @@ SIGNATURES = {
                                             _i32, _f32, _i32, _vp, _i64, _vp]),
     "hsr_block_mean": (C.c_int, [_vp, _i32, _i64, _i64, _i32, _i32, _i32, _i32, _f32, _vp, _i64, _i64, _vp]),
     "hsr_bilinear_upsample": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _i64, _i64, _vp]),
+    "hsr_bilinear_upsample_mask_hist": (C.c_int, [_vp, _i64, _i64, _i32, _i32, _i32, _i32, _vp, _vp, _vp, _vp]),
     "hsr_probe_read": (C.c_int, [_vp, _i64, _i32, _vp, _vp]),
     "hsr_step_plan_create": (C.c_int, [C.POINTER(StepDesc), C.POINTER(_vp)]),
     "hsr_step_plan_destroy": (None, [_vp]),

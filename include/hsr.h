@@ -477,6 +477,14 @@ int hsr_block_mean(const void* in_dev, int32_t in_dtype, int64_t in_bs, int64_t 
                    float* out_dev, int64_t out_bs, int64_t out_ps, hsr_stream_t stream);
 int hsr_bilinear_upsample(const float* in_dev, int64_t in_bs, int64_t in_ps, int32_t nb, int32_t Hc, int32_t Wc,
                           int32_t factor, float* out_dev, int64_t out_bs, int64_t out_ps, hsr_stream_t stream);
+/* The upsampler as a producer for the next two steps of the reference's driver (poly_regression.py:159 ff.): besides the fine
+ * image - band-last rows of 4 floats, nb <= 4, out_dev 16-byte aligned - it writes the "all bands finite" mask of every fine
+ * pixel (what hsr_valid_mask gives for this image with pos_band = -1) and adds the pass-1 histogram of the masked values
+ * to the percentile workspace (after hsr_percentile_begin; continue with hsr_percentile_scan(1), _hist(2), ...), i.e. the
+ * fine image is not read back for either.  Bit-identical to hsr_bilinear_upsample + hsr_valid_mask + hsr_percentile_hist(1). */
+int hsr_bilinear_upsample_mask_hist(const float* in_dev, int64_t in_bs, int64_t in_ps, int32_t nb, int32_t Hc, int32_t Wc,
+                                    int32_t factor, float* out_dev, uint8_t* mask_out_dev, void* percentile_work_dev,
+                                    hsr_stream_t stream);
 
 /* ---- step executor (ABI 4): the hot path of one tile as PREPARED launches, and the one-tile-deep pipeline -------------
  * A plan stores every argument of K1+K2 (hsr_srf_integrate_moments[_u16]), of the slot reduction + solve

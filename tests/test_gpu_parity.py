@@ -729,6 +729,34 @@ def test_poly_ridge_golden_g11_notebook_shapes(torch_gpu):
 # ---------------------------------------------------------------------------------------------
 # f1 resamplers and the reference-ordered driver (a7)
 # ---------------------------------------------------------------------------------------------
+def test_upsample_mask_limits_in_one_chain_bit_identical(torch_gpu):
+    """hsr_bilinear_upsample_mask_hist (r03): the upsampler also writes the finite mask and counts the first radix pass of the
+    percentile select.  Fine image, mask and limits must carry the bits of bilinear_upsample + valid_mask + percentile_limits:
+    ragged sizes (a last column block and a last row block that are not full), 1-4 bands, NaN / Inf pixels in the coarse image
+    (they spread to their fine neighbours), a coarse image that is all NaN (empty mask -> NaN limits), 16-byte rows or not."""
+    torch = torch_gpu
+    from s2_emit import _engine as eng, _native as nat
+    rng = np.random.default_rng(77)
+    for Hc, Wc, f, nb in ((37, 45, 6, 3), (64, 64, 6, 3), (9, 130, 3, 4), (50, 7, 10, 1), (33, 33, 2, 2)):
+        row = eng.padded_row(nb)
+        c = np.zeros((Hc * Wc, row), np.float32)
+        c[:, :nb] = (rng.random((Hc * Wc, nb)) ** 2).astype(np.float32)
+        c[5, 0] = np.nan
+        c[Hc * Wc // 2, nb - 1] = np.inf
+        c[-1, 0] = -np.inf
+        for variant in ("data", "allnan"):
+            cd = torch.from_numpy(c if variant == "data" else np.full_like(c, np.nan)).cuda()
+            fine, mask, lohi = eng.bilinear_upsample_mask_limits(cd, Hc, Wc, f, 2, 98, nb=nb)
+            ref_f = eng.bilinear_upsample(cd, Hc, Wc, f, layout=nat.PIXMAJOR, nb=nb)
+            ref_m = eng.valid_mask(ref_f, -1, None, None, nat.PIXMAJOR, nbx=nb)
+            ref_l = eng.percentile_limits(ref_f, ref_m, 2, 98, nat.PIXMAJOR, nb=nb)
+            assert torch.equal(fine.view(torch.int32)[:, :nb], ref_f.view(torch.int32)[:, :nb]), (Hc, Wc, f, nb, variant)
+            assert torch.equal(mask, ref_m), (Hc, Wc, f, nb, variant)
+            assert torch.equal(lohi.view(torch.int64), ref_l.view(torch.int64)), (Hc, Wc, f, nb, variant, lohi, ref_l)
+            if variant == "data":
+                assert 0 < int(mask.sum()) < mask.numel()
+
+
 def test_resamplers_vs_oracle(torch_gpu):
     torch = torch_gpu
     from s2_emit import _engine as eng

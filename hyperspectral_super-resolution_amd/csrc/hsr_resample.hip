@@ -191,6 +191,9 @@ __global__ __launch_bounds__(256) void bilinear_up_kernel(const float* __restric
 // the end).  That removes two full reads of the fine image - 604 MB each at 6144 x 6144 x 4 - from the chain upsample ->
 // valid_mask -> percentile_limits: r03 trace of match_pair, 145 us + 144 us of 1.7 ms.  Same values, same mask rule as
 // valid_mask_kernel (no positivity test), same bins as select_hist_rows4_kernel<1>: the results are bit-identical.
+// (Also built and measured: the REST of that chain without the fine image at all - the select's passes 2 and 3 and the
+// stretch + polynomial each recomputing the fine values from the coarse image instead of reading them back - bit-identical
+// and slower, 1.81 ms against 1.53 ms for match_pair: four float64 interpolations per sample cost more than one 604 MB read.)
 constexpr int kUpHistRows = 32;      // rows per workgroup: the LDS histogram is zeroed and flushed once per 32 x 256 pixels
 
 template <bool IN4>

@@ -43,5 +43,64 @@ __device__ __forceinline__ void hist_add_wave(uint32_t* h, uint32_t bin) {
   if (bin != kNoBin) atomicAdd(&h[(COPIES > 1 ? (lane & (COPIES - 1)) * kBins1 : 0) + bin], 1u);
 }
 
+// ---- state of a select in progress and the increments of passes 2 / 3 (shared with the producer kernels of hsr_resample.hip)
+struct SelState {      // one per channel
+  uint32_t n;          // masked sample count
+  uint32_t nan_count;  // masked NaNs (copied from the pass-1 histogram tail by scan 1)
+  uint32_t prefix[kQ]; // key prefix fixed so far, per rank query
+  uint32_t rem[kQ];    // rank remaining inside that prefix
+  double gamma[2];     // interpolation weights of (pmin, pmax)
+};
+
+// The prev / next ranks of a percentile nearly always share their prefix (and on short-range data both percentiles do): a
+// query whose prefix equals its predecessor's is not histogrammed a second time - its slot is parked on a key no sample has -
+// and the scan reads the predecessor's histogram for it (select_scan_kernel).  r03 trace: pass 2 was the slowest of the three
+// (168 us against 142 / 88 us on three 6144 x 6144 planes), every matching sample paying two LDS atomics.
+constexpr uint32_t kNoPrefix = 0xffffffffu;      // prefixes have 11 or 22 bits
+__device__ __forceinline__ void dedupe_prefixes(uint32_t (&pre)[kQ]) {
+  const uint32_t p0 = pre[0], p1 = pre[1], p2 = pre[2], p3 = pre[3];
+  pre[1] = p1 == p0 ? kNoPrefix : p1;
+  pre[2] = p2 == p1 ? kNoPrefix : p2;
+  pre[3] = p3 == p2 ? kNoPrefix : p3;
+}
+
+// LDS holds the histograms of TWO queries in passes 2 and 3 (kLdsQ): query 0 and the next query with a prefix of its own
+// (`second`, 1..3; 0 = none).  A third / fourth distinct prefix - the prev / next ranks of a percentile straddling a bin
+// boundary - is rare and counts straight into the global histogram.  With all four in LDS pass 2 needed 32 KB per channel
+// (96 KB for the three channels of the band-last kernel: one workgroup per CU) and was the slowest pass for lack of waves in
+// flight, not for its atomics.
+constexpr int kLdsQ = 2;
+#ifndef HSR_SEL_COPIES
+#define HSR_SEL_COPIES 4
+#endif
+constexpr int kPass1Copies = HSR_SEL_COPIES;   // pass-1 histogram copies of select_hist_kernel (planes)
+template <int PASS, int COPIES = 1>
+__device__ __forceinline__ void hist_sample(uint32_t* h, uint32_t* nanc, const uint32_t (&pre)[kQ], int second, uint32_t* g,
+                                            float v, bool use) {
+  const uint32_t k = f32_key(v);
+  if (PASS == 1) {
+    hist_add_wave<COPIES>(h, use ? (k >> 21) : kNoBin);
+    if (use && v != v) atomicAdd(nanc, 1u);
+  } else {
+    constexpr int NBINS = PASS == 2 ? kBins2 : kBins3;
+    const uint32_t key = PASS == 2 ? (k >> 21) : (k >> 10);
+    const uint32_t bin = PASS == 2 ? ((k >> 10) & 2047u) : (k & 1023u);
+    if (use) {
+      if (key == pre[0]) atomicAdd(&h[bin], 1u);
+#pragma unroll
+      for (int q = 1; q < kQ; ++q)
+        if (key == pre[q]) {
+          if (q == second) atomicAdd(&h[NBINS + bin], 1u);
+          else atomicAdd(&g[q * NBINS + bin], 1u);
+        }
+    }
+  }
+}
+
+// first query after 0 whose prefix is its own (after dedupe_prefixes); 0 if there is none
+__device__ __forceinline__ int second_query(const uint32_t (&pre)[kQ]) {
+  return pre[1] != kNoPrefix ? 1 : (pre[2] != kNoPrefix ? 2 : (pre[3] != kNoPrefix ? 3 : 0));
+}
+
 }  // namespace hsr
 #endif

@@ -263,7 +263,10 @@ extern "C" int hsr_pipeline_submit(hsr_pipeline* pl, const void* cube_dev, const
     }
     hsr_step_plan* last = (tail && pl->n >= 1) ? pl->slot[(pl->n + 2) % 3] : nullptr;     // tile n - 1: its fit rides in this launch's tail
     const int grid = hsr_partial_slots(p->d.npix, &p->d.opts);
-    if (last && last->pending && !last->fitted && grid > 0) {
+    // (every workgroup of the launch draws ONE ticket and tickets 0 .. nb-1 fit one band each: a launch of fewer workgroups
+    // than bands - a tile of fewer than nb 64-pixel groups - cannot carry the fit; that tile's fit runs as its own launch
+    // below, when its K3 comes up.  Found by tools/dbg/stress_fused.py: a 2 x 158 tile with 7 bands kept two stale rows.)
+    if (last && last->pending && !last->fitted && grid >= p->d.nb) {
       job.fit_partials_dev = last->d.partials_dev;
       job.fit_slots = last->slots;
       job.fit_moments_dev = last->d.moments_dev;
@@ -271,6 +274,12 @@ extern "C" int hsr_pipeline_submit(hsr_pipeline* pl, const void* cube_dev, const
       job.fit_min_count = last->d.min_count;
       job.fit_counter_dev = pl->counter;
       job.fit_ticket_base = pl->tickets;
+    }
+    if (carry && tail && !old->fitted) {         // its fit did not ride in the previous launch (see above): a launch of its own
+      rc = hsr_moments_reduce_solve(old->d.partials_dev, old->slots, old->d.nb, old->d.deg, old->d.min_count, old->d.moments_dev,
+                                    old->d.coeffs_dev, main);
+      if (rc != HSR_OK) return rc;
+      old->fitted = true;
     }
     if (k1_begin_event) rc = hsr::check_hip(hipEventRecord((hipEvent_t)k1_begin_event, main), "hsr_pipeline: record K1 begin");
     if (rc != HSR_OK) return rc;

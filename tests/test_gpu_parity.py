@@ -1751,7 +1751,10 @@ def test_fused_pipeline_k3_inside_k1_launch_bit_identical(torch_gpu):
     srf13 = onp.synthetic_srf()
     g = torch.Generator(device="cuda")
     g.manual_seed(11)
-    for names_sel, gm, H, W in ((None, good, 70, 61), (("B4", "B3", "B2"), good, 64, 64), (None, None, 33, 97)):
+    # (the last two shapes: fewer 64-pixel groups than bands - such a launch cannot carry the previous tile's fit, one
+    # workgroup per band, and the executor runs that fit as a launch of its own; found by tools/dbg/stress_fused.py)
+    for names_sel, gm, H, W in ((None, good, 70, 61), (("B4", "B3", "B2"), good, 64, 64), (None, None, 33, 97),
+                                (None, good, 2, 158), (None, None, 1, 70)):
         srf = srf13 if names_sel is None else {k: srf13[k] for k in names_sel}
         nb = eng.build_srf_table(w, srf, gm).nb
         row = eng.padded_row(nb)
@@ -1786,6 +1789,17 @@ def test_fused_pipeline_k3_inside_k1_launch_bit_identical(torch_gpu):
     # uint16 tiles (r03, hsr_srf_integrate_moments_u16_apply): the ring kernel carries the older tile's K3 and the previous
     # tile's fit as well - same bits as step(), exact and fast arithmetic, masks, nodata; a cube the ring kernel cannot
     # load (2-byte aligned only) quietly takes the two-slot pipeline
+    tiny = [eng.tile_encode_u16(torch.rand((3, 90, 285), generator=g, device="cuda") * 0.6) for _ in range(2)]   # 5 groups, 12 bands
+    rt = [torch.rand((3, 90, 12), generator=g, device="cuda") for _ in range(2)]
+    pt = SpectralFusion(w, srf13, good, deg=2, min_valid=0.0, min_count=5, fuse_apply=True)
+    outs = [pt.submit(tiny[i % 2], rt[i % 2]) for i in range(4)]
+    outs = [tuple(t.clone() for t in (o.matched, o.coeffs)) for o in outs if o is not None] + [(o.matched.clone(), o.coeffs.clone()) for o in pt.drain()]
+    assert pt._pipe["fused"] and len(outs) == 4
+    rf = SpectralFusion(w, srf13, good, deg=2, min_valid=0.0, min_count=5)
+    for i, (mt, co) in enumerate(outs):
+        want = rf.step(tiny[i % 2], rt[i % 2], reuse_buffers=False)
+        assert torch.equal(mt.view(torch.int32), want.matched.view(torch.int32)) and torch.equal(co.view(torch.int64), want.coeffs.view(torch.int64)), i
+    pt.close()
     raw = [eng.tile_encode_u16(torch.rand((40, 64, 285), generator=g, device="cuda") * 0.6) for _ in range(3)]
     raw[1].view(torch.int16)[3, 5, 100] = -1                                          # 65535 = nodata
     raw[2].view(torch.int16)[:, 7, :] = -1

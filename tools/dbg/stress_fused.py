@@ -1,5 +1,6 @@
-"""Randomised tiles through the fused one-kernel-per-tile pipeline (float32 and uint16 cubes): every tile must carry the bits
-of its own step().  python tools/dbg/stress_fused.py [seed] [cases]"""
+"""Randomised tiles through the fused one-kernel-per-tile pipeline, the two-slot pipeline and the prepared step() (float32 and
+uint16 cubes): every tile must carry the bits of the operator-by-operator path (step(reuse_buffers=False)).
+python tools/dbg/stress_fused.py [seed] [cases]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "hyperspectral_super-resolution_amd"))
@@ -15,7 +16,8 @@ prob = device_problem(8, 8, 285, deg=3, seed=seed, device=torch.device("cuda", 0
 names = list(prob.srf.keys())
 bad = 0
 for k in range(cases):
-    H, W = int(rng.integers(1, 300)), int(rng.integers(1, 300))
+    big = len(sys.argv) > 3 and sys.argv[3] == "big"
+    H, W = (int(rng.integers(300, 1100)), int(rng.integers(300, 1100))) if big else (int(rng.integers(1, 300)), int(rng.integers(1, 300)))
     npix = H * W
     sel = [None, ("B4", "B3", "B2"), tuple(names[:7])][int(rng.integers(0, 3))]
     srf = prob.srf if sel is None else {n: prob.srf[n] for n in sel}
@@ -25,7 +27,8 @@ for k in range(cases):
     kw = dict(deg=deg, min_valid=0.0, min_count=int(rng.choice([0, 5, 50])), apply_mask=bool(rng.random() < 0.5), clip=bool(rng.random() < 0.7),
               u16_fast=bool(u16 and rng.random() < 0.5))
     ref = SpectralFusion(prob.emit_w, srf, gm, **kw)
-    pipe = SpectralFusion(prob.emit_w, srf, gm, fuse_apply=True, **kw)
+    mode = int(rng.integers(0, 3))             # 0: fused pipeline, 1: two-slot pipeline, 2: prepared step()
+    pipe = SpectralFusion(prob.emit_w, srf, gm, fuse_apply=(mode == 0), **kw)
     nb = ref.table.nb
     row = eng.padded_row(nb)
     cubes = []
@@ -39,10 +42,11 @@ for k in range(cases):
     seq = [(cubes[i % 3], reals[(i + 1) % 3], masks[i % 4]) for i in range(int(rng.integers(1, 8)))]
     got = []
     for c, r, m in seq:
-        o = pipe.submit(c, r, m)
+        o = pipe.step(c, r, m) if mode == 2 else pipe.submit(c, r, m)
         if o is not None:
             got.append(tuple(t.clone() for t in (o.pseudo, o.matched, o.moments, o.coeffs)))
-    got += [tuple(t.clone() for t in (o.pseudo, o.matched, o.moments, o.coeffs)) for o in pipe.drain()]
+    if mode != 2:
+        got += [tuple(t.clone() for t in (o.pseudo, o.matched, o.moments, o.coeffs)) for o in pipe.drain()]
     ok = len(got) == len(seq)
     for (c, r, m), gt in zip(seq, got):
         w = ref.step(c, r, m, reuse_buffers=False)
@@ -50,7 +54,7 @@ for k in range(cases):
             and torch.equal(gt[2].view(torch.int64), w.moments.view(torch.int64)) and torch.equal(gt[3].view(torch.int64), w.coeffs.view(torch.int64))
     if not ok:
         bad += 1
-        print("MISMATCH", H, W, nb, deg, u16, kw, len(seq), pipe._pipe["fused"], flush=True)
+        print("MISMATCH", H, W, nb, deg, u16, kw, len(seq), mode, flush=True)
     pipe.close()
     ref.close()
 print("fused pipeline stress done; failures:", bad, flush=True)

@@ -617,6 +617,17 @@ def moments_reduce_solve(ws: MomentWorkspace, min_count: int):
     return ws.moments, ws.coeffs
 
 
+def reduce_slots(partials, slots: int, nb: int, deg: int, out=None):
+    """hsr_moments_reduce over any [slot][band][moment] float64 array -> (nb, 3 deg + 2) moments: the fixed-order sum (lane
+    l adds slots l, l + 64, ...; butterfly over the 64 lane sums) that every form of a mosaic's global fit uses."""
+    torch = nat.require_gpu()
+    lib = nat.load()
+    mo = torch.empty((nb, 3 * deg + 2), dtype=torch.float64, device=partials.device) if out is None else out
+    with _launch(partials) as st:
+        nat.check(lib.hsr_moments_reduce(_ptr(partials), int(slots), int(nb), int(deg), _ptr(mo), st), "hsr_moments_reduce")
+    return mo
+
+
 def reduce_solve_slots(partials, slots: int, ws: MomentWorkspace, min_count: int, moments=None, coeffs=None):
     """hsr_moments_reduce_solve over any [slot][band][moment] float64 array (e.g. the per-tile moments of a mosaic, one
     "slot" per tile) -> (moments, coeffs): the given tensors, or the workspace's."""

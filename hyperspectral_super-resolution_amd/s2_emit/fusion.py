@@ -512,7 +512,7 @@ class SpectralFusion:
         band_last = all(self._real_image(r, c.numel() // c.shape[-1])[1] == nat.PIXMAJOR for c, r in tiles)
         if resident and band_last and self.layout == nat.PIXMAJOR and len(tiles) <= 64:
             return self._fuse_mosaic_batched(tiles, masks, k1_events)
-        total = None
+        moms = []
         pseudos = []
         for ti, ((cube, real), mask) in enumerate(zip(tiles, masks)):
             npix = cube.numel() // cube.shape[-1]
@@ -521,8 +521,11 @@ class SpectralFusion:
                                                     self.min_valid, out=None, events=k1_events if ti == 0 else None,
                                                     reduce=True, layout=self.layout,
                                                     real_layout=real_layout, scale=self.tile_scale, nodata=self.tile_nodata, opts=self.opts)
-            total = mom.clone() if total is None else total + mom          # tile order: a fixed summation order
+            moms.append(mom.clone())
             pseudos.append(pseudo)
+        # the sum over the tiles by the same fixed-order reduction as the resident form (one "slot" per tile), so that both
+        # forms of a mosaic give the same bits (a sequential sum here differed from it in the last bit: tools/dbg/stress_mosaic.py)
+        total = eng.reduce_slots(torch.stack(moms), len(moms), self.table.nb, self.deg)
         if self._exchanges():
             total, coeffs = exchange_moments(total, self._solve, self.group, self.coeff_sync)
             coeffs = coeffs.clone()                    # _solve writes into the plan's workspace

@@ -7,6 +7,8 @@ Run on an MI355X with ``pytest -m gpu``.  Tolerances (stated where used):
   * coefficients from moments vs np.polyfit: rel 1e-7 (deg <= 3), 1e-6 (deg 4)
   * end-to-end matched planes: 1e-4 relative (the north-star tolerance), observed ~1e-6
 """
+import os
+import sys
 import warnings
 
 import numpy as np
@@ -2248,3 +2250,18 @@ def test_step_batch_other_band_counts(torch_gpu):
             assert torch.equal(o.moments.view(torch.int64), ti.moments.view(torch.int64)), (nb, i)
             assert torch.equal(o.coeffs.view(torch.int64), ti.coeffs.view(torch.int64)), (nb, i)
             assert torch.equal(o.matched.view(torch.int32), ti.matched.view(torch.int32)), (nb, i)
+
+
+@pytest.mark.parametrize("script,args", [("stress_fused.py", ["7", "12"]), ("stress_batch.py", ["7", "4"]), ("stress_mosaic.py", ["7", "5"]),
+                                         ("stress_r03.py", ["7", "20"]), ("stress_upsample.py", ["7", "15"]), ("stress_k1.py", ["7", "15"])])
+def test_randomised_shapes_through_the_round3_paths(torch_gpu, script, args):
+    """A short, seeded run of the randomised stress tools (tools/dbg/stress_*.py; one child process each): random tile shapes,
+    band sets, degrees, masks and cube types through the fused / two-slot pipelines and the prepared step(), step_batch,
+    both forms of fuse_mosaic, the rebuilt Gram / Cholesky / percentile / predict kernels, the producer upsampler and K1 -
+    against the operator-by-operator path or NumPy.  Longer runs of the same tools found the two defects fixed in round 3
+    (a launch of fewer workgroups than bands carrying the tail fit; the last-bit difference between the two mosaic forms)."""
+    import subprocess
+    from conftest import ROOT
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "dbg", script)] + args, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, (script, r.stdout[-1500:], r.stderr[-1500:])
+    assert "failures: 0" in r.stdout

@@ -2253,7 +2253,8 @@ def test_step_batch_other_band_counts(torch_gpu):
 
 
 @pytest.mark.parametrize("script,args", [("stress_fused.py", ["7", "12"]), ("stress_batch.py", ["7", "4"]), ("stress_mosaic.py", ["7", "5"]),
-                                         ("stress_r03.py", ["7", "20"]), ("stress_upsample.py", ["7", "15"]), ("stress_k1.py", ["7", "15"])])
+                                         ("stress_r03.py", ["7", "20"]), ("stress_upsample.py", ["7", "15"]), ("stress_k1.py", ["7", "15"]),
+                                         ("stress_stream.py", ["7", "5"])])
 def test_randomised_shapes_through_the_round3_paths(torch_gpu, script, args):
     """A short, seeded run of the randomised stress tools (tools/dbg/stress_*.py; one child process each): random tile shapes,
     band sets, degrees, masks and cube types through the fused / two-slot pipelines and the prepared step(), step_batch,

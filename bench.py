@@ -541,6 +541,7 @@ def main(argv=None):
                 "kernel_ms_after_region": round(sum(extra) / max(1, len(extra)), 4) if extra else None,
                 "agrees_with": "profiles/r03_kernel_stats.csv (rocprofv3 --kernel-trace --stats of this command): average duration of "
                                "the srf_kernel<..., true> (fused pipeline) / srf_kernel / srf_u16_ring_kernel row",
+                "frac_cube_bytes_only": round(cube_bytes * ntl / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),     # SURVEY 8(d)'s headline figure (the cube read once) over this launch's time
                 "step_frac_of_peak": round(ntl * cube_bytes * args.steps / dt_max / 1e9 / HBM_PEAK_GBS, 4),
                 "total_fraction": round(ntl * full_bytes * args.steps / dt_max / 1e9 / HBM_PEAK_GBS, 4),
                 "total_bytes_per_step": ntl * full_bytes}

@@ -1814,6 +1814,10 @@ static int srf_moments_entry(const char* who, const void* cube_dev, bool u16, fl
     if (job->fit_partials_dev) {
       HSR_REQUIRE(job->fit_moments_dev && job->fit_coeffs_dev && job->fit_counter_dev && job->fit_slots >= 1 && job->fit_min_count >= 0,
                   HSR_ERR_INVALID, "%s: incomplete tail fit in hsr_apply_job", who);
+      // one ticket per workgroup, one band per ticket: a launch of fewer workgroups than bands would leave bands unfitted
+      HSR_REQUIRE(hsr_partial_slots(npix, opts) >= nb, HSR_ERR_UNSUPPORTED,
+                  "%s: a launch of %d workgroups cannot carry the tail fit of %d bands (hsr_partial_slots(npix) >= nb needed); run "
+                  "hsr_moments_reduce_solve for that tile instead", who, hsr_partial_slots(npix, opts), nb);
       a.lazy_partials = job->fit_partials_dev;
       a.lazy_slots = job->fit_slots;
       a.lazy_min_count = (long long)job->fit_min_count;

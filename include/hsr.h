@@ -134,7 +134,8 @@ typedef struct hsr_apply_job {
   double* fit_coeffs_dev;        /* own, no side stream.  x_dev may be NULL when only the tail fit rides.                           */
   int64_t fit_min_count;
   unsigned int* fit_counter_dev; /* running ticket counter (device, zero before the first launch that uses it)                      */
-  unsigned int fit_ticket_base;  /* = number of workgroups of all earlier launches that used the counter (mod 2^32)                */
+  unsigned int fit_ticket_base;  /* = number of workgroups of all earlier launches that used the counter (mod 2^32).  The launch   */
+                                 /* must have >= nb workgroups (hsr_partial_slots(npix, opts) >= nb), else HSR_ERR_UNSUPPORTED         */
   int32_t reserved;
 } hsr_apply_job;
 int hsr_srf_integrate_moments_apply(const float* cube_dev, int64_t npix, int32_t B,

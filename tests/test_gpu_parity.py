@@ -2252,7 +2252,7 @@ def test_step_batch_other_band_counts(torch_gpu):
             assert torch.equal(o.matched.view(torch.int32), ti.matched.view(torch.int32)), (nb, i)
 
 
-@pytest.mark.parametrize("script,args", [("stress_fused.py", ["7", "12"]), ("stress_batch.py", ["7", "4"]), ("stress_mosaic.py", ["7", "5"]),
+@pytest.mark.parametrize("script,args", [("stress_fused.py", ["7", "12"]), ("stress_fused.py", ["8", "20", "tiny"]), ("stress_batch.py", ["7", "4"]), ("stress_mosaic.py", ["7", "5"]),
                                          ("stress_r03.py", ["7", "20"]), ("stress_upsample.py", ["7", "15"]), ("stress_k1.py", ["7", "15"]),
                                          ("stress_stream.py", ["7", "5"])])
 def test_randomised_shapes_through_the_round3_paths(torch_gpu, script, args):

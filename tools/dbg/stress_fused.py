@@ -1,6 +1,6 @@
 """Randomised tiles through the fused one-kernel-per-tile pipeline, the two-slot pipeline and the prepared step() (float32 and
 uint16 cubes): every tile must carry the bits of the operator-by-operator path (step(reuse_buffers=False)).
-python tools/dbg/stress_fused.py [seed] [cases]"""
+python tools/dbg/stress_fused.py [seed] [cases] [tiny | mid | big]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.join(ROOT, "hyperspectral_super-resolution_amd"))
@@ -16,8 +16,9 @@ prob = device_problem(8, 8, 285, deg=3, seed=seed, device=torch.device("cuda", 0
 names = list(prob.srf.keys())
 bad = 0
 for k in range(cases):
-    big = len(sys.argv) > 3 and sys.argv[3] == "big"
-    H, W = (int(rng.integers(300, 1100)), int(rng.integers(300, 1100))) if big else (int(rng.integers(1, 300)), int(rng.integers(1, 300)))
+    size = sys.argv[3] if len(sys.argv) > 3 else "mid"       # tiny: 1-40 pixel edges, mid: 1-300, big: 300-1100
+    lo, hi = {"tiny": (1, 40), "mid": (1, 300), "big": (300, 1100)}[size]
+    H, W = int(rng.integers(lo, hi)), int(rng.integers(lo, hi))
     npix = H * W
     sel = [None, ("B4", "B3", "B2"), tuple(names[:7])][int(rng.integers(0, 3))]
     srf = prob.srf if sel is None else {n: prob.srf[n] for n in sel}

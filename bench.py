@@ -105,6 +105,9 @@ def parse_args(argv=None):
     ap.add_argument("--event-every", type=int, default=4,
                     help="bracket the K1+K2 kernel with HIP events on every n-th timed step (each pair of event "
                          "records costs ~12 us of launch gap, so not on every step)")
+    ap.add_argument("--launcher", action="store_true",
+                    help="take the parent -> torchrun -> rank path also at N = 1 (with --force-exchange the child then creates its "
+                         "one-rank RCCL group exactly as the ranks of an N > 1 run do): rehearses the launcher on a one-GPU box")
     ap.add_argument("--dist-timeout", type=float, default=180.0,
                     help="seconds a rank waits in init_process_group or in any collective before the run is aborted (N > 1)")
     ap.add_argument("--deadline", type=float, default=900.0,
@@ -123,6 +126,38 @@ def _free_port() -> int:
         return s.getsockname()[1]
 
 
+def visible_gpu_count() -> int:
+    """GPUs this node shows, counted WITHOUT loading HIP / HSA in this process: the self-launching parent goes on to start
+    torchrun (fork + exec), which a process that has initialised the GPU must not do on this pool - and
+    torch.cuda.device_count() only stays clear of hipGetDeviceCount while its amdsmi discovery works.  KFD's topology lists
+    every node; GPU nodes are the ones with SIMDs.  HIP_/ROCR_/CUDA_VISIBLE_DEVICES narrow the set as they do for the runtime.
+    Returns 0 without a KFD driver, -1 if the topology is there but cannot be read (the ranks' own check then decides)."""
+    base = "/sys/class/kfd/kfd/topology/nodes"
+    if not os.path.isdir("/sys/class/kfd"):            # no amdgpu / KFD driver on this machine at all
+        return 0
+    try:
+        n = 0
+        for node in os.listdir(base):
+            with open(os.path.join(base, node, "properties")) as f:
+                props = dict(ln.split(None, 1) for ln in f.read().splitlines() if " " in ln)
+            if int(props.get("simd_count", "0")) > 0:
+                n += 1
+    except (OSError, ValueError):
+        return -1
+    try:                                               # a container is usually handed only its own render nodes
+        rn = len([d for d in os.listdir("/dev/dri") if d.startswith("renderD")])
+        if rn > 0:
+            n = min(n, rn)
+    except OSError:
+        pass
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        v = os.environ.get(var)
+        if v is not None:
+            ids = [x for x in v.split(",") if x.strip() != ""]
+            n = min(n, len(ids))
+    return n
+
+
 def self_launch(args, argv) -> int:
     """`python bench.py --gpus N` with no WORLD_SIZE in the environment: this process - which never touches the GPU and
     replaces nothing by exec - starts `python -m torch.distributed.run --nproc-per-node N bench.py <same arguments>` as a
@@ -130,14 +165,13 @@ def self_launch(args, argv) -> int:
     failed, if the job outlived its deadline, or if no line was produced)."""
     import subprocess
     if not args.same_device:
-        import torch                                   # device_count() does not initialise the GPU
-        ndev = torch.cuda.device_count()
-        if args.gpus > ndev:
+        ndev = visible_gpu_count()                     # sysfs only: this process never loads HIP
+        if 0 <= ndev < args.gpus:
             sys.stderr.write(f"[bench] --gpus {args.gpus} needs {args.gpus} visible GPUs on this node, {ndev} found "
                              f"(rehearse the control flow of more ranks than GPUs with --backend gloo --same-device)\n")
             return 2
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + [a for a in argv if a != "--launcher"]
     limit = args.deadline + 60.0 if args.deadline > 0 else None
     proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, text=True, start_new_session=True)
     try:
@@ -292,7 +326,7 @@ def cpu_baseline(args, pool, nworkers, cube_host, real_host, gpu_pseudo, gpu_mat
 def main(argv=None):
     argv = list(sys.argv[1:] if argv is None else argv)
     args = parse_args(argv)
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+    if (args.gpus > 1 or args.launcher) and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args, argv))
     real_stdout = _claim_stdout()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -322,8 +356,8 @@ def main(argv=None):
     ndev = torch.cuda.device_count()           # does not initialise the GPU
     if local_rank >= ndev:
         raise SystemExit(f"[bench] rank {rank}: local rank {local_rank} needs cuda:{local_rank}, but only {ndev} device(s) are visible. "
-                         f"--gpus N needs N visible GPUs on this node (rehearse the control flow of more ranks than GPUs with "
-                         f"--backend gloo --same-device).")
+                         f"--gpus {args.gpus} needs {args.gpus} visible GPUs on this node, {ndev} found (rehearse the control flow of more "
+                         f"ranks than GPUs with --backend gloo --same-device).")
     if strong and (args.height % world or args.tiles_per_gpu != 1):
         raise SystemExit(f"--scaling strong needs --height ({args.height}) divisible by the number of ranks ({world}) and one tile per GPU")
     if strong and world > 1 and args.coeff_sync == "local":
@@ -341,7 +375,10 @@ def main(argv=None):
             opts = dist.ProcessGroupNCCL.Options()
             opts.is_high_priority_stream = True
             return opts
-        if args.force_exchange:
+        if args.force_exchange and "MASTER_PORT" in os.environ and "WORLD_SIZE" in os.environ:
+            # started by the launcher (--launcher): the rendezvous the ranks of an N > 1 run use
+            dist.init_process_group("nccl", device_id=device, pg_options=rccl_options(), timeout=dist_timeout)
+        elif args.force_exchange:
             dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{_free_port()}", rank=0, world_size=1, device_id=device,
                                     pg_options=rccl_options(), timeout=dist_timeout)
         elif args.backend == "nccl":
@@ -365,31 +402,44 @@ def main(argv=None):
     probs = [device_problem(H, W, B, deg=args.deg, seed=rank * ntl + i, device=device) for i in range(ntl)]
     prob = probs[0]
     exchanging = world > 1 or args.force_exchange
-    want_fused = ntl == 1 and not exchanging and not args.fused_fit and args.pipeline in ("fused", "auto")
+    # the library's own RCCL communicator (include/hsr.h hsr_comm_*): ONE for every plan of this run; the step executor issues the
+    # per-step collective on it from C.  Under gloo (rehearsal) there is none and the exchange pipeline uses its host transport.
+    comm = eng.Comm(None, device) if exchanging and (args.backend == "nccl" or args.force_exchange) and args.coeff_sync != "local" else None
+    exchanging = exchanging and args.coeff_sync != "local"
+    want_fused = ntl == 1 and not args.fused_fit and args.pipeline in ("fused", "auto")
+    reserve = args.reserve_cus if exchanging else 0      # CUs kept free for the side stream's kernels (gate, collective, solve)
     fused_note = None
     if want_fused:
-        # self-check on THIS tile before anything is timed: five tiles through the fused pipeline must come out with the bits of
-        # step() (pseudo, matched, moments, coefficients).  auto falls back to the plain sequence if they do not.
+        # self-check on THIS tile before anything is timed: seven tiles through the fused pipeline must come out with the bits of
+        # step() (pseudo, matched, moments, coefficients) - with an exchange: step()'s collective goes through torch.distributed,
+        # the pipeline's through the C ABI.  auto falls back (to the plain sequence / the two-slot pipeline) if they do not.
         chk = SpectralFusion(prob.emit_w, prob.srf, prob.good_mask, deg=args.deg, min_valid=0.0, min_count=50, clip=True,
-                             device=device, coeff_sync="local", fuse_apply=True, u16_fast=args.u16_fast)
+                             device=device, coeff_sync=args.coeff_sync if exchanging else "local", fuse_apply=True,
+                             force_exchange=args.force_exchange, reserved_cus=reserve, comm=comm, u16_fast=args.u16_fast)
         chk_cube = prob.cube if args.cube == "f32" else eng.tile_encode_u16(prob.cube)
         ref_out = chk.step(chk_cube, prob.real, reuse_buffers=False)
-        got = [chk.submit(chk_cube, prob.real) for _ in range(5)]
+        ref_out = [t.clone() for t in (ref_out.pseudo, ref_out.matched, ref_out.moments, ref_out.coeffs)]
+        got = [chk.submit(chk_cube, prob.real) for _ in range(7)]
         got = [o for o in got if o is not None] + chk.drain()
-        same = chk._pipe["fused"] and len(got) == 5 and all(
-            torch.equal(o.pseudo.view(torch.int32), ref_out.pseudo.view(torch.int32)) and
-            torch.equal(o.matched.view(torch.int32), ref_out.matched.view(torch.int32)) and
-            torch.equal(o.moments.view(torch.int64), ref_out.moments.view(torch.int64)) and
-            torch.equal(o.coeffs.view(torch.int64), ref_out.coeffs.view(torch.int64)) for o in got)
+        same = chk._pipe["fused"] and len(got) == 7 and chk.pipeline_status() == 0 and all(
+            torch.equal(o.pseudo.view(torch.int32), ref_out[0].view(torch.int32)) and
+            torch.equal(o.matched.view(torch.int32), ref_out[1].view(torch.int32)) and
+            (torch.equal(o.moments.view(torch.int64), ref_out[2].view(torch.int64)) or (args.coeff_sync == "broadcast" and rank != 0)) and
+            torch.equal(o.coeffs.view(torch.int64), ref_out[3].view(torch.int64)) for o in got)
+        if world > 1:                                  # one decision for all ranks
+            flag = torch.tensor([1.0 if same else 0.0], device=device if args.backend == "nccl" else "cpu")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            same = bool(flag.item() > 0.5)
+        why = chk.fused_fallback
         chk.close()
         del chk, got, ref_out, chk_cube
         if not same:
             if args.pipeline == "fused":
-                raise SystemExit("[bench] --pipeline fused: the fused pipeline did not reproduce step() on this tile")
+                raise SystemExit(f"[bench] --pipeline fused: the fused pipeline did not reproduce step() on this tile ({why})")
             want_fused = False
-            fused_note = "auto: the fused pipeline's self-check failed, plain sequence used"
+            fused_note = f"auto: the fused pipeline's self-check failed ({why}), {'two-slot pipeline' if exchanging else 'plain sequence'} used"
         else:
-            fused_note = "self-checked before timing: five tiles through the fused pipeline carry the bits of step()"
+            fused_note = "self-checked before timing: seven tiles through the fused pipeline carry the bits of step()"
     pipelined = ntl == 1 and (args.pipeline == "on" or want_fused or (args.pipeline == "auto" and exchanging))
     fused = pipelined and want_fused
 
@@ -398,9 +448,11 @@ def main(argv=None):
                               clip=True, device=device, group=None,
                               coeff_sync=args.coeff_sync if exchanging else "local",
                               force_exchange=args.force_exchange,
-                              reserved_cus=args.reserve_cus if (pipelined and not fused) else 0,   # CUs kept free for the side stream
+                              # CUs kept free for the side stream: with an exchange (gate, collective, solve) and for the two-slot
+                              # pipeline's fit; the fused pipeline without an exchange has no side-stream work
+                              reserved_cus=(args.reserve_cus if (exchanging or not fused) else 0) if pipelined else 0,
                               u16_fast=args.u16_fast, fused_fit=args.fused_fit, placement_trials=trials,
-                              placement_budget_gb=args.placement_budget_gb, fuse_apply=fused)
+                              placement_budget_gb=args.placement_budget_gb, fuse_apply=fused, comm=comm)
     real = prob.real            # (H, W, row) band-last, like the cube and the reference's (H, W, C) images
     cube = prob.cube
     if args.cube == "u16":      # quantise once, outside the timed region (the writer's arithmetic, on the device)
@@ -423,6 +475,8 @@ def main(argv=None):
             return plan_.step(cube_, real_, k1_events=k1_events)
         return run_step
 
+    host_issue = [0.0]
+
     def timed_region(plan_, run_step, steps, warm, settle_steps):
         """settle (untimed load) -> W warm-up steps -> barrier -> exactly `steps` timed steps -> barrier."""
         for i in range(settle_steps):
@@ -440,6 +494,7 @@ def main(argv=None):
         t0 = time.perf_counter()
         for i in range(steps):
             run_step(ev.get(i))
+        host_issue[0] = (time.perf_counter() - t0) / max(1, steps)      # host time to ISSUE a step (the GPU runs behind)
         if pipelined:
             plan_.flush()            # the last tile's apply belongs to the timed region
         barrier()
@@ -523,25 +578,29 @@ def main(argv=None):
         esz = 4 if args.cube == "f32" else 2
         cube_bytes = npb * esz
         full_bytes = H * W * (esz * B + 16 * nb)        # + pseudo write, real read, apply read + write (no mask in this run)
-        launch_bytes = cube_bytes * ntl            # a mosaic step runs K1+K2 of all its tiles in one batched launch
-        if fused:                                  # the timed launch also carries K3 of tile i-2: + 8 * row bytes per pixel
-            launch_bytes += H * W * 8 * prob.real.shape[-1]
-        achieved = launch_bytes / (k1_ms * 1e-3) / 1e9
-        roof = {"bound": "hbm", "kernel": ("srf_kernel<deg,fast,...,APPLY>: K1+K2 of tile i + K3 of tile i-2 (pre-phase) + fit of tile i-1 (tail) "
-                                           "in one launch; algorithmic bytes = cube + K3's 8 x row bytes per pixel" if fused else
-                                           "srf_kernel<deg,fast> (K1+K2 fused)") if args.cube == "f32" else
-                          "srf_u16_ring_kernel<deg%s> (K1+K2 fused, uint16 tile decode%s)%s" % (
-                              ",...,APPLY" if fused else "", ", fast arithmetic" if args.u16_fast else "",
-                              " + K3 of tile i-2 (pre-phase) + fit of tile i-1 (tail) in one launch; algorithmic bytes = cube + K3's 8 x row "
-                              "bytes per pixel" if fused else ""), "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None, "traffic_source": None, "algorithmic_bytes": launch_bytes, "kernel_ms": round(k1_ms, 4),
+        # the algorithmic bytes of the dominant kernel are the cube read ONCE (H*W*285*4 per tile) - roofline.achieved
+        # and .frac use exactly that over the kernel's time.  What the launch moves beyond it (targets, planes, and in the fused
+        # pipelines K3 of an older tile: + 8 x row bytes per pixel) is reported beside it as frac_launch_bytes.
+        alg_bytes = cube_bytes * ntl               # a mosaic step runs K1+K2 of all its tiles in one batched launch
+        launch_bytes = alg_bytes + (H * W * 8 * prob.real.shape[-1] if fused else 0)
+        achieved = alg_bytes / (k1_ms * 1e-3) / 1e9
+        carried = ("K1+K2 of tile i + K3 of tile i-3 (pre-phase) + slot reduction of tile i-1 (tail) in one launch, exchange on the side stream"
+                   if (fused and exchanging) else "K1+K2 of tile i + K3 of tile i-2 (pre-phase) + fit of tile i-1 (tail) in one launch")
+        roof = {"bound": "hbm", "kernel": (f"srf_kernel<deg,fast,...,APPLY>: {carried}" if fused else "srf_kernel<deg,fast> (K1+K2 fused)")
+                if args.cube == "f32" else
+                "srf_u16_ring_kernel<deg%s> (K1+K2 fused, uint16 tile decode%s)%s" % (
+                    ",...,APPLY" if fused else "", ", fast arithmetic" if args.u16_fast else "", (": " + carried) if fused else ""),
+                "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": None, "traffic_source": None, "algorithmic_bytes": alg_bytes,
+                "algorithmic_bytes_note": "SURVEY 8(d): H*W*285*4 per tile, the cube read exactly once (x tiles per launch)",
+                "kernel_ms": round(k1_ms, 4),
                 "kernel_launches_timed": len(k1_all),
                 "kernel_ms_in_timed_region": round(sum(in_region) / max(1, len(in_region)), 4), "launches_in_timed_region": len(in_region),
                 "kernel_ms_after_region": round(sum(extra) / max(1, len(extra)), 4) if extra else None,
-                "agrees_with": "profiles/r03_kernel_stats.csv (rocprofv3 --kernel-trace --stats of this command): average duration of "
+                "agrees_with": "profiles/r04_kernel_stats.csv (rocprofv3 --kernel-trace --stats of this command): average duration of "
                                "the srf_kernel<..., true> (fused pipeline) / srf_kernel / srf_u16_ring_kernel row",
-                "frac_cube_bytes_only": round(cube_bytes * ntl / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),     # SURVEY 8(d)'s headline figure (the cube read once) over this launch's time
+                "launch_bytes": launch_bytes,                 # everything of the cube + the carried K3 the launch must move
+                "frac_launch_bytes": round(launch_bytes / (k1_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                 "step_frac_of_peak": round(ntl * cube_bytes * args.steps / dt_max / 1e9 / HBM_PEAK_GBS, 4),
                 "total_fraction": round(ntl * full_bytes * args.steps / dt_max / 1e9 / HBM_PEAK_GBS, 4),
                 "total_bytes_per_step": ntl * full_bytes}
@@ -572,6 +631,7 @@ def main(argv=None):
         line = {"metric": "Mpixel*bands/s fused (SRF + deg-%d per-band LSQ fit + apply)" % args.deg,
                 "value": round(value, 1), "unit": "Mpixel*bands/s", "n_gpus": world, "steps": args.steps,
                 "warmup": args.warmup, "ms_per_step": round(dt_max / args.steps * 1e3, 4),
+                "host_issue_us_per_step": round(host_issue[0] * 1e6, 2),
                 "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
                 "dtype": "f32" if args.cube == "f32" else "u16->f32",
                 "data": "synthetic",
@@ -580,9 +640,16 @@ def main(argv=None):
                 "config": {"workload": wl,
                            "tiles_per_gpu": ntl, "rows_per_gpu": H, "coeff_sync": (args.coeff_sync if world > 1 else "none") +
                            (f" (rehearsal: one-rank RCCL {args.coeff_sync} forced)" if args.force_exchange else ""),
-                           "pipeline": ("one kernel per tile: K3 of tile i-2 as a pre-phase, K1+K2 of tile i, fit of tile i-1 as tail work "
-                                        "(no side stream, no events, no reserved CUs); " + str(fused_note) if fused else
-                                        f"one tile deep, {args.reserve_cus} CUs reserved") if pipelined else "off",
+                           "pipeline": (("one kernel per tile with the exchange issued from C: K3 of tile i-3 as a pre-phase, K1+K2 of tile i, slot "
+                                         "reduction of tile i-1 as tail work; gate -> " +
+                                         (("RCCL " + args.coeff_sync + " through the library's own communicator") if comm is not None else
+                                          "host transport (pinned round trip + torch.distributed on the CPU)") +
+                                         f" -> solve on the side stream, no event or stream wait on the caller's stream, {args.reserve_cus} CUs "
+                                         "reserved; " + str(fused_note)) if (fused and exchanging) else
+                                        ("one kernel per tile: K3 of tile i-2 as a pre-phase, K1+K2 of tile i, fit of tile i-1 as tail work "
+                                         "(no side stream, no events, no reserved CUs); " + str(fused_note)) if fused else
+                                        f"one tile deep (two slots, fit on a side stream), {args.reserve_cus} CUs reserved") if pipelined else "off",
+                           "exchange_transport": (plan._pipe or {}).get("transport") if pipelined else None,
                            "settle": {"ms": args.settle_ms, "untimed_steps": settle_steps,
                                       "note": "untimed load before the W warm-up steps: from idle a 20-step region sits in a "
                                               "power-management transient 6-10 % slower than the continuous-load state"},
@@ -615,6 +682,9 @@ def main(argv=None):
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
     if world > 1 or args.force_exchange:
         dist.barrier()
+        plan.close()
+        if comm is not None:
+            comm.close()
         dist.destroy_process_group()
 
 

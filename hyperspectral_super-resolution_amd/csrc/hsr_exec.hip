@@ -11,6 +11,8 @@
 #include <new>
 
 #include "hsr_common.h"
+#include "hsr_solve.h"
+#include "hsr_sync_dev.h"
 
 struct hsr_step_plan {
   hsr_step_desc d;
@@ -18,30 +20,61 @@ struct hsr_step_plan {
   int32_t slots;
   hipEvent_t ev_k1, ev_fit;       // pipeline: K1 of this slot enqueued / fit of this slot done
   bool pending;                   // pipeline: K1 + fit enqueued, K3 not yet
-  bool fitted;                    // fused pipeline without an exchange: the tail fit of this slot's tile has been enqueued
+  bool fitted;                    // fused pipelines: the slot reduction (+ solve, without an exchange) of this slot's tile has been enqueued
+  bool exchanged;                 // four slots: gate -> collective -> solve of this slot's tile has been enqueued on the side stream
+  unsigned int seq;               // four slots: sequence number of the tile in this slot (the value of its "ready" word)
 };
 
 struct hsr_pipeline {
-  hsr_step_plan* slot[3];
-  int nslots;                     // 2: K3(i-1) as its own launch behind K1(i);  3 (fused): K3(i-2) inside K1(i)'s launch
+  hsr_step_plan* slot[4];
+  int nslots;                     // 2: K3(i-1) as its own launch behind K1(i);  3 (fused): K3(i-2) inside K1(i)'s launch;
+                                  // 4 (fused + exchange from C): K3(i-3) inside K1(i)'s launch, see hsr_pipeline_create_exchange
   hipStream_t side;
   int64_t n;                      // tiles submitted
-  int exchange;                   // 1: the caller runs the fit (reduce -> collective -> solve) itself between
+  int exchange;                   // two slots, 1: the caller runs the fit (reduce -> collective -> solve) itself between
                                   //    hsr_pipeline_submit and hsr_pipeline_fit_done
-  unsigned int* counter;          // fused, no exchange: ticket counter of the tail fits (device), and what it holds
+  unsigned int* counter;          // fused: ticket counter of the tail fits (device), and what it holds
   unsigned int tickets;
+  // ---- four slots: the exchange is issued from here ----
+  hsr_exchange x;
+  unsigned int* sync;             // device words: [0] tickets (= counter), [1] bands whose moments are published, [2] error code,
+                                  //               [4 + k] "coefficients ready" word of slot k (holds the sequence number of its tile)
+  unsigned int published;         // value sync[1] reaches once every reduction enqueued so far has run (nb per tile)
+  double* host_moments[4];        // pinned staging of the host_sum transport, one per slot
+  struct host_job { hsr_pipeline* pl; double* values; int32_t count; } host_jobs[4];
+  volatile int host_error;        // host_sum returned non-zero
 };
 
 namespace {
 
-// One wave that sleeps for ~n x 3.4 us (s_sleep 127 = 8 128 cycles).  It opens the side stream's work in the FUSED pipeline:
-// there the fit of tile i becomes runnable at the very moment K1 of tile i+1 does, and when the fit's workgroups were placed
-// first they sat on CUs K1 needs two full workgroup slots of - K1 then ran a second round for the workgroups that did not fit
-// (rocprofv3, r03: 292 us instead of 205 us, the 6 us fit kernel 170 us).  The sleeper needs 1 wave, no LDS and a handful of
-// registers, so it fits next to a full set of K1 workgroups wherever it lands; when it ends K1 is resident and the fit goes to
-// the CUs K1 leaves free (hsr_srf_options.reserved_cus), as in the two-slot pipeline.
-__global__ void side_delay_kernel(int n) {
-  for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(127);
+// ---- kernels of the exchange pipeline (four slots) ----------------------------------------------------------------
+// gate: one wave on the side stream that polls a device word until it has reached `target` - the stream-ordered work behind
+// it (the collective, the solve) then starts without any event on the caller's stream.  1 wave, no LDS, a handful of
+// registers: it fits on a CU the persistent K1 leaves free (hsr_srf_options.reserved_cus).
+__global__ __launch_bounds__(64) void gate_kernel(const unsigned int* word, unsigned int target, unsigned int* err, unsigned int code) {
+  if (threadIdx.x == 0) hsr::wait_word_at_least(word, target, err, code);
+}
+
+// adds `n` to a word at agent scope: tiles whose slot reduction ran as a launch of its own publish their moments this way
+__global__ __launch_bounds__(64) void publish_add_kernel(unsigned int* word, unsigned int n) {
+  if (threadIdx.x == 0) __hip_atomic_fetch_add(word, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// np.polyfit from the (all-reduced) moments, one thread per band - solve_kernel of hsr_poly.hip, hence its bits - and then the
+// publication: coefficients written through to memory, stores waited for, the slot's "ready" word set to the tile's sequence
+// number.  do_solve = 0: publish only (the coefficients came by broadcast).
+__global__ __launch_bounds__(64) void solve_publish_kernel(const double* __restrict__ moments, int nb, int deg, long long min_count,
+                                                           double* coeffs, int do_solve, unsigned int* ready, unsigned int value) {
+  const int b = threadIdx.x;
+  if (do_solve && b < nb) {
+    double c[HSR_MAX_DEG + 1];
+    hsr::solve_band(moments + (size_t)b * hsr::moment_count(deg), deg, min_count, c);
+    for (int j = 0; j <= deg; ++j)
+      __hip_atomic_store(coeffs + (size_t)b * (deg + 1) + j, c[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) hsr::st_agent_u32(ready, value);
 }
 
 int run_k1(hsr_step_plan* p, const void* cube, const float* real, const uint8_t* mask, hipStream_t s,
@@ -152,29 +185,51 @@ extern "C" int hsr_step_run_apply(hsr_step_plan* p, const uint8_t* mask_dev, hsr
 //     side stream     :  fit(0)        fit(1)        fit(2) ...          fit(i) runs under K1(i+1)
 // K3(i) waits for ev_fit(i) and precedes K1(i+2) in stream order, so two slots need no further events.  The event that
 // releases fit(i) is recorded behind K3(i-1), not between K1(i) and K3(i-1) (a record in between cost a 13 us bubble).
-static int pipeline_new(hsr_step_plan* s0, hsr_step_plan* s1, hsr_step_plan* s2, hsr_stream_t side_stream, int32_t exchange,
-                        hsr_pipeline** out, const char* who) {
-  HSR_REQUIRE(s0 && s1 && s0 != s1 && out, HSR_ERR_INVALID, "%s: distinct plans needed", who);
+static int pipeline_new(hsr_step_plan* const* sl, int nslots, hsr_stream_t side_stream, int32_t exchange, hsr_pipeline** out,
+                        const char* who) {
+  HSR_REQUIRE(out, HSR_ERR_INVALID, "%s: NULL argument", who);
+  for (int i = 0; i < nslots; ++i) {
+    HSR_REQUIRE(sl[i], HSR_ERR_INVALID, "%s: NULL plan", who);
+    for (int k = 0; k < i; ++k) {
+      HSR_REQUIRE(sl[i] != sl[k], HSR_ERR_INVALID, "%s: distinct plans needed", who);
+      // In one fused launch the pre-phase reads the coefficients of one slot, the tail writes the moments / coefficients and reads
+      // the partials of another, K1 writes the partials of a third: aliased work buffers would race silently.
+      const hsr_step_desc &a = sl[i]->d, &b = sl[k]->d;
+      HSR_REQUIRE(nslots == 2 || (a.partials_dev != b.partials_dev && a.moments_dev != b.moments_dev && a.coeffs_dev != b.coeffs_dev &&
+                                  a.pseudo_dev != b.pseudo_dev && a.matched_dev != b.matched_dev),
+                  HSR_ERR_INVALID, "%s: plans %d and %d share a work buffer (partials / moments / coefficients / images must be distinct)", who, k, i);
+    }
+  }
   HSR_REQUIRE(side_stream != nullptr, HSR_ERR_INVALID, "%s: the side stream must be a real stream, not the default one", who);
   hsr_pipeline* pl = new (std::nothrow) hsr_pipeline();
   HSR_REQUIRE(pl, HSR_ERR_INVALID, "%s: out of host memory", who);
-  pl->slot[0] = s0;
-  pl->slot[1] = s1;
-  pl->slot[2] = s2;
-  pl->nslots = s2 ? 3 : 2;
+  for (int i = 0; i < 4; ++i) {
+    pl->slot[i] = i < nslots ? sl[i] : nullptr;
+    pl->host_moments[i] = nullptr;
+  }
+  pl->nslots = nslots;
   pl->side = (hipStream_t)side_stream;
   pl->n = 0;
   pl->exchange = exchange ? 1 : 0;
   pl->counter = nullptr;
-  pl->tickets = 0;
-  for (int k = 0; k < pl->nslots; ++k) pl->slot[k]->pending = pl->slot[k]->fitted = false;
-  if (s2 && !exchange) {          // not a launch-path call: the tail fits' ticket counter
-    if (hipMalloc(&pl->counter, sizeof(unsigned int)) != hipSuccess || hipMemset(pl->counter, 0, sizeof(unsigned int)) != hipSuccess) {
+  pl->sync = nullptr;
+  pl->tickets = pl->published = 0;
+  pl->x = hsr_exchange{};
+  pl->host_error = 0;
+  for (int k = 0; k < nslots; ++k) {
+    pl->slot[k]->pending = pl->slot[k]->fitted = pl->slot[k]->exchanged = false;
+    pl->slot[k]->seq = 0;
+  }
+  if (nslots >= 3) {              // not a launch-path call: the device words of the fused pipelines
+    if (hipMalloc(&pl->sync, 8 * sizeof(unsigned int)) != hipSuccess || hipMemset(pl->sync, 0, 8 * sizeof(unsigned int)) != hipSuccess ||
+        hipDeviceSynchronize() != hipSuccess) {
       (void)hipGetLastError();
+      if (pl->sync) (void)hipFree(pl->sync);
       delete pl;
-      hsr::set_error("%s: could not allocate the ticket counter", who);
+      hsr::set_error("%s: could not allocate the pipeline's device words", who);
       return HSR_ERR_HIP;
     }
+    pl->counter = pl->sync;
   }
   *out = pl;
   return HSR_OK;
@@ -182,39 +237,83 @@ static int pipeline_new(hsr_step_plan* s0, hsr_step_plan* s1, hsr_step_plan* s2,
 
 extern "C" int hsr_pipeline_create(hsr_step_plan* slot0, hsr_step_plan* slot1, hsr_stream_t side_stream, int32_t exchange,
                                    hsr_pipeline** out) {
-  return pipeline_new(slot0, slot1, nullptr, side_stream, exchange, out, "hsr_pipeline_create");
+  hsr_step_plan* sl[2] = {slot0, slot1};
+  return pipeline_new(sl, 2, side_stream, exchange, out, "hsr_pipeline_create");
+}
+
+// The fused launches need one tile geometry in every plan, 16-byte aligned pixel-major rows of 4 / 8 / 12 / 16 floats, and a K1
+// kernel that can carry the job (hsr_srf_fused_launch_supported: weights in LDS, for uint16 tiles the ring kernel) - checked HERE
+// so that a caller can fall back to the two-slot pipeline before any tile is in flight, not at the first carrying launch.
+static int fused_geometry(hsr_step_plan* const* ps, int n, const char* who) {
+  for (int i = 0; i < n; ++i) {
+    HSR_REQUIRE(ps[i], HSR_ERR_INVALID, "%s: NULL plan", who);
+    const hsr_step_desc &d = ps[i]->d, &d0 = ps[0]->d;
+    HSR_REQUIRE(d.cube_dtype == d0.cube_dtype && d.out_bs == 1 && (d.out_ps & 3) == 0 && d.out_ps <= HSR_MAX_BANDS && d.matched_bs == 1 &&
+                    d.matched_ps == d.out_ps && ((((uintptr_t)d.pseudo_dev) | ((uintptr_t)d.matched_dev)) & 15) == 0 &&
+                    d.npix == d0.npix && d.out_ps == d0.out_ps && d.nb == d0.nb && d.deg == d0.deg && d.B == d0.B &&
+                    d.opts.reserved_cus == d0.opts.reserved_cus,
+                HSR_ERR_UNSUPPORTED, "%s: 16-byte aligned pixel-major rows of 4 / 8 / 12 / 16 floats, "
+                "the same geometry, cube type and options in all plans", who);
+  }
+  const hsr_step_desc& d = ps[0]->d;
+  return hsr_srf_fused_launch_supported(d.cube_dtype, d.B, d.nb, ps[0]->k0, ps[0]->klen, d.out_ps, d.deg, &d.opts);
 }
 
 // Fused pipeline over THREE plans: K3 of tile i-2 rides in the launch of K1 of tile i (hsr_srf_integrate_moments_apply), so the
 // caller's stream carries ONE kernel per tile:
-//     exchange = 0 :  [K1(0)]  [K1(1) + fit(0)]  [K3(0) + K1(2) + fit(1)]  [K3(1) + K1(3) + fit(2)] ...   nothing else: the fit of
-//                     tile i is tail work of launch i+1 (first workgroups to finish), no side stream, no events, no free CUs
-//     exchange = 1 :  [K1(0)]  [K1(1)]  [K3(0) + K1(2)] ...   + side stream: delay, then the caller's reduce -> collective -> solve
-// All three plans must describe the same float32 tile geometry with 16-byte aligned pixel-major rows of 4 / 8 / 12 / 16 floats.
+//     [K1(0)]  [K1(1) + fit(0)]  [K3(0) + K1(2) + fit(1)]  [K3(1) + K1(3) + fit(2)] ...   nothing else: the fit of tile i is tail
+//     work of launch i+1 (first workgroups to finish), no side stream, no events, no free CUs
+// No exchange (a collective cannot ride in a kernel's tail): with one, hsr_pipeline_create_exchange.
 extern "C" int hsr_pipeline_create_fused(hsr_step_plan* slot0, hsr_step_plan* slot1, hsr_step_plan* slot2, hsr_stream_t side_stream,
                                          int32_t exchange, hsr_pipeline** out) {
-  HSR_REQUIRE(slot0 && slot1 && slot2 && slot2 != slot0 && slot2 != slot1, HSR_ERR_INVALID, "hsr_pipeline_create_fused: three distinct plans needed");
+  HSR_REQUIRE(!exchange, HSR_ERR_UNSUPPORTED, "hsr_pipeline_create_fused: no exchange in the three-slot form; use hsr_pipeline_create_exchange");
   hsr_step_plan* ps[3] = {slot0, slot1, slot2};
-  for (hsr_step_plan* p : ps) {
-    const hsr_step_desc& d = p->d;
-    HSR_REQUIRE(d.cube_dtype == slot0->d.cube_dtype && d.out_bs == 1 && (d.out_ps & 3) == 0 && d.out_ps <= HSR_MAX_BANDS && d.matched_bs == 1 &&
-                    d.matched_ps == d.out_ps && ((((uintptr_t)d.pseudo_dev) | ((uintptr_t)d.matched_dev)) & 15) == 0 &&
-                    d.npix == slot0->d.npix && d.out_ps == slot0->d.out_ps && d.nb == slot0->d.nb && d.deg == slot0->d.deg,
-                HSR_ERR_UNSUPPORTED, "hsr_pipeline_create_fused: 16-byte aligned pixel-major rows of 4 / 8 / 12 / 16 floats, "
-                "the same geometry and cube type in all three plans");
+  int rc = fused_geometry(ps, 3, "hsr_pipeline_create_fused");
+  if (rc != HSR_OK) return rc;
+  return pipeline_new(ps, 3, side_stream, 0, out, "hsr_pipeline_create_fused");
+}
+
+extern "C" int hsr_pipeline_create_exchange(hsr_step_plan* const* slots4, hsr_stream_t side_stream, const hsr_exchange* x,
+                                            hsr_pipeline** out) {
+  const char* who = "hsr_pipeline_create_exchange";
+  HSR_REQUIRE(slots4 && x && out, HSR_ERR_INVALID, "%s: NULL argument", who);
+  HSR_REQUIRE((x->comm != nullptr) != (x->host_sum != nullptr), HSR_ERR_INVALID, "%s: exactly one of comm and host_sum must be given", who);
+  HSR_REQUIRE(x->mode == HSR_SYNC_ALLREDUCE || x->mode == HSR_SYNC_BROADCAST, HSR_ERR_INVALID, "%s: mode %d", who, x->mode);
+  HSR_REQUIRE(!x->comm || (x->root >= 0 && x->root < hsr_comm_ranks(x->comm)), HSR_ERR_INVALID, "%s: root %d", who, x->root);
+  int rc = fused_geometry(slots4, 4, who);
+  if (rc != HSR_OK) return rc;
+  hsr_pipeline* pl = nullptr;
+  rc = pipeline_new(slots4, 4, side_stream, 1, &pl, who);
+  if (rc != HSR_OK) return rc;
+  pl->x = *x;
+  if (x->host_sum) {
+    const size_t bytes = (size_t)pl->slot[0]->d.nb * hsr::moment_count(pl->slot[0]->d.deg) * sizeof(double);
+    for (int k = 0; k < 4; ++k) {
+      if (hipHostMalloc(&pl->host_moments[k], bytes, hipHostMallocDefault) != hipSuccess) {
+        (void)hipGetLastError();
+        hsr_pipeline_destroy(pl);
+        hsr::set_error("%s: could not allocate the pinned staging of the host transport", who);
+        return HSR_ERR_HIP;
+      }
+      pl->host_jobs[k] = {pl, pl->host_moments[k], (int32_t)(bytes / sizeof(double))};
+    }
   }
-  return pipeline_new(slot0, slot1, slot2, side_stream, exchange, out, "hsr_pipeline_create_fused");
+  *out = pl;
+  return HSR_OK;
 }
 
 extern "C" void hsr_pipeline_destroy(hsr_pipeline* pl) {
   if (!pl) return;
-  if (pl->counter) (void)hipFree(pl->counter);
+  if (pl->nslots == 4) (void)hipStreamSynchronize(pl->side);      // a host_sum callback may still point at this object
+  for (int k = 0; k < 4; ++k)
+    if (pl->host_moments[k]) (void)hipHostFree(pl->host_moments[k]);
+  if (pl->sync) (void)hipFree(pl->sync);
   delete pl;
 }
 
 static int finish_slot(hsr_pipeline* pl, hsr_step_plan* p, const uint8_t* mask, hipStream_t main) {
   int rc = HSR_OK;
-  if (pl->nslots == 3 && !pl->exchange) {      // tail-fit pipeline: everything lives on the caller's stream
+  if (pl->nslots == 3) {                       // tail-fit pipeline: everything lives on the caller's stream
     if (!p->fitted)
       rc = hsr_moments_reduce_solve(p->d.partials_dev, p->slots, p->d.nb, p->d.deg, p->d.min_count, p->d.moments_dev, p->d.coeffs_dev, main);
     p->fitted = true;
@@ -227,9 +326,147 @@ static int finish_slot(hsr_pipeline* pl, hsr_step_plan* p, const uint8_t* mask, 
   return rc;
 }
 
-// Starts tile i in slot i % 2 and finishes tile i-1 (its K3).  *finished_slot = slot of the finished tile, or -1.
-// prev_mask_dev: the mask of tile i-1 (only read when the plan applies the mask in K3).
-// With exchange = 0 the fit (slot reduction + solve) is enqueued on the side stream here.  With exchange = 1 the side stream
+// ---- four slots: the exchange issued from here ------------------------------------------------------------------------
+static void host_sum_trampoline(void* arg) {
+  auto* j = static_cast<hsr_pipeline::host_job*>(arg);
+  if (j->pl->x.host_sum(j->pl->x.host_user, j->values, j->count) != 0) j->pl->host_error = 1;
+}
+
+// The slot reduction of a tile as a launch of its own on the caller's stream (tiles whose follower cannot carry it in its tail:
+// fewer workgroups than bands, or no follower at a drain), published like a tail reduction.
+static int reduce_and_publish(hsr_pipeline* pl, hsr_step_plan* p, hipStream_t main) {
+  int rc = hsr_moments_reduce(p->d.partials_dev, p->slots, p->d.nb, p->d.deg, p->d.moments_dev, main);
+  if (rc != HSR_OK) return rc;
+  hipLaunchKernelGGL(publish_add_kernel, dim3(1), dim3(64), 0, main, pl->sync + 1, (unsigned int)p->d.nb);
+  HSR_LAUNCH_CHECK("publish_add_kernel");
+  pl->published += (unsigned int)p->d.nb;
+  p->fitted = true;
+  return HSR_OK;
+}
+
+// gate -> collective -> solve + publish of the tile in slot k, on the side stream.  Called once per tile, in tile order, on every
+// rank: the collectives of all ranks line up.
+static int enqueue_exchange(hsr_pipeline* pl, int k) {
+  hsr_step_plan* p = pl->slot[k];
+  const hsr_step_desc& d = p->d;
+  const int64_t nmom = (int64_t)d.nb * hsr::moment_count(d.deg);
+  hipLaunchKernelGGL(gate_kernel, dim3(1), dim3(64), 0, pl->side, pl->sync + 1, pl->published, pl->sync + 2, 1u);
+  HSR_LAUNCH_CHECK("gate_kernel");
+  int rc = HSR_OK;
+  int solve_here = 1;
+  if (pl->x.host_sum) {
+    double* h = pl->host_moments[k];
+    rc = hsr::check_hip(hipMemcpyAsync(h, d.moments_dev, nmom * sizeof(double), hipMemcpyDeviceToHost, pl->side), "hsr_pipeline: moments to the host");
+    if (rc == HSR_OK) rc = hsr::check_hip(hipLaunchHostFunc(pl->side, host_sum_trampoline, &pl->host_jobs[k]), "hsr_pipeline: host_sum");
+    if (rc == HSR_OK) rc = hsr::check_hip(hipMemcpyAsync(d.moments_dev, h, nmom * sizeof(double), hipMemcpyHostToDevice, pl->side), "hsr_pipeline: moments back");
+  } else if (pl->x.mode == HSR_SYNC_ALLREDUCE) {
+    rc = hsr_allreduce_f64(pl->x.comm, d.moments_dev, nmom, pl->side);
+  } else {
+    rc = hsr_reduce_f64(pl->x.comm, d.moments_dev, nmom, pl->x.root, pl->side);
+    if (rc != HSR_OK) return rc;
+    rc = hsr_poly_solve(d.moments_dev, d.nb, d.deg, d.min_count, d.coeffs_dev, pl->side);      // only the root's is kept
+    if (rc != HSR_OK) return rc;
+    rc = hsr_bcast(pl->x.comm, d.coeffs_dev, (int64_t)d.nb * (d.deg + 1) * (int64_t)sizeof(double), pl->x.root, pl->side);
+    solve_here = 0;
+  }
+  if (rc != HSR_OK) return rc;
+  hipLaunchKernelGGL(solve_publish_kernel, dim3(1), dim3(64), 0, pl->side, d.moments_dev, d.nb, d.deg, (long long)d.min_count, d.coeffs_dev,
+                     solve_here, pl->sync + 4 + k, p->seq);
+  HSR_LAUNCH_CHECK("solve_publish_kernel");
+  p->exchanged = true;
+  return HSR_OK;
+}
+
+static int submit_exchange(hsr_pipeline* pl, const void* cube_dev, const float* real_dev, const uint8_t* mask_dev,
+                           const uint8_t* prev_mask_dev, hipStream_t main, int32_t* finished_slot, void* k1_begin_event,
+                           void* k1_end_event) {
+  const int cur = (int)(pl->n % 4);
+  hsr_step_plan* p = pl->slot[cur];
+  const int ko = (int)((pl->n + 1) % 4), kl = (int)((pl->n + 3) % 4);
+  hsr_step_plan* old = pl->n >= 3 ? pl->slot[ko] : nullptr;        // tile n - 3: its K3 rides in this launch
+  hsr_step_plan* last = pl->n >= 1 ? pl->slot[kl] : nullptr;       // tile n - 1: its slot reduction rides in this launch's tail
+  int rc = HSR_OK;
+  hsr_apply_job job{};
+  job.sync_error_dev = pl->sync + 2;
+  const bool carry = old && old->pending;
+  if (carry) {
+    HSR_REQUIRE(old->exchanged, HSR_ERR_INVALID, "hsr_pipeline_submit: tile %lld has no exchange enqueued", (long long)(pl->n - 3));
+    job.x_dev = old->d.pseudo_dev;
+    job.out_dev = old->d.matched_dev;
+    job.coeffs_dev = old->d.coeffs_dev;
+    job.mask_dev = old->d.apply_mask ? prev_mask_dev : nullptr;
+    job.npix = old->d.npix;
+    job.clip = old->d.clip;
+    job.coeffs_ready_dev = pl->sync + 4 + ko;
+    job.coeffs_ready_value = old->seq;
+  }
+  const int grid = hsr_partial_slots(p->d.npix, &p->d.opts);
+  const bool reduce_last = last && last->pending && !last->fitted;
+  const bool ride = reduce_last && grid >= p->d.nb;                // one ticket per workgroup, one band per ticket
+  if (ride) {
+    job.fit_partials_dev = last->d.partials_dev;
+    job.fit_slots = last->slots;
+    job.fit_moments_dev = last->d.moments_dev;
+    job.fit_coeffs_dev = last->d.coeffs_dev;                       // not written in this mode
+    job.fit_min_count = last->d.min_count;
+    job.fit_counter_dev = pl->sync;
+    job.fit_ticket_base = pl->tickets;
+    job.fit_ready_dev = pl->sync + 1;
+  } else if (reduce_last) {
+    rc = reduce_and_publish(pl, last, main);
+    if (rc != HSR_OK) return rc;
+  }
+  if (k1_begin_event) rc = hsr::check_hip(hipEventRecord((hipEvent_t)k1_begin_event, main), "hsr_pipeline: record K1 begin");
+  if (rc != HSR_OK) return rc;
+  rc = run_k1(p, cube_dev, real_dev, mask_dev, main, (carry || ride) ? &job : nullptr);
+  if (rc != HSR_OK) return rc;
+  if (ride) {
+    HSR_REQUIRE(p->slots == grid, HSR_ERR_INVALID, "hsr_pipeline_submit: the launch used %d workgroups, %d expected", p->slots, grid);
+    pl->tickets += (unsigned int)p->slots;     // every workgroup of the launch drew one ticket
+    pl->published += (unsigned int)p->d.nb;
+    last->fitted = true;
+  }
+  if (k1_end_event) rc = hsr::check_hip(hipEventRecord((hipEvent_t)k1_end_event, main), "hsr_pipeline: record K1 end");
+  if (rc != HSR_OK) return rc;
+  if (reduce_last) {                           // its moments are (or will be, when this launch's tail runs) published: the exchange
+    rc = enqueue_exchange(pl, kl);
+    if (rc != HSR_OK) return rc;
+  }
+  if (carry) {
+    old->pending = false;
+    if (finished_slot) *finished_slot = ko;
+  }
+  p->pending = true;
+  p->fitted = p->exchanged = false;
+  p->seq = (unsigned int)(pl->n + 1);
+  pl->n += 1;
+  return HSR_OK;
+}
+
+// finish the tile in slot k outside a K1 launch (drain): reduction and exchange if they have not been enqueued yet, then K3 as its
+// own launch behind an event of the side stream
+static int finish_exchange_slot(hsr_pipeline* pl, int k, const uint8_t* mask, hipStream_t main) {
+  hsr_step_plan* p = pl->slot[k];
+  int rc = HSR_OK;
+  if (!p->fitted) rc = reduce_and_publish(pl, p, main);
+  if (rc == HSR_OK && !p->exchanged) rc = enqueue_exchange(pl, k);
+  if (rc != HSR_OK) return rc;
+  // (an EVENT here, not a polling gate: this is a drain, a bubble costs nothing - and a wave spinning on the caller's stream would
+  // deadlock, until its time limit, against side-stream work queued behind it if the runtime serves both streams from one
+  // hardware queue.  Everything the side stream still holds in front of the record is released by launches that are already
+  // enqueued on the caller's stream.)
+  rc = hsr::check_hip(hipEventRecord(p->ev_fit, pl->side), "hsr_pipeline: record fit");
+  if (rc == HSR_OK) rc = hsr::check_hip(hipStreamWaitEvent(main, p->ev_fit, 0), "hsr_pipeline: wait for the fit");
+  if (rc != HSR_OK) return rc;
+  rc = run_apply(p, mask, main);
+  p->pending = false;
+  return rc;
+}
+
+// Starts tile i in slot i % S and finishes tile i-1 (two slots), i-2 (fused) or i-3 (fused with exchange): its K3.
+// *finished_slot = slot of the finished tile, or -1.  prev_mask_dev: the mask of the tile being finished (only read when the
+// plan applies the mask in K3).
+// Two slots, exchange = 0: the fit (slot reduction + solve) is enqueued on the side stream here.  With exchange = 1 the side stream
 // has been made to wait for K1(i) when this returns; the caller enqueues reduce -> collective -> solve on it and then calls
 // hsr_pipeline_fit_done.
 extern "C" int hsr_pipeline_submit(hsr_pipeline* pl, const void* cube_dev, const float* real_dev, const uint8_t* mask_dev,
@@ -243,17 +480,13 @@ extern "C" int hsr_pipeline_submit(hsr_pipeline* pl, const void* cube_dev, const
   HSR_REQUIRE(!p->pending, HSR_ERR_INVALID, "hsr_pipeline_submit: slot %d still holds an unfinished tile", cur);
   int rc = HSR_OK;
   if (finished_slot) *finished_slot = -1;
+  if (S == 4) return submit_exchange(pl, cube_dev, real_dev, mask_dev, prev_mask_dev, main, finished_slot, k1_begin_event, k1_end_event);
   if (S == 3) {
     // fused: this launch carries K3 of tile n - 2 (slot (n + 1) % 3); its fit has had all of K1(n - 1) to finish
     hsr_step_plan* old = pl->n >= 2 ? pl->slot[(pl->n + 1) % 3] : nullptr;
     hsr_apply_job job{};
     const bool carry = old && old->pending;
-    const bool tail = pl->exchange == 0;
     if (carry) {
-      if (!tail) {
-        rc = hsr::check_hip(hipStreamWaitEvent(main, old->ev_fit, 0), "hsr_pipeline: wait for the fit");
-        if (rc != HSR_OK) return rc;
-      }
       job.x_dev = old->d.pseudo_dev;
       job.out_dev = old->d.matched_dev;
       job.coeffs_dev = old->d.coeffs_dev;
@@ -261,7 +494,7 @@ extern "C" int hsr_pipeline_submit(hsr_pipeline* pl, const void* cube_dev, const
       job.npix = old->d.npix;
       job.clip = old->d.clip;
     }
-    hsr_step_plan* last = (tail && pl->n >= 1) ? pl->slot[(pl->n + 2) % 3] : nullptr;     // tile n - 1: its fit rides in this launch's tail
+    hsr_step_plan* last = pl->n >= 1 ? pl->slot[(pl->n + 2) % 3] : nullptr;     // tile n - 1: its fit rides in this launch's tail
     const int grid = hsr_partial_slots(p->d.npix, &p->d.opts);
     // (every workgroup of the launch draws ONE ticket and tickets 0 .. nb-1 fit one band each: a launch of fewer workgroups
     // than bands - a tile of fewer than nb 64-pixel groups - cannot carry the fit; that tile's fit runs as its own launch
@@ -275,7 +508,7 @@ extern "C" int hsr_pipeline_submit(hsr_pipeline* pl, const void* cube_dev, const
       job.fit_counter_dev = pl->counter;
       job.fit_ticket_base = pl->tickets;
     }
-    if (carry && tail && !old->fitted) {         // its fit did not ride in the previous launch (see above): a launch of its own
+    if (carry && !old->fitted) {                 // its fit did not ride in the previous launch (see above): a launch of its own
       rc = hsr_moments_reduce_solve(old->d.partials_dev, old->slots, old->d.nb, old->d.deg, old->d.min_count, old->d.moments_dev,
                                     old->d.coeffs_dev, main);
       if (rc != HSR_OK) return rc;
@@ -286,7 +519,10 @@ extern "C" int hsr_pipeline_submit(hsr_pipeline* pl, const void* cube_dev, const
     rc = run_k1(p, cube_dev, real_dev, mask_dev, main, (carry || job.fit_partials_dev) ? &job : nullptr);
     if (rc != HSR_OK) return rc;
     if (job.fit_partials_dev) {
-      pl->tickets += (unsigned int)grid;         // every workgroup of the launch drew one ticket
+      // the ticket base advances by the workgroups the launch REALLY had (run_k1 reports them), and that must be the number the
+      // "can this launch carry the fit" test above was made with
+      HSR_REQUIRE(p->slots == grid, HSR_ERR_INVALID, "hsr_pipeline_submit: the launch used %d workgroups, %d expected", p->slots, grid);
+      pl->tickets += (unsigned int)p->slots;
       last->fitted = true;
     }
     if (k1_end_event) rc = hsr::check_hip(hipEventRecord((hipEvent_t)k1_end_event, main), "hsr_pipeline: record K1 end");
@@ -295,31 +531,27 @@ extern "C" int hsr_pipeline_submit(hsr_pipeline* pl, const void* cube_dev, const
       old->pending = false;
       if (finished_slot) *finished_slot = (int)((pl->n + 1) % 3);
     }
-  } else {
-    hsr_step_plan* prev = pl->slot[cur ^ 1];
-    if (k1_begin_event) rc = hsr::check_hip(hipEventRecord((hipEvent_t)k1_begin_event, main), "hsr_pipeline: record K1 begin");
-    if (rc != HSR_OK) return rc;
-    rc = run_k1(p, cube_dev, real_dev, mask_dev, main);
-    if (rc != HSR_OK) return rc;
-    if (k1_end_event) rc = hsr::check_hip(hipEventRecord((hipEvent_t)k1_end_event, main), "hsr_pipeline: record K1 end");
-    if (rc != HSR_OK) return rc;
-    if (prev->pending) {
-      rc = finish_slot(pl, prev, prev_mask_dev, main);
-      if (rc != HSR_OK) return rc;
-      if (finished_slot) *finished_slot = cur ^ 1;
-    }
-  }
-  if (S == 3 && !pl->exchange) {        // tail fits: nothing on the side stream, no events
-    p->pending = true;
+    p->pending = true;                    // tail fits: nothing on the side stream, no events
     p->fitted = false;
     pl->n += 1;
     return HSR_OK;
+  }
+  hsr_step_plan* prev = pl->slot[cur ^ 1];
+  if (k1_begin_event) rc = hsr::check_hip(hipEventRecord((hipEvent_t)k1_begin_event, main), "hsr_pipeline: record K1 begin");
+  if (rc != HSR_OK) return rc;
+  rc = run_k1(p, cube_dev, real_dev, mask_dev, main);
+  if (rc != HSR_OK) return rc;
+  if (k1_end_event) rc = hsr::check_hip(hipEventRecord((hipEvent_t)k1_end_event, main), "hsr_pipeline: record K1 end");
+  if (rc != HSR_OK) return rc;
+  if (prev->pending) {
+    rc = finish_slot(pl, prev, prev_mask_dev, main);
+    if (rc != HSR_OK) return rc;
+    if (finished_slot) *finished_slot = cur ^ 1;
   }
   rc = hsr::check_hip(hipEventRecord(p->ev_k1, main), "hsr_pipeline: record K1");
   if (rc != HSR_OK) return rc;
   rc = hsr::check_hip(hipStreamWaitEvent(pl->side, p->ev_k1, 0), "hsr_pipeline: side stream wait");
   if (rc != HSR_OK) return rc;
-  if (S == 3) hipLaunchKernelGGL(side_delay_kernel, dim3(1), dim3(64), 0, pl->side, 3);
   if (!pl->exchange) {
     rc = hsr_moments_reduce_solve(p->d.partials_dev, p->slots, p->d.nb, p->d.deg, p->d.min_count, p->d.moments_dev,
                                   p->d.coeffs_dev, pl->side);
@@ -332,22 +564,23 @@ extern "C" int hsr_pipeline_submit(hsr_pipeline* pl, const void* cube_dev, const
   return HSR_OK;
 }
 
-// exchange = 1: the caller has enqueued the fit of the slot submitted last on the side stream.
+// two slots, exchange = 1: the caller has enqueued the fit of the slot submitted last on the side stream.
 extern "C" int hsr_pipeline_fit_done(hsr_pipeline* pl) {
-  HSR_REQUIRE(pl && pl->n > 0, HSR_ERR_INVALID, "hsr_pipeline_fit_done: nothing submitted");
+  HSR_REQUIRE(pl && pl->n > 0 && pl->nslots == 2, HSR_ERR_INVALID, "hsr_pipeline_fit_done: nothing submitted, or not a two-slot pipeline");
   hsr_step_plan* p = pl->slot[(pl->n - 1) % pl->nslots];
   return hsr::check_hip(hipEventRecord(p->ev_fit, pl->side), "hsr_pipeline: record fit");
 }
 
-// K3 of the tile left in the pipeline; *finished_slot = its slot or -1.
+// K3 of the OLDEST tile left in the pipeline; *finished_slot = its slot or -1.
 extern "C" int hsr_pipeline_flush(hsr_pipeline* pl, const uint8_t* mask_dev, hsr_stream_t main_stream, int32_t* finished_slot) {
   HSR_REQUIRE(pl, HSR_ERR_INVALID, "hsr_pipeline_flush: NULL pipeline");
   if (finished_slot) *finished_slot = -1;
   const int S = pl->nslots;
-  for (int64_t i = pl->n >= S - 1 ? pl->n - (S - 1) : 0; i < pl->n; ++i) {        // the OLDEST unfinished tile
+  for (int64_t i = pl->n >= S - 1 ? pl->n - (S - 1) : 0; i < pl->n; ++i) {
     hsr_step_plan* p = pl->slot[i % S];
     if (!p->pending) continue;
-    int rc = finish_slot(pl, p, mask_dev, (hipStream_t)main_stream);
+    int rc = S == 4 ? finish_exchange_slot(pl, (int)(i % S), mask_dev, (hipStream_t)main_stream)
+                    : finish_slot(pl, p, mask_dev, (hipStream_t)main_stream);
     if (rc == HSR_OK && finished_slot) *finished_slot = (int)(i % S);
     return rc;
   }
@@ -355,3 +588,15 @@ extern "C" int hsr_pipeline_flush(hsr_pipeline* pl, const uint8_t* mask_dev, hsr
 }
 
 extern "C" int64_t hsr_pipeline_count(const hsr_pipeline* pl) { return pl ? pl->n : -1; }
+
+extern "C" int hsr_pipeline_status(hsr_pipeline* pl, hsr_stream_t main_stream, uint32_t* sync_error_out) {
+  HSR_REQUIRE(pl && sync_error_out, HSR_ERR_INVALID, "hsr_pipeline_status: NULL argument");
+  *sync_error_out = 0;
+  int rc = hsr::check_hip(hipStreamSynchronize((hipStream_t)main_stream), "hsr_pipeline_status: caller's stream");
+  if (rc == HSR_OK) rc = hsr::check_hip(hipStreamSynchronize(pl->side), "hsr_pipeline_status: side stream");
+  if (rc != HSR_OK || !pl->sync) return rc;
+  unsigned int code = 0;
+  rc = hsr::check_hip(hipMemcpy(&code, pl->sync + 2, sizeof code, hipMemcpyDeviceToHost), "hsr_pipeline_status: read the error word");
+  *sync_error_out = code | (pl->host_error ? 16u : 0u);
+  return rc;
+}

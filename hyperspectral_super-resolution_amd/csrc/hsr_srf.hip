@@ -34,6 +34,7 @@
 // HBM-bound by construction: 4*B bytes in, 4*nb (+4*nb+1) bytes out/in per pixel, ~0.35 kflop.
 #include "hsr_common.h"
 #include "hsr_solve.h"
+#include "hsr_sync_dev.h"
 
 namespace hsr {
 
@@ -97,6 +98,14 @@ struct SrfArgs {
   double* lazy_coeffs;              // (nb, DEG + 1) out
   unsigned int* lazy_counter;       // running ticket counter (one ticket per workgroup and launch)
   unsigned int lazy_base;           // its value before this launch
+  // exchange pipelines (hsr_pipeline_create_exchange): the fit crosses to ANOTHER queue between the slot reduction and the solve
+  // (all-reduce of the moments over the ranks), so the tail stops at the moments - written through to memory - and counts every
+  // finished band into *lazy_ready, which a one-wave gate kernel on the side stream polls; and the K3 pre-phase reads
+  // coefficients that a side-stream kernel published by setting *apply_ready to apply_ready_value
+  unsigned int* lazy_ready;         // non-NULL: reduce only, publish (no solve)
+  const unsigned int* apply_ready;  // non-NULL: poll until (int)(*apply_ready - apply_ready_value) >= 0, then read the coefficients through
+  unsigned int apply_ready_value;
+  unsigned int* sync_error;         // set to a non-zero code if a poll runs into its time limit (HSR_SYNC_TIMEOUT_S)
 #ifdef HSR_PHASE_STAMPS
   unsigned long long* stamps;
   unsigned long long* stamps2;   // [grid][4]: REFCLK (100 MHz) at workgroup entry and exit, XCC id, HW_ID
@@ -513,7 +522,13 @@ __device__ __forceinline__ void lazy_fit(const SrfArgs& a, unsigned char* smem, 
 #pragma unroll
       for (int l = 0; l < off; ++l) acc[l] = acc[l] + acc[l + off];
     mom[t] = acc[0];
-    a.lazy_moments[(size_t)b * M + t] = acc[0];
+    if (a.lazy_ready) st_agent(a.lazy_moments + (size_t)b * M + t, acc[0]);     // read by another queue while this launch still runs
+    else a.lazy_moments[(size_t)b * M + t] = acc[0];
+  }
+  if (a.lazy_ready) {                                     // exchange pipelines: the all-reduce and the solve follow on the side stream
+    stores_done_barrier();
+    if (t == 0) __hip_atomic_fetch_add(a.lazy_ready, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return;
   }
   __syncthreads();
   if (t == 0) solve_band_t<DEG, true>(mom, a.lazy_min_count, a.lazy_coeffs + (size_t)b * (DEG + 1), work);
@@ -527,23 +542,36 @@ __device__ __forceinline__ void lazy_fit(const SrfArgs& a, unsigned char* smem, 
 // without FMA contraction, mask select, clip, channels >= nb pass through), hence the same bits.  504 of the 512 threads
 // take part: 504 is a multiple of every row length in float4 (1 .. 4), so a thread keeps its channel group and its
 // coefficients stay in registers.
+// Exchange pipelines: the coefficients were written by a kernel of ANOTHER queue (all-reduce -> solve on the side stream) with no
+// event in between, so the workgroup first polls the tile's "coefficients ready" word - set a whole K1 ago in any sane
+// schedule - and reads them through to LDS (agent-scope loads: this XCD's L2 may hold the slot's previous set).
 template <int N, int T>
-__device__ __forceinline__ void apply_prephase(const SrfArgs& a, int t) {
+__device__ __forceinline__ void apply_prephase(const SrfArgs& a, unsigned char* smem, int t) {
   constexpr int kUse = T / 12 * 12;
   constexpr int U = 4;
-  if (a.apply_x == nullptr || t >= kUse) return;
+  if (a.apply_x == nullptr) return;                            // workgroup-uniform
+  const bool gated = a.apply_ready != nullptr;
+  double* cl = reinterpret_cast<double*>(smem);                // [nb][N]: the tile buffers are not in use yet
+  if (gated) {
+    if (t == 0) wait_word_at_least(a.apply_ready, a.apply_ready_value, a.sync_error, 2u);
+    __syncthreads();
+    if (t < a.nb * N) cl[t] = ld_agent(a.apply_coeffs + t);
+    __syncthreads();
+  }
   const int q = (int)(a.out_ps >> 2);
   const uint32_t nv = (uint32_t)(a.apply_npix * q);            // host: apply_npix * q < 2^31
   const uint32_t stride = gridDim.x * (uint32_t)kUse;
-  const uint32_t i0 = blockIdx.x * (uint32_t)kUse + (uint32_t)t;
+  const uint32_t i0 = blockIdx.x * (uint32_t)kUse + (uint32_t)(t < kUse ? t : 0);
   const int c0 = (int)(i0 % (uint32_t)q) * 4;
   double c[4][N];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
     const int ch = c0 + j < a.nb ? c0 + j : 0;
 #pragma unroll
-    for (int k = 0; k < N; ++k) c[j][k] = a.apply_coeffs[ch * N + k];
+    for (int k = 0; k < N; ++k) c[j][k] = gated ? cl[ch * N + k] : a.apply_coeffs[ch * N + k];
   }
+  if (gated) __syncthreads();                                  // everybody holds its coefficients: the first group's DMA may land on cl
+  if (t >= kUse) return;
   const float4* x4 = reinterpret_cast<const float4*>(a.apply_x);
   float4* o4 = reinterpret_cast<float4*>(a.apply_out);
   for (uint32_t ib = i0; ib < nv; ib += stride * U) {
@@ -611,7 +639,7 @@ __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
   // (The pre-phase stays AHEAD of the first DMA.  Behind it - so that the first group lands while the workgroup applies its
   // slice - the fused launch took 0.296 ms instead of 0.207: vmcnt counts in order, so every load of the pre-phase waits for
   // the whole 73 KB group that was issued before it, in every workgroup at once.)
-  if constexpr (APPLY && DEG > 0) apply_prephase<DEG + 1, T>(a, t);
+  if constexpr (APPLY && DEG > 0) apply_prephase<DEG + 1, T>(a, smem, t);
 
   // the (at most two) bands of this thread, fixed for the whole launch
   int bk0[kBandSlots], bkl[kBandSlots], bwo[kBandSlots], bidx[kBandSlots];
@@ -1278,7 +1306,7 @@ __global__ __launch_bounds__(512, 4) void srf_u16_ring_kernel(const SrfArgs a) {
   const bool has_nodata = a.nodata <= 0xffffu;
   const int nchunk_full = tile_bytes >> 4;
 
-  if constexpr (APPLY && DEG > 0) apply_prephase<DEG + 1, T>(a, t);   // K3 of an older tile (fused pipeline, as in srf_kernel)
+  if constexpr (APPLY && DEG > 0) apply_prephase<DEG + 1, T>(a, smem, t);   // K3 of an older tile (fused pipeline, as in srf_kernel)
 
   int bk0[kBandSlots], bkl[kBandSlots], bwo[kBandSlots], bidx[kBandSlots];
   bool bval[kBandSlots];
@@ -1739,6 +1767,42 @@ extern "C" int hsr_partial_slots(int64_t npix, const hsr_srf_options* opts) {
   return hsr::srf_slots(npix, tn.tile_pixels, tn.reserved_cus);
 }
 
+// Can a K1 launch of this geometry carry an apply job / a tail fit (hsr_srf_integrate_moments[_u16]_apply)?  The conditions of
+// dispatch_fast / dispatch_u16_deg and srf_common in one place, without a launch, so that hsr_pipeline_create_fused /
+// _exchange fail at creation - where the caller can still fall back to the two-slot pipeline - instead of at the first
+// carrying launch, with tiles in flight.  (What it cannot see is the cube pointer: uint16 cubes must be 16-byte aligned.)
+extern "C" int hsr_srf_fused_launch_supported(int32_t cube_dtype, int32_t B, int32_t nb, const int32_t* k0, const int32_t* klen,
+                                              int64_t out_ps, int32_t deg, const hsr_srf_options* opts) {
+  const char* who = "hsr_srf_fused_launch_supported";
+  HSR_REQUIRE(cube_dtype == 0 || cube_dtype == 2, HSR_ERR_INVALID, "%s: cube_dtype %d (0 float32, 2 uint16)", who, cube_dtype);
+  HSR_REQUIRE(deg >= 1 && deg <= HSR_MAX_DEG, HSR_ERR_UNSUPPORTED, "%s: deg=%d outside [1,%d]", who, deg, HSR_MAX_DEG);
+  HSR_REQUIRE((out_ps & 3) == 0 && out_ps >= nb && out_ps <= HSR_MAX_BANDS, HSR_ERR_UNSUPPORTED,
+              "%s: pixel-major rows of 4 / 8 / 12 / 16 floats needed, got %lld", who, (long long)out_ps);
+  hsr::SrfTuning tn;
+  int rc = hsr::srf_tuning(opts, &tn, who);
+  if (rc != HSR_OK) return rc;
+  hsr::SrfArgs a{};
+  static const float dummy = 0.0f;
+  a.wn = &dummy;                   // srf_prepare_bands only tests it
+  a.B = B;
+  a.nb = nb;
+  a.out_bs = 1;
+  a.out_ps = out_ps;
+  rc = hsr::srf_prepare_bands(a, k0, klen);
+  if (rc != HSR_OK) return rc;
+  HSR_REQUIRE(a.wtaps > 0, HSR_ERR_UNSUPPORTED, "%s: the weight taps of the %d bands do not fit the %d floats of LDS reserved for them",
+              who, nb, hsr::kWeightCap);
+  if (cube_dtype == 2) {
+    HSR_REQUIRE(tn.u16_ring && hsr::u16_ring_fits(a, true) && 2 * 64 * B * 2 >= 12 * 1024, HSR_ERR_UNSUPPORTED,
+                "%s: uint16 tiles ride only in the double-buffered kernel (u16_single_buffer = 0, 48 <= B, two %d-byte group buffers + "
+                "%d taps + the %lld-float rows within 80 KB of LDS)", who, 64 * B * 2, a.wtaps, (long long)out_ps);
+  } else {
+    const size_t lds = (size_t)64 * a.ldsB * 4 + 64 * sizeof(uint32_t) + (size_t)a.wtaps * 4 + (size_t)64 * out_ps * 4 + hsr::target_stage_bytes(nb);
+    HSR_REQUIRE(lds <= 160 * 1024, HSR_ERR_UNSUPPORTED, "%s: a 64-pixel group of B=%d samples needs %zu bytes of LDS (160 KB per workgroup)", who, B, lds);
+  }
+  return HSR_OK;
+}
+
 extern "C" int hsr_srf_integrate(const float* cube_dev, int64_t npix, int32_t B, const float* wn_dev,
                                  const int32_t* k0, const int32_t* klen, int32_t nb, float* out_dev,
                                  int64_t out_bs, int64_t out_ps, const hsr_srf_options* opts, hsr_stream_t stream) {
@@ -1825,7 +1889,13 @@ static int srf_moments_entry(const char* who, const void* cube_dev, bool u16, fl
       a.lazy_coeffs = job->fit_coeffs_dev;
       a.lazy_counter = job->fit_counter_dev;
       a.lazy_base = job->fit_ticket_base;
+      a.lazy_ready = job->fit_ready_dev;
     }
+    if (job->x_dev && job->coeffs_ready_dev) {
+      a.apply_ready = job->coeffs_ready_dev;
+      a.apply_ready_value = job->coeffs_ready_value;
+    }
+    a.sync_error = job->sync_error_dev;
   }
   int rc = hsr::srf_common(a, k0, klen, deg, opts, (hipStream_t)stream);
   if (rc == HSR_OK && slots_out) *slots_out = a.one.slots;

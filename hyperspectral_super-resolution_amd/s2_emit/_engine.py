@@ -847,6 +847,77 @@ def bilinear_upsample_mask_limits(coarse, Hc: int, Wc: int, factor: int, pmin=2.
     return out, mask, lohi
 
 
+# ---------------------------------------------------------------------------------------------
+# C1 from C: an RCCL communicator of the library's own (include/hsr.h "hsr_comm"), set up over a torch.distributed group
+# ---------------------------------------------------------------------------------------------
+class Comm:
+    """hsr_comm: RCCL's C API behind the C ABI.  torch.distributed is used ONCE, to carry rank 0's 128-byte ncclUniqueId to the
+    other ranks of ``group``; every collective afterwards is a stream-ordered call into the library (hsr_allreduce_f64 ...),
+    issued by the step executor on its side stream or through the methods below.  One communicator per (group, device)."""
+
+    def __init__(self, group=None, device=None, rank: Optional[int] = None, world: Optional[int] = None):
+        import torch
+        import torch.distributed as dist
+        lib = nat.load()
+        if not lib.hsr_comm_available():
+            raise nat.HsrUnavailable("RCCL (librccl.so.1) could not be bound: no hsr_comm on this machine")
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        idbuf = (C.c_ubyte * nat.HSR_COMM_ID_BYTES)()
+        if rank is None:
+            rank, world = dist.get_rank(group), dist.get_world_size(group)
+        if rank == 0:
+            nat.check(lib.hsr_comm_unique_id(idbuf), "hsr_comm_unique_id")
+        if world > 1:
+            t = torch.frombuffer(idbuf, dtype=torch.uint8)              # shares idbuf's memory
+            on_gpu = dist.get_backend(group) == "nccl"
+            tt = t.to(self.device) if on_gpu else t
+            dist.broadcast(tt, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            if on_gpu:
+                t.copy_(tt.cpu())
+        self.rank, self.world = int(rank), int(world)
+        self.handle = C.c_void_p()
+        with torch.cuda.device(self.device):
+            nat.check(lib.hsr_comm_init(self.rank, self.world, idbuf, C.byref(self.handle)), "hsr_comm_init")
+            # first collective now (connection set-up belongs here, not under the first pipelined tile)
+            probe = torch.ones(1, dtype=torch.float64, device=self.device)
+            self.allreduce_f64(probe)
+            torch.cuda.synchronize(self.device)
+            if int(probe.item()) != self.world:
+                raise nat.HsrError(f"hsr_comm: an all-reduce of ones over {self.world} rank(s) gave {probe.item()}")
+
+    def allreduce_f64(self, t):
+        """In-place sum of a contiguous float64 GPU tensor over the ranks, on the current stream."""
+        with _launch(t) as st:
+            nat.check(nat.load().hsr_allreduce_f64(self.handle, _ptr(t), t.numel(), st), "hsr_allreduce_f64")
+        return t
+
+    def reduce_f64(self, t, root: int = 0):
+        with _launch(t) as st:
+            nat.check(nat.load().hsr_reduce_f64(self.handle, _ptr(t), t.numel(), int(root), st), "hsr_reduce_f64")
+        return t
+
+    def allreduce_u32(self, t):
+        with _launch(t) as st:
+            nat.check(nat.load().hsr_allreduce_u32(self.handle, _ptr(t), t.numel(), st), "hsr_allreduce_u32")
+        return t
+
+    def bcast(self, t, root: int = 0):
+        with _launch(t) as st:
+            nat.check(nat.load().hsr_bcast(self.handle, _ptr(t), t.numel() * t.element_size(), int(root), st), "hsr_bcast")
+        return t
+
+    def close(self):
+        h, self.handle = self.handle, None
+        if h and nat._lib is not None:
+            nat._lib.hsr_comm_destroy(h)
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def probe_read_bandwidth(nbytes: int = 1 << 30, iters: int = 10, device="cuda:0", mode: int = 0) -> float:
     """Measured pure-read HBM rate of this box in bytes/s (diagnostic for the roofline report).
     mode 0: K1's own load shape (non-temporal LDS-DMA, 72 KiB slabs, 512 persistent workgroups) - a ceiling for K1;

@@ -71,6 +71,18 @@ class StepDesc(C.Structure):
                 ("apply_mask", _i32), ("clip", _i32), ("opts", SrfOptions)]
 
 
+HSR_ABI_VERSION = 5
+HSR_COMM_ID_BYTES = 128
+HSR_SYNC_ALLREDUCE, HSR_SYNC_BROADCAST = 1, 2
+# hsr_host_sum_fn: int (*)(void* user, double* values, int32_t count) - the host transport of an exchange pipeline
+HOST_SUM_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int32)
+
+
+class Exchange(C.Structure):
+    """hsr_exchange: how the fit crosses the ranks in hsr_pipeline_create_exchange (an RCCL communicator or a host callback)."""
+    _fields_ = [("comm", _vp), ("mode", _i32), ("root", _i32), ("host_sum", HOST_SUM_FN), ("host_user", _vp)]
+
+
 BATCH_RECORD_BYTES = 64          # sizeof(hsr_batch_tile) == sizeof(hsr_batch_unit)
 assert C.sizeof(BatchTile) == BATCH_RECORD_BYTES
 _popt = C.POINTER(SrfOptions)
@@ -162,6 +174,20 @@ SIGNATURES = {
     "hsr_pipeline_fit_done": (C.c_int, [_vp]),
     "hsr_pipeline_flush": (C.c_int, [_vp, _vp, _vp, _pi32]),
     "hsr_pipeline_count": (_i64, [_vp]),
+    "hsr_pipeline_create_exchange": (C.c_int, [C.POINTER(_vp), _vp, C.POINTER(Exchange), C.POINTER(_vp)]),
+    "hsr_pipeline_status": (C.c_int, [_vp, _vp, C.POINTER(C.c_uint32)]),
+    "hsr_srf_fused_launch_supported": (C.c_int, [_i32, _i32, _i32, _pi32, _pi32, _i64, _i32, _popt]),
+    "hsr_comm_available": (C.c_int, []),
+    "hsr_comm_version": (C.c_int, []),
+    "hsr_comm_unique_id": (C.c_int, [_vp]),
+    "hsr_comm_init": (C.c_int, [_i32, _i32, _vp, C.POINTER(_vp)]),
+    "hsr_comm_destroy": (C.c_int, [_vp]),
+    "hsr_comm_rank": (C.c_int, [_vp]),
+    "hsr_comm_ranks": (C.c_int, [_vp]),
+    "hsr_allreduce_f64": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "hsr_reduce_f64": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
+    "hsr_allreduce_u32": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "hsr_bcast": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -109,7 +109,7 @@ class SpectralFusion:
                  reserved_cus: Optional[int] = None, tile_pixels: int = 0, u16_single_buffer: bool = False,
                  u16_fast: bool = False, placement_trials: int = 0, fused_fit: bool = False,
                  placement_pitch_gb: float = eng.PLACEMENT_PITCH_GB, placement_budget_gb: Optional[float] = None,
-                 side_stream=None, fuse_apply: bool = False):
+                 side_stream=None, fuse_apply: bool = False, comm=None):
         """``placement_trials`` (default 0 = OFF: the plan allocates once and never synchronises with the host): opt in to
         the placement search of eng.placement_search for tiles of >= 65 536 pixels - up to min(4, trials) candidate output
         images on the first step()/submit()/step_batch() over a tile size, up to ``trials`` candidate (cube, target, image)
@@ -168,6 +168,7 @@ class SpectralFusion:
         # against 8.5 us + one launch gap for the separate hsr_moments_reduce_solve - 3 us per step slower.
         self.fused_fit = bool(fused_fit)
         self._pipe = None                            # state of submit()/flush(), created on first use
+        self.fused_fallback = None                   # why submit() fell back from a fused pipeline to the two-slot one, if it did
         # the stream the fits of submit() run on: None = chosen by measurement on the first submit (_pick_side_stream)
         self.side_stream = side_stream
         self.side_stream_log = None                  # us per pipelined step of each candidate stream, if measured
@@ -178,6 +179,15 @@ class SpectralFusion:
         # and, for uint16 tiles, a cube the ring kernel can load (16-byte aligned, 48 <= B <= 300); otherwise submit()
         # quietly uses the two-slot pipeline.
         self.fuse_apply = bool(fuse_apply)
+        # With an exchange, fuse_apply=True runs the FOUR-slot pipeline (hsr_pipeline_create_exchange): still one kernel per tile on
+        # the caller's stream - K3 of tile i-3 as a pre-phase, K1+K2 of tile i, the slot reduction of tile i-1 in the tail - while
+        # the side stream carries gate -> collective -> solve, all issued from C: no torch.distributed call per step, no event or
+        # stream wait on the caller's stream.  The collective is RCCL through the library's own communicator (``comm``: an
+        # eng.Comm, or None = built over ``group`` on first use) when the group's backend is nccl; with any other backend (gloo)
+        # the moments make a round trip through pinned host memory and torch.distributed sums them there (a host callback).
+        self._comm = comm
+        self._host_cb = None                         # the ctypes callback object of the host transport (kept alive with the plan)
+        self._backlog: List[FusionOutput] = []       # tiles finished by a pipeline rebuild, returned by the next submit() / drain()
         self._native: Dict[tuple, object] = {}       # prepared launches of step(), by _native_key
         self._native_handles: list = []              # ("plan" | "pipe", handle) to destroy with the plan
         self._pipe_images: Dict[int, list] = {}      # output images placed by place_inputs() for the pipeline's two slots
@@ -344,8 +354,51 @@ class SpectralFusion:
         self._pipe = None
         if lib is None:
             return
+        self._destroy_handles(handles)
+
+    @staticmethod
+    def _destroy_handles(handles):
+        lib = nat._lib
         for kind, h in reversed(handles):                       # pipelines before the plans they point to
             (lib.hsr_pipeline_destroy if kind == "pipe" else lib.hsr_step_plan_destroy)(h)
+
+    # ---- the exchange of an exchange pipeline ----------------------------------------------------------------------------
+    def comm(self):
+        """The library's own RCCL communicator over this plan's group (built on first use; collective over the group)."""
+        if self._comm is None:
+            import torch.distributed as dist
+            if not (dist.is_available() and dist.is_initialized()):
+                raise nat.HsrError("no torch.distributed group to carry the communicator's id")
+            self._comm = eng.Comm(self.group, self.device)
+        return self._comm
+
+    def _exchange_desc(self):
+        """hsr_exchange of this plan: RCCL from C for an nccl group, the host transport (pinned round trip + torch.distributed on the
+        CPU tensor, called from a runtime thread in stream order) for any other backend."""
+        import ctypes as C
+        import torch.distributed as dist
+        torch = nat.require_gpu()
+        x = nat.Exchange()
+        x.mode = nat.HSR_SYNC_BROADCAST if self.coeff_sync == "broadcast" else nat.HSR_SYNC_ALLREDUCE
+        x.root = 0
+        if self._comm is not None or dist.get_backend(self.group) == "nccl":
+            x.comm = self.comm().handle
+            x.host_sum = nat.HOST_SUM_FN(0)
+            return x, "rccl"
+        group = self.group
+
+        def host_sum(_user, values, count):
+            try:
+                t = torch.from_numpy(np.ctypeslib.as_array(values, shape=(int(count),)))
+                dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+                return 0
+            except BaseException:                      # never let an exception cross into the runtime's thread
+                return 1
+        self._host_cb = nat.HOST_SUM_FN(host_sum)
+        x.comm = None
+        x.host_sum = self._host_cb
+        x.mode = nat.HSR_SYNC_ALLREDUCE                # the host transport always sums everywhere; every rank solves
+        return x, "host"
 
     def __del__(self):
         try:
@@ -746,7 +799,12 @@ class SpectralFusion:
         import ctypes as C
         lib = nat.load()
         if self._pipe is not None:
-            self.flush()                                   # a tile of the previous shape still in flight: finish it
+            # tiles of the previous shape still in flight: finish them and keep their outputs - the next submit() / drain() calls
+            # return them first, in order (round 3 dropped them here: a mosaic with a ragged last tile lost one or two tiles)
+            self._backlog.extend(self.drain())
+            old, self._pipe = self._pipe, None
+            self._native_handles = [e for e in self._native_handles if not any(e[1] is h for _, h in old["handles"])]
+            self._destroy_handles(old["handles"])
         npix = cube.numel() // cube.shape[-1]
         real2, real_layout = self._real_image(real, npix)
         if not (real2.is_cuda and real2.dtype == torch.float32):
@@ -763,41 +821,58 @@ class SpectralFusion:
             placed = [eng.alloc_image(torch, nb, npix, self.layout, self.device) for _ in range(2)]
             if self.placement_trials > 1 and npix >= (1 << 16):
                 placed = self._place(npix, placed, probe, count=2)       # ONE search for both slots' images
-        # with an exchange the fit needs a collective between reduce and solve, which cannot ride in a kernel's tail: the
-        # two-slot pipeline (fit on the side stream) stays the multi-rank form
-        B = int(cube.shape[-1])
-        u16_ok = (cube.dtype != torch.float32 and cube.data_ptr() % 16 == 0 and 48 <= B <= 300 and not self.u16_single_buffer)
-        fused = (self.fuse_apply and self.layout == nat.PIXMAJOR and (cube.dtype == torch.float32 or u16_ok)
-                 and not self._exchanges())                # uint16 tiles: only the ring kernel carries the older tile's K3
-        if fused and len(placed) < 3:
-            placed = list(placed) + [eng.alloc_image(torch, nb, npix, self.layout, self.device)]
-        slots, outs = [], []
-        for k in range(3 if fused else 2):
+        # Three forms: two slots (fit on the side stream, K3 as its own launch); fused, three slots (one kernel per tile, fit in the
+        # tail: no exchange possible); fused with the exchange issued from C, four slots (hsr_pipeline_create_exchange).
+        # The C side decides whether a K1 launch of this geometry can carry the older tile's K3 (hsr_srf_fused_launch_supported, called
+        # by the create functions); what it cannot see is the cube pointer - uint16 tiles need the 16-byte aligned loader.
+        exchange = self._exchanges()
+        fused = (self.fuse_apply and self.layout == nat.PIXMAJOR and
+                 (cube.dtype == torch.float32 or (cube.data_ptr() % 16 == 0 and not self.u16_single_buffer)))
+        nslots = (4 if exchange else 3) if fused else 2
+        while len(placed) < nslots:
+            placed.append(eng.alloc_image(torch, nb, npix, self.layout, self.device))
+        slots, outs, handles = [], [], []
+        for k in range(nslots):
             ws = eng.MomentWorkspace(self.device, nb, self.deg)
             matched = eng.alloc_image(torch, nb, npix, self.layout, self.device)
             h, keep = self._native_plan(cube, real2, real_layout, placed[k], matched, ws)
+            handles.append(("plan", h))
             slots.append(dict(plan=h, ws=ws, keep=keep, mask=None))
             outs.append(FusionOutput(self.names, placed[k], ws.moments, ws.coeffs, matched, self.layout))
-        exchange = self._exchanges()
         if self.side_stream is not None:
             side = self.side_stream
-        elif fused:                                    # the fused pipeline has no side-stream work: nothing to choose
+        elif fused and not exchange:                   # the three-slot pipeline has no side-stream work: nothing to choose
             side = torch.cuda.Stream(device=self.device)
+        elif fused:                                    # gate -> collective -> solve: a queue of its own (high priority gets one)
+            side = torch.cuda.Stream(device=self.device, priority=-1)
         else:
             side = self._pick_side_stream(slots, cube, real2, mask)
         ph = C.c_void_p()
-        if fused:
+        transport = None
+        if fused and exchange:
+            x, transport = self._exchange_desc()
+            arr = (C.c_void_p * 4)(*[sl["plan"] for sl in slots])
+            rc = lib.hsr_pipeline_create_exchange(arr, C.c_void_p(side.cuda_stream), C.byref(x), C.byref(ph))
+        elif fused:
             rc = lib.hsr_pipeline_create_fused(slots[0]["plan"], slots[1]["plan"], slots[2]["plan"], C.c_void_p(side.cuda_stream),
-                                               1 if exchange else 0, C.byref(ph))
-            if rc != nat.HSR_OK:                       # geometry the fused launch does not cover: the two-slot pipeline
-                fused = False
-                slots, outs = slots[:2], outs[:2]
+                                               0, C.byref(ph))
+        if fused and rc != nat.HSR_OK:                 # geometry the fused launch does not cover: the two-slot pipeline
+            fused, transport = False, None
+            self.fused_fallback = nat.load().hsr_last_error().decode("utf-8", "replace")
+            for kind, h in reversed(handles[2:]):
+                lib.hsr_step_plan_destroy(h)
+            self._native_handles = [e for e in self._native_handles if not any(e[1] is h for _, h in handles[2:])]
+            slots, outs, handles = slots[:2], outs[:2], handles[:2]
+            if self.side_stream is None:
+                side = self._pick_side_stream(slots, cube, real2, mask)
         if not fused:
             nat.check(lib.hsr_pipeline_create(slots[0]["plan"], slots[1]["plan"], C.c_void_p(side.cuda_stream), 1 if exchange else 0,
                                               C.byref(ph)), "hsr_pipeline_create")
         self._native_handles.append(("pipe", ph))
+        handles.append(("pipe", ph))
         self._pipe = dict(key=key, npix=npix, h=ph, slots=slots, outs=outs, side=side, side_handle=C.c_void_p(side.cuda_stream),
-                          exchange=exchange, n=0, fin=C.c_int32(-1), fused=fused, S=len(slots), inflight=[])
+                          exchange=exchange, n=0, fin=C.c_int32(-1), fused=fused, S=len(slots), inflight=[], handles=handles,
+                          c_exchange=bool(fused and exchange), transport=transport)
         return self._pipe
 
     @staticmethod
@@ -810,7 +885,7 @@ class SpectralFusion:
 
     def submit(self, cube, real, mask=None, k1_events=None) -> Optional[FusionOutput]:
         """Pipelined step: start tile i, finish and return tile i-1 (None on the first call) - tile i-2 with
-        ``fuse_apply=True`` (None on the first two calls).  One call into the native
+        ``fuse_apply=True`` (None on the first two calls), tile i-3 with ``fuse_apply=True`` and an exchange.  One call into the native
         pipeline (csrc/hsr_exec.hip) enqueues K1(i) and K3(i-1) on the caller's stream and - without an exchange - the fit
         of tile i on the side stream; with an exchange the fit (slot reduction -> collective -> solve) is enqueued from
         here on the side stream."""
@@ -843,7 +918,7 @@ class SpectralFusion:
             slot = st["slots"][cur]
             slot["mask"] = mask                        # K3 of this tile reads it one submit() later
             slot["ws"].slots = lib.hsr_step_plan_slots(slot["plan"])
-            if st["exchange"]:
+            if st["exchange"] and not st["c_exchange"]:      # two slots: the collective goes through torch.distributed from here
                 sh = st["side_handle"]
                 with torch.cuda.stream(st["side"]):
                     nat.check(lib.hsr_step_run_reduce(slot["plan"], sh), "hsr_step_run_reduce")
@@ -855,21 +930,39 @@ class SpectralFusion:
                 nat.check(lib.hsr_pipeline_fit_done(st["h"]), "hsr_pipeline_fit_done")
         st["n"] += 1
         st["inflight"].append(cur)
-        if fin.value < 0:
-            return None
-        st["inflight"].remove(fin.value)
-        st["slots"][fin.value]["mask"] = None
-        return st["outs"][fin.value]
+        out = None
+        if fin.value >= 0:
+            st["inflight"].remove(fin.value)
+            st["slots"][fin.value]["mask"] = None
+            out = st["outs"][fin.value]
+        if self._backlog:                        # tiles a pipeline rebuild finished come first
+            if out is not None:
+                self._backlog.append(out)
+            out = self._backlog.pop(0)
+        return out
+
+    def pipeline_status(self) -> int:
+        """Exchange pipelines (fuse_apply with an exchange): synchronise both streams and return what the device-side polls and the
+        host transport recorded - 0, or 1 / 2 (a poll hit its 20 s limit: moments gate / coefficients of a K3), + 16 (the host
+        callback failed).  0 for the other pipelines."""
+        st = self._pipe
+        if st is None or not st.get("c_exchange"):
+            return 0
+        import ctypes as C
+        code = C.c_uint32(0)
+        with eng._launch(st["outs"][0].pseudo) as stream:
+            nat.check(nat.load().hsr_pipeline_status(st["h"], stream, C.byref(code)), "hsr_pipeline_status")
+        return int(code.value)
 
     def drain(self) -> List[FusionOutput]:
         """Finish (K3, on the caller's stream) every tile still in the pipeline, oldest first, and return their outputs."""
         st = self._pipe
+        outs, self._backlog = self._backlog, []
         if st is None or st["n"] == 0:
-            return []
+            return outs
         import ctypes as C
         lib = nat._lib or nat.load()
         fin = st["fin"]
-        outs = []
         with eng._launch(st["outs"][0].pseudo) as stream:
             while st["inflight"]:
                 slot = st["inflight"].pop(0)             # oldest first; its mask was kept with the slot

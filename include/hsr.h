@@ -26,7 +26,7 @@
 extern "C" {
 #endif
 
-#define HSR_ABI_VERSION 4
+#define HSR_ABI_VERSION 5
 
 #define HSR_OK 0
 #define HSR_ERR_INVALID 1      /* bad argument (shape, alignment, NULL)            */
@@ -137,6 +137,14 @@ typedef struct hsr_apply_job {
   unsigned int fit_ticket_base;  /* = number of workgroups of all earlier launches that used the counter (mod 2^32).  The launch   */
                                  /* must have >= nb workgroups (hsr_partial_slots(npix, opts) >= nb), else HSR_ERR_UNSUPPORTED         */
   int32_t reserved;
+  /* ABI 5 - exchange pipelines (hsr_pipeline_create_exchange): the fit crosses to another queue of the same GPU between the slot   */
+  /* reduction and the solve.  All three may be NULL (= ABI 4 behaviour).                                                           */
+  unsigned int* fit_ready_dev;   /* non-NULL: the tail fit stops at the moments (written through to memory, no solve) and adds 1 to   */
+                                 /* this word per finished band: nb additions = the tile's moments are complete                     */
+  const unsigned int* coeffs_ready_dev; /* non-NULL: coeffs_dev is written by a kernel of another queue; the pre-phase polls this   */
+  unsigned int coeffs_ready_value;      /* word until it has reached this value (wrap-safe >=), then reads the coefficients through */
+  unsigned int reserved2;
+  unsigned int* sync_error_dev;  /* optional: receives a non-zero code if a poll runs into its wall-clock limit (20 s)              */
 } hsr_apply_job;
 int hsr_srf_integrate_moments_apply(const float* cube_dev, int64_t npix, int32_t B,
                                     const float* wn_dev, const int32_t* k0, const int32_t* klen, int32_t nb,
@@ -148,6 +156,10 @@ int hsr_srf_integrate_moments_apply(const float* cube_dev, int64_t npix, int32_t
 /* The same for a cube in the uint16 tile format (hsr_srf_integrate_moments_u16's arguments + the job).  Only the ring kernel
  * carries a job: HSR_ERR_UNSUPPORTED unless the cube is 16-byte aligned, 48 <= B <= ~300, the weights fit LDS and the rows
  * are pixel-major. */
+/* HSR_OK if a K1 launch of this geometry can carry an apply job / tail fit (the conditions of the two entry points below except the
+ * cube pointer's alignment), HSR_ERR_UNSUPPORTED with the reason otherwise.  Host only; hsr_pipeline_create_fused / _exchange call it. */
+int hsr_srf_fused_launch_supported(int32_t cube_dtype, int32_t B, int32_t nb, const int32_t* k0, const int32_t* klen,
+                                   int64_t out_ps, int32_t deg, const hsr_srf_options* opts);
 int hsr_srf_integrate_moments_u16_apply(const uint16_t* cube_dev, int64_t npix, int32_t B, float scale, int32_t nodata,
                                         const float* wn_dev, const int32_t* k0, const int32_t* klen, int32_t nb,
                                         float* out_dev, int64_t out_bs, int64_t out_ps,
@@ -557,6 +569,68 @@ int hsr_pipeline_submit(hsr_pipeline* pipeline, const void* cube_dev, const floa
 int hsr_pipeline_fit_done(hsr_pipeline* pipeline);
 int hsr_pipeline_flush(hsr_pipeline* pipeline, const uint8_t* mask_dev, hsr_stream_t main_stream, int32_t* finished_slot);
 int64_t hsr_pipeline_count(const hsr_pipeline* pipeline);
+
+/* ---- C1 from C: the exchange of the fit over the GPUs of one node (ABI 5) -----------------------------------------
+ * One process per GPU; what crosses is the sum the reference forms per channel over the pixels it fits
+ * (s2_emit/poly_regression.py:59-60) when those pixels are spread over several ranks' tiles (the reference's own unit
+ * of work: tiles_helpers/utils.py:223-305): nb x (3deg+2) moment doubles per step.  RCCL's C API, bound at
+ * run time (dlopen of librccl.so.1 - inside a PyTorch process the copy torch has already mapped); without RCCL these
+ * return HSR_ERR_UNSUPPORTED and everything else works.
+ *   hsr_comm_unique_id   rank 0 fills HSR_COMM_ID_BYTES bytes (ncclGetUniqueId) and hands them to the other ranks by any
+ *                        means (a file, a socket, torch.distributed's store)
+ *   hsr_comm_init        ncclCommInitRank on the CURRENT device; collective over all ranks
+ *   hsr_allreduce_f64    in-place sum of `count` doubles over the ranks, stream ordered; every rank receives the same bits
+ *   hsr_reduce_f64       in-place sum to `root` (other ranks' buffers are left as they were)
+ *   hsr_allreduce_u32    in-place sum of uint32 (the histograms of the distributed percentile select, hsr_percentile_hist_region)
+ *   hsr_bcast            `bytes` bytes from root's buffer to everybody's
+ * A communicator is used by one host thread at a time; collectives must be issued in the same order on every rank. */
+#define HSR_COMM_ID_BYTES 128
+typedef struct hsr_comm hsr_comm;
+int hsr_comm_available(void);                      /* 1 if RCCL could be bound                                  */
+int hsr_comm_version(void);                        /* ncclGetVersion code (e.g. 22606), -1 without RCCL          */
+int hsr_comm_unique_id(void* id_out);
+int hsr_comm_init(int32_t rank, int32_t nranks, const void* unique_id, hsr_comm** comm_out);
+int hsr_comm_destroy(hsr_comm* comm);
+int hsr_comm_rank(const hsr_comm* comm);
+int hsr_comm_ranks(const hsr_comm* comm);
+int hsr_allreduce_f64(hsr_comm* comm, double* buf_dev, int64_t count, hsr_stream_t stream);
+int hsr_reduce_f64(hsr_comm* comm, double* buf_dev, int64_t count, int32_t root, hsr_stream_t stream);
+int hsr_allreduce_u32(hsr_comm* comm, uint32_t* buf_dev, int64_t count, hsr_stream_t stream);
+int hsr_bcast(hsr_comm* comm, void* buf_dev, int64_t bytes, int32_t root, hsr_stream_t stream);
+
+/* ---- the fused pipeline WITH an exchange (ABI 5) -------------------------------------------------------------------
+ * Four plans (four buffer sets); the caller's stream still carries ONE kernel per tile and no event or stream wait:
+ *     caller's stream :  [K3(i-3) | K1+K2(i) | slot reduction of tile i-1 in the tail]       (hsr_srf_integrate_moments[_u16]_apply)
+ *     side stream     :  gate(i-1) -> all-reduce of the moments of tile i-1 -> solve + publish      (under K1(i+1))
+ * The tail of launch i reduces the partial slots of tile i-1 (the first nb workgroups to finish, one band each - the tree of
+ * hsr_moments_reduce), writes the moments through to memory and counts the bands into a device word; `gate` is a one-wave
+ * kernel on the side stream that polls that word; the collective follows it in stream order; the solve publishes the
+ * coefficients by setting the tile's "ready" word, which the K3 pre-phase of launch i+2 polls (it has been set for a
+ * whole K1 by then) before it reads them.  Tiles whose launch cannot carry the reduction (fewer workgroups than bands,
+ * the last tiles at a drain) get it as a launch of their own; results are bit-identical to hsr_step_run with the same
+ * collective between reduce and solve.  hsr_pipeline_submit(i) finishes tile i-3; hsr_pipeline_flush the oldest
+ * unfinished tile per call.  Use plans with opts.reserved_cus > 0: the side stream's kernels need CUs that the
+ * persistent K1 leaves free.
+ *   mode HSR_SYNC_ALLREDUCE : hsr_allreduce_f64 of the moments, every rank solves (identical bits everywhere)
+ *   mode HSR_SYNC_BROADCAST : hsr_reduce_f64 to `root`, solve, hsr_bcast of the coefficients (the north star's wording)
+ *   host_sum != NULL (comm == NULL): any other transport - the moments travel to a pinned host buffer, host_sum(user, values,
+ *     count) must replace them by their sum over the ranks (called on a runtime thread in stream order; it must not call
+ *     HIP), and travel back; e.g. an MPI or gloo all-reduce.  Return 0 on success. */
+#define HSR_SYNC_ALLREDUCE 1
+#define HSR_SYNC_BROADCAST 2
+typedef int (*hsr_host_sum_fn)(void* user, double* values, int32_t count);
+typedef struct hsr_exchange {
+  hsr_comm* comm;
+  int32_t mode;
+  int32_t root;
+  hsr_host_sum_fn host_sum;
+  void* host_user;
+} hsr_exchange;
+int hsr_pipeline_create_exchange(hsr_step_plan* const* slots4, hsr_stream_t side_stream, const hsr_exchange* exchange,
+                                 hsr_pipeline** pipeline_out);
+/* Synchronises `main_stream` and the side stream and reports what the device-side polls and the host callback recorded:
+ * *sync_error_out = 0, or 1 (the gate of a tile's moments) / 2 (the coefficients of a K3 pre-phase) ran into the 20 s limit, + 16 = host_sum failed. */
+int hsr_pipeline_status(hsr_pipeline* pipeline, hsr_stream_t main_stream, uint32_t* sync_error_out);
 
 /* ---- diagnostics -------------------------------------------------------------------------------
  * Pure streaming read of `bytes` bytes (a multiple of 16, 16-byte aligned base): the measured HBM read ceiling of

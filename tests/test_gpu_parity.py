@@ -540,6 +540,115 @@ def test_rccl_exchange_path_single_rank(torch_gpu):
             dist.destroy_process_group()
 
 
+def _one_rank_rccl_group(torch):
+    """(created?, dist): a one-rank RCCL group on cuda:0 unless the process already has a group."""
+    import os
+    import torch.distributed as dist
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if dist.is_initialized():
+        return False, dist
+    dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29519", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    return True, dist
+
+
+def test_comm_c_abi_single_rank(torch_gpu):
+    """include/hsr.h hsr_comm_*: RCCL's C API behind the C ABI.  One rank on the box: the id round trip, init,
+    every collective stream-ordered and value-preserving, ranks / rank, destroy; argument errors come back as codes."""
+    torch = torch_gpu
+    import ctypes as C
+    from s2_emit import _engine as eng, _native as nat
+    lib = nat.load()
+    assert lib.hsr_comm_available() == 1 and lib.hsr_comm_version() >= 20000
+    c = eng.Comm(rank=0, world=1)
+    assert lib.hsr_comm_ranks(c.handle) == 1 and lib.hsr_comm_rank(c.handle) == 0
+    x = torch.arange(132, dtype=torch.float64, device="cuda") * 0.37
+    x0 = x.clone()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        c.allreduce_f64(x)
+        c.reduce_f64(x, 0)
+        c.bcast(x, 0)
+    side.synchronize()
+    assert torch.equal(x, x0)
+    h = torch.arange(4096, dtype=torch.int32, device="cuda")
+    c.allreduce_u32(h)
+    torch.cuda.synchronize()
+    assert torch.equal(h, torch.arange(4096, dtype=torch.int32, device="cuda"))
+    assert lib.hsr_allreduce_f64(c.handle, None, 4, None) == 1 and b"hsr_allreduce_f64" in lib.hsr_last_error()
+    assert lib.hsr_bcast(c.handle, C.c_void_p(x.data_ptr()), 8, 3, None) == 1
+    hh = C.c_void_p()
+    assert lib.hsr_comm_init(2, 2, (C.c_ubyte * 128)(), C.byref(hh)) == 1
+    c.close()
+
+
+def test_exchange_pipeline_from_c_single_rank(torch_gpu):
+    """The fused pipeline WITH an exchange (hsr_pipeline_create_exchange): one kernel per tile on the caller's
+    stream - K3 of tile i-3 as a pre-phase, K1+K2 of tile i, the slot reduction of tile i-1 in the tail - and gate -> RCCL
+    collective -> solve on the side stream, all issued from C.  One-rank RCCL communicator through the C ABI; every tile (three
+    submits late, the rest through drain()) carries the bits of its own step(): both sync modes, masks that come and go,
+    float32 and uint16 tiles, a tile of fewer 64-pixel groups than bands (its reduction runs as a launch of its own), a drain
+    in the middle of the stream, and the host transport (a gloo group: pinned round trip + callback).  No poll may time out."""
+    torch = torch_gpu
+    from s2_emit import SpectralFusion, _engine as eng
+    created, dist = _one_rank_rccl_group(torch)
+    try:
+        w, good = onp.synthetic_wavelengths()
+        srf = onp.synthetic_srf()
+        g = torch.Generator(device="cuda")
+        g.manual_seed(23)
+        gloo = dist.new_group(backend="gloo")
+        for (H, W), u16 in (((70, 61), False), ((40, 64), True), ((3, 90), False)):
+            npix = H * W
+            cubes = [torch.rand((H, W, 285), generator=g, device="cuda") * 0.6 for _ in range(3)]
+            if u16:
+                cubes = [eng.tile_encode_u16(c) for c in cubes]
+                cubes[1].view(torch.int16)[3, 5, 100] = -1                      # nodata
+            reals = [torch.rand((H, W, 12), generator=g, device="cuda") for _ in range(3)]
+            masks = [None, (torch.rand(npix, generator=g, device="cuda") > 0.3).to(torch.uint8), None,
+                     (torch.rand(npix, generator=g, device="cuda") > 0.6).to(torch.uint8), None]
+            for mode, group in (("allreduce", None), ("broadcast", None), ("allreduce", gloo)):
+                for deg in (1, 3):
+                    kw = dict(deg=deg, min_valid=0.0, min_count=5, apply_mask=True)
+                    ref = SpectralFusion(w, srf, good, coeff_sync="local", **kw)
+                    pipe = SpectralFusion(w, srf, good, coeff_sync=mode, force_exchange=True, fuse_apply=True, group=group, **kw)
+                    assert pipe.opts.reserved_cus == 8
+                    seq = [(cubes[i % 3], reals[i % 3], masks[i % 5]) for i in range(9)]
+                    got = []
+
+                    def keep(o):
+                        got.append(tuple(t.clone() for t in (o.pseudo, o.matched, o.moments, o.coeffs)))
+                    for i, (c, r, m) in enumerate(seq):
+                        o = pipe.submit(c, r, m)
+                        if i == 5:                                                 # a drain in mid-stream, then on
+                            assert o is not None
+                            keep(o)
+                            for o in pipe.drain():
+                                keep(o)
+                            assert len(got) == 6
+                            continue
+                        assert (o is None) == (i < 3 or 6 <= i < 9), (i, o is None)
+                        if o is not None:
+                            keep(o)
+                    st = pipe._pipe
+                    assert st["fused"] and st["S"] == 4 and st["c_exchange"] and st["transport"] == ("host" if group is not None else "rccl")
+                    for o in pipe.drain():
+                        keep(o)
+                    assert len(got) == len(seq) and pipe.drain() == []
+                    assert pipe.pipeline_status() == 0
+                    for i, ((c, r, m), gt) in enumerate(zip(seq, got)):
+                        want = ref.step(c, r, m, reuse_buffers=False)
+                        tag = (H, W, u16, mode, deg, i)
+                        assert torch.equal(gt[0].view(torch.int32), want.pseudo.view(torch.int32)), tag + ("pseudo",)
+                        assert torch.equal(gt[2].view(torch.int64), want.moments.view(torch.int64)), tag + ("moments",)
+                        assert torch.equal(gt[3].view(torch.int64), want.coeffs.view(torch.int64)), tag + ("coeffs",)
+                        assert torch.equal(gt[1].view(torch.int32), want.matched.view(torch.int32)), tag + ("matched",)
+                    pipe.close()
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 # ---------------------------------------------------------------------------------------------
 # variant a9: multivariate polynomial ridge on the matrix cores
 # ---------------------------------------------------------------------------------------------

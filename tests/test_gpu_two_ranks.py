@@ -55,8 +55,21 @@ def _worker(rank, port, mode, q):
         b_res = (b.coeffs.cpu().numpy().copy(), b.matched.cpu().numpy().copy())
         c = plan.flush()
         c_res = (c.coeffs.cpu().numpy(), c.matched.cpu().numpy())
+        # the fused pipeline with the exchange issued from C (hsr_pipeline_create_exchange): one kernel per tile on the caller's
+        # stream; under gloo the moments cross through the host transport (pinned round trip + callback on a runtime thread)
+        fplan = SpectralFusion(w, srf, good, deg=DEG, coeff_sync=mode, fuse_apply=True)
+        f_res = []
+        for i in range(6):
+            o = fplan.submit(Rd, reald)
+            assert (o is None) == (i < 3)
+            if o is not None:
+                f_res.append((o.coeffs.cpu().numpy().copy(), o.matched.cpu().numpy().copy(), o.moments.cpu().numpy().copy()))
+        f_res += [(o.coeffs.cpu().numpy().copy(), o.matched.cpu().numpy().copy(), o.moments.cpu().numpy().copy()) for o in fplan.drain()]
+        st = fplan._pipe
+        assert st["S"] == 4 and st["c_exchange"] and st["transport"] == "host" and len(f_res) == 6
+        assert fplan.pipeline_status() == 0
         torch.cuda.synchronize()
-        q.put((rank, step_res, b_res, c_res))
+        q.put((rank, step_res, b_res, c_res, f_res))
     finally:
         dist.destroy_process_group()
 
@@ -91,7 +104,11 @@ def test_two_ranks_fit_the_union_of_their_tiles(mode):
     ref_matched = ref.matched.cpu().numpy()
     npix = H * W
     for r in range(WORLD):
-        (co, matched, mom), (co_b, matched_b), (co_c, matched_c) = res[r]
+        (co, matched, mom), (co_b, matched_b), (co_c, matched_c), f_res = res[r]
+        for co_f, matched_f, mom_f in f_res:           # the four-slot pipeline: the bits of step() on the same rank, every tile
+            np.testing.assert_array_equal(co_f, co)
+            np.testing.assert_array_equal(matched_f, matched)
+            np.testing.assert_array_equal(mom_f, mom if mode == "allreduce" else mom_f)
         # same moments up to the grouping of the partial sums -> same polynomial
         if mode == "allreduce" or r == 0:        # "broadcast" reduces to rank 0 only: the other ranks never see the sums
             np.testing.assert_allclose(mom, ref.moments.cpu().numpy(), rtol=1e-12)

@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, n), f"{n} declared in include/hsr.h but not exported"
         assert n in nat.SIGNATURES, f"{n} has no ctypes signature in _native.py"
     assert set(nat.SIGNATURES) == set(names)
-    assert lib.hsr_abi_version() == 4
+    assert lib.hsr_abi_version() == 5
 
 
 def test_sizing_helpers_and_error_strings():

@@ -105,6 +105,11 @@ def parse_args(argv=None):
     ap.add_argument("--event-every", type=int, default=4,
                     help="bracket the K1+K2 kernel with HIP events on every n-th timed step (each pair of event "
                          "records costs ~12 us of launch gap, so not on every step)")
+    ap.add_argument("--fake-collective-us", type=float, default=0.0,
+                    help="rehearsal only (with --force-exchange): a one-rank RCCL all-reduce launches no kernel, so a stand-in kernel "
+                         "(--fake-collective-blocks workgroups of 256 threads and 48 KB of LDS) stays resident on the side stream for "
+                         "this many microseconds where the collective of an N-rank run would run")
+    ap.add_argument("--fake-collective-blocks", type=int, default=2)
     ap.add_argument("--launcher", action="store_true",
                     help="take the parent -> torchrun -> rank path also at N = 1 (with --force-exchange the child then creates its "
                          "one-rank RCCL group exactly as the ranks of an N > 1 run do): rehearses the launcher on a one-GPU box")
@@ -452,7 +457,9 @@ def main(argv=None):
                               # pipeline's fit; the fused pipeline without an exchange has no side-stream work
                               reserved_cus=(args.reserve_cus if (exchanging or not fused) else 0) if pipelined else 0,
                               u16_fast=args.u16_fast, fused_fit=args.fused_fit, placement_trials=trials,
-                              placement_budget_gb=args.placement_budget_gb, fuse_apply=fused, comm=comm)
+                              placement_budget_gb=args.placement_budget_gb, fuse_apply=fused, comm=comm,
+                              rehearsal_collective=(args.fake_collective_us, args.fake_collective_blocks)
+                              if (args.force_exchange and args.fake_collective_us > 0) else None)
     real = prob.real            # (H, W, row) band-last, like the cube and the reference's (H, W, C) images
     cube = prob.cube
     if args.cube == "u16":      # quantise once, outside the timed region (the writer's arithmetic, on the device)
@@ -650,6 +657,8 @@ def main(argv=None):
                                          "(no side stream, no events, no reserved CUs); " + str(fused_note)) if fused else
                                         f"one tile deep (two slots, fit on a side stream), {args.reserve_cus} CUs reserved") if pipelined else "off",
                            "exchange_transport": (plan._pipe or {}).get("transport") if pipelined else None,
+                           "fake_collective": ({"us": args.fake_collective_us, "blocks": args.fake_collective_blocks}
+                                               if (args.force_exchange and args.fake_collective_us > 0) else None),
                            "settle": {"ms": args.settle_ms, "untimed_steps": settle_steps,
                                       "note": "untimed load before the W warm-up steps: from idle a 20-step region sits in a "
                                               "power-management transient 6-10 % slower than the continuous-load state"},

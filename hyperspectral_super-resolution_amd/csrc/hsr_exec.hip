@@ -40,6 +40,8 @@ struct hsr_pipeline {
   unsigned int* sync;             // device words: [0] tickets (= counter), [1] bands whose moments are published, [2] error code,
                                   //               [4 + k] "coefficients ready" word of slot k (holds the sequence number of its tile)
   unsigned int published;         // value sync[1] reaches once every reduction enqueued so far has run (nb per tile)
+  int deferred;                   // slot whose solve + publish is not enqueued yet: it rides in the launch that gates the NEXT tile's
+  int deferred_solve;             // collective (one side-stream launch per step instead of two), or goes out alone at a drain; -1: none
   double* host_moments[4];        // pinned staging of the host_sum transport, one per slot
   struct host_job { hsr_pipeline* pl; double* values; int32_t count; } host_jobs[4];
   volatile int host_error;        // host_sum returned non-zero
@@ -60,11 +62,24 @@ __global__ __launch_bounds__(64) void publish_add_kernel(unsigned int* word, uns
   if (threadIdx.x == 0) __hip_atomic_fetch_add(word, n, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// Rehearsal stand-in for the collective's kernel on a one-GPU box (hsr_exchange.rehearsal_us): resident for `us` microseconds with
+// the footprint of a small RCCL kernel, computes nothing.
+__global__ __launch_bounds__(256) void rehearsal_collective_kernel(int us, unsigned int* sink) {
+  __shared__ unsigned int lds[12288];          // 48 KB
+  lds[threadIdx.x] = threadIdx.x;
+  __syncthreads();
+  const unsigned long long t0 = hsr::sync_realtime();
+  while (hsr::sync_realtime() - t0 < (unsigned long long)us * 100ull) __builtin_amdgcn_s_sleep(8);
+  if (lds[(threadIdx.x * 7) & 255] == 0xffffffffu) *sink = 1u;      // never true: keeps the LDS allocation
+}
+
 // np.polyfit from the (all-reduced) moments, one thread per band - solve_kernel of hsr_poly.hip, hence its bits - and then the
 // publication: coefficients written through to memory, stores waited for, the slot's "ready" word set to the tile's sequence
 // number.  do_solve = 0: publish only (the coefficients came by broadcast).
+// gate_word != NULL: the kernel then goes on as the NEXT tile's gate (one launch per step on the side stream instead of two).
 __global__ __launch_bounds__(64) void solve_publish_kernel(const double* __restrict__ moments, int nb, int deg, long long min_count,
-                                                           double* coeffs, int do_solve, unsigned int* ready, unsigned int value) {
+                                                           double* coeffs, int do_solve, unsigned int* ready, unsigned int value,
+                                                           const unsigned int* gate_word, unsigned int gate_target, unsigned int* err) {
   const int b = threadIdx.x;
   if (do_solve && b < nb) {
     double c[HSR_MAX_DEG + 1];
@@ -74,7 +89,10 @@ __global__ __launch_bounds__(64) void solve_publish_kernel(const double* __restr
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  if (threadIdx.x == 0) hsr::st_agent_u32(ready, value);
+  if (threadIdx.x == 0) {
+    hsr::st_agent_u32(ready, value);
+    if (gate_word) hsr::wait_word_at_least(gate_word, gate_target, err, 1u);
+  }
 }
 
 int run_k1(hsr_step_plan* p, const void* cube, const float* real, const uint8_t* mask, hipStream_t s,
@@ -216,6 +234,8 @@ static int pipeline_new(hsr_step_plan* const* sl, int nslots, hsr_stream_t side_
   pl->tickets = pl->published = 0;
   pl->x = hsr_exchange{};
   pl->host_error = 0;
+  pl->deferred = -1;
+  pl->deferred_solve = 0;
   for (int k = 0; k < nslots; ++k) {
     pl->slot[k]->pending = pl->slot[k]->fitted = pl->slot[k]->exchanged = false;
     pl->slot[k]->seq = 0;
@@ -280,6 +300,8 @@ extern "C" int hsr_pipeline_create_exchange(hsr_step_plan* const* slots4, hsr_st
   HSR_REQUIRE((x->comm != nullptr) != (x->host_sum != nullptr), HSR_ERR_INVALID, "%s: exactly one of comm and host_sum must be given", who);
   HSR_REQUIRE(x->mode == HSR_SYNC_ALLREDUCE || x->mode == HSR_SYNC_BROADCAST, HSR_ERR_INVALID, "%s: mode %d", who, x->mode);
   HSR_REQUIRE(!x->comm || (x->root >= 0 && x->root < hsr_comm_ranks(x->comm)), HSR_ERR_INVALID, "%s: root %d", who, x->root);
+  HSR_REQUIRE(x->rehearsal_us >= 0 && x->rehearsal_us <= 1000 && x->rehearsal_blocks >= 0 && x->rehearsal_blocks <= 64, HSR_ERR_INVALID,
+              "%s: rehearsal stand-in of %d us x %d blocks (at most 1000 us, 64 blocks)", who, x->rehearsal_us, x->rehearsal_blocks);
   int rc = fused_geometry(slots4, 4, who);
   if (rc != HSR_OK) return rc;
   hsr_pipeline* pl = nullptr;
@@ -344,15 +366,31 @@ static int reduce_and_publish(hsr_pipeline* pl, hsr_step_plan* p, hipStream_t ma
   return HSR_OK;
 }
 
+// solve + publish of the deferred slot, optionally going on as the gate of the next tile's collective
+static int launch_solve_publish(hsr_pipeline* pl, bool with_gate) {
+  hsr_step_plan* p = pl->slot[pl->deferred];
+  const hsr_step_desc& d = p->d;
+  hipLaunchKernelGGL(solve_publish_kernel, dim3(1), dim3(64), 0, pl->side, d.moments_dev, d.nb, d.deg, (long long)d.min_count, d.coeffs_dev,
+                     pl->deferred_solve, pl->sync + 4 + pl->deferred, p->seq, with_gate ? pl->sync + 1 : nullptr, pl->published, pl->sync + 2);
+  HSR_LAUNCH_CHECK("solve_publish_kernel");
+  pl->deferred = -1;
+  return HSR_OK;
+}
+
 // gate -> collective -> solve + publish of the tile in slot k, on the side stream.  Called once per tile, in tile order, on every
-// rank: the collectives of all ranks line up.
+// rank: the collectives of all ranks line up.  The solve + publish itself is enqueued with the NEXT tile's gate (or by a drain).
 static int enqueue_exchange(hsr_pipeline* pl, int k) {
   hsr_step_plan* p = pl->slot[k];
   const hsr_step_desc& d = p->d;
   const int64_t nmom = (int64_t)d.nb * hsr::moment_count(d.deg);
-  hipLaunchKernelGGL(gate_kernel, dim3(1), dim3(64), 0, pl->side, pl->sync + 1, pl->published, pl->sync + 2, 1u);
-  HSR_LAUNCH_CHECK("gate_kernel");
   int rc = HSR_OK;
+  if (pl->deferred >= 0) {
+    rc = launch_solve_publish(pl, true);       // the previous tile's solve, then this tile's gate
+    if (rc != HSR_OK) return rc;
+  } else {
+    hipLaunchKernelGGL(gate_kernel, dim3(1), dim3(64), 0, pl->side, pl->sync + 1, pl->published, pl->sync + 2, 1u);
+    HSR_LAUNCH_CHECK("gate_kernel");
+  }
   int solve_here = 1;
   if (pl->x.host_sum) {
     double* h = pl->host_moments[k];
@@ -370,9 +408,13 @@ static int enqueue_exchange(hsr_pipeline* pl, int k) {
     solve_here = 0;
   }
   if (rc != HSR_OK) return rc;
-  hipLaunchKernelGGL(solve_publish_kernel, dim3(1), dim3(64), 0, pl->side, d.moments_dev, d.nb, d.deg, (long long)d.min_count, d.coeffs_dev,
-                     solve_here, pl->sync + 4 + k, p->seq);
-  HSR_LAUNCH_CHECK("solve_publish_kernel");
+  if (pl->x.rehearsal_us > 0) {
+    hipLaunchKernelGGL(rehearsal_collective_kernel, dim3(pl->x.rehearsal_blocks > 0 ? pl->x.rehearsal_blocks : 1), dim3(256), 0, pl->side,
+                       (int)pl->x.rehearsal_us, pl->sync + 3);
+    HSR_LAUNCH_CHECK("rehearsal_collective_kernel");
+  }
+  pl->deferred = k;
+  pl->deferred_solve = solve_here;
   p->exchanged = true;
   return HSR_OK;
 }
@@ -450,6 +492,7 @@ static int finish_exchange_slot(hsr_pipeline* pl, int k, const uint8_t* mask, hi
   int rc = HSR_OK;
   if (!p->fitted) rc = reduce_and_publish(pl, p, main);
   if (rc == HSR_OK && !p->exchanged) rc = enqueue_exchange(pl, k);
+  if (rc == HSR_OK && pl->deferred >= 0) rc = launch_solve_publish(pl, false);     // (this tile's, or a later one's: at most one is deferred)
   if (rc != HSR_OK) return rc;
   // (an EVENT here, not a polling gate: this is a drain, a bubble costs nothing - and a wave spinning on the caller's stream would
   // deadlock, until its time limit, against side-stream work queued behind it if the runtime serves both streams from one

@@ -80,7 +80,8 @@ HOST_SUM_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.POINTER(C.c_double), C.c_int32)
 
 class Exchange(C.Structure):
     """hsr_exchange: how the fit crosses the ranks in hsr_pipeline_create_exchange (an RCCL communicator or a host callback)."""
-    _fields_ = [("comm", _vp), ("mode", _i32), ("root", _i32), ("host_sum", HOST_SUM_FN), ("host_user", _vp)]
+    _fields_ = [("comm", _vp), ("mode", _i32), ("root", _i32), ("host_sum", HOST_SUM_FN), ("host_user", _vp),
+                ("rehearsal_us", _i32), ("rehearsal_blocks", _i32)]
 
 
 BATCH_RECORD_BYTES = 64          # sizeof(hsr_batch_tile) == sizeof(hsr_batch_unit)

@@ -109,7 +109,7 @@ class SpectralFusion:
                  reserved_cus: Optional[int] = None, tile_pixels: int = 0, u16_single_buffer: bool = False,
                  u16_fast: bool = False, placement_trials: int = 0, fused_fit: bool = False,
                  placement_pitch_gb: float = eng.PLACEMENT_PITCH_GB, placement_budget_gb: Optional[float] = None,
-                 side_stream=None, fuse_apply: bool = False, comm=None):
+                 side_stream=None, fuse_apply: bool = False, comm=None, rehearsal_collective=None):
         """``placement_trials`` (default 0 = OFF: the plan allocates once and never synchronises with the host): opt in to
         the placement search of eng.placement_search for tiles of >= 65 536 pixels - up to min(4, trials) candidate output
         images on the first step()/submit()/step_batch() over a tile size, up to ``trials`` candidate (cube, target, image)
@@ -186,6 +186,9 @@ class SpectralFusion:
         # eng.Comm, or None = built over ``group`` on first use) when the group's backend is nccl; with any other backend (gloo)
         # the moments make a round trip through pinned host memory and torch.distributed sums them there (a host callback).
         self._comm = comm
+        # one-GPU rehearsals only: (microseconds, workgroups) of a stand-in kernel enqueued where the collective's kernel would run
+        # (hsr_exchange.rehearsal_us; a one-rank RCCL all-reduce launches nothing)
+        self.rehearsal_collective = rehearsal_collective
         self._host_cb = None                         # the ctypes callback object of the host transport (kept alive with the plan)
         self._backlog: List[FusionOutput] = []       # tiles finished by a pipeline rebuild, returned by the next submit() / drain()
         self._native: Dict[tuple, object] = {}       # prepared launches of step(), by _native_key
@@ -381,6 +384,8 @@ class SpectralFusion:
         x = nat.Exchange()
         x.mode = nat.HSR_SYNC_BROADCAST if self.coeff_sync == "broadcast" else nat.HSR_SYNC_ALLREDUCE
         x.root = 0
+        if self.rehearsal_collective:
+            x.rehearsal_us, x.rehearsal_blocks = int(self.rehearsal_collective[0]), int(self.rehearsal_collective[1])
         if self._comm is not None or dist.get_backend(self.group) == "nccl":
             x.comm = self.comm().handle
             x.host_sum = nat.HOST_SUM_FN(0)

@@ -625,6 +625,12 @@ typedef struct hsr_exchange {
   int32_t root;
   hsr_host_sum_fn host_sum;
   void* host_user;
+  /* Rehearsal on ONE GPU only (0 in production): a one-rank RCCL all-reduce launches no kernel, so nothing stands where the
+   * collective of an N-rank run would run next to K1.  rehearsal_us > 0 enqueues, behind the collective call, a stand-in kernel of
+   * rehearsal_blocks workgroups (256 threads, 48 KB of LDS each - the footprint of a small RCCL kernel) that stays resident for
+   * that many microseconds; it computes nothing and touches no data. */
+  int32_t rehearsal_us;
+  int32_t rehearsal_blocks;
 } hsr_exchange;
 int hsr_pipeline_create_exchange(hsr_step_plan* const* slots4, hsr_stream_t side_stream, const hsr_exchange* exchange,
                                  hsr_pipeline** pipeline_out);

@@ -161,6 +161,32 @@ def test_bench_rccl_on_too_few_gpus_fails_fast():
     assert time.time() - t0 < 120          # dominated by `import torch` on a fresh box
 
 
+def test_bench_real_launcher_path_with_rccl_at_n1():
+    """The path an N > 1 run takes, on the one-GPU box: `python bench.py --gpus 1 --launcher --force-exchange`
+    UN-WRAPPED - the parent (which must not initialise the GPU: it counts devices from KFD's sysfs topology) starts
+    `python -m torch.distributed.run`, the rank creates its RCCL group from the launcher's rendezvous, builds the library's own
+    communicator (hsr_comm_init) and runs the four-slot exchange pipeline; the parent relays the single JSON line."""
+    import json
+    r = _bench("--gpus", "1", "--launcher", "--force-exchange", "--steps", "3", "--warmup", "1", "--settle-ms", "5", "--no-probe",
+               "--no-cpu-baseline", "--placement-trials", "0", "--cold-steps", "0")
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = r.stdout.strip().splitlines()
+    assert len(lines) == 1, lines
+    line = json.loads(lines[0])
+    assert line["rccl_ranks"] == 1 and line["world_size"] == 1 and line["n_gpus"] == 1
+    assert line["config"]["exchange_transport"] == "rccl" and "exchange issued from C" in line["config"]["pipeline"]
+    assert line["value"] > 0 and line["roofline"]["frac"] > 0.3
+    # the parent never loaded torch.cuda / HIP: its device count comes from sysfs
+    sys.path.insert(0, ROOT)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    assert bench.visible_gpu_count() >= 1
+    import inspect
+    assert "import torch" not in inspect.getsource(bench.self_launch) and "torch" not in inspect.getsource(bench.visible_gpu_count)
+
+
 def test_bench_n1_reports_cold_beside_placed():
     """The driver's N = 1 command: cold (first allocations, no trials, no settle) and placed numbers in one line, the
     traffic figure labelled with its source."""

@@ -141,14 +141,18 @@ def visible_gpu_count() -> int:
     if not os.path.isdir("/sys/class/kfd"):            # no amdgpu / KFD driver on this machine at all
         return 0
     try:
-        n = 0
-        for node in os.listdir(base):
+        nodes = os.listdir(base)
+    except OSError:
+        return -1
+    n = 0
+    for node in nodes:
+        try:
             with open(os.path.join(base, node, "properties")) as f:
                 props = dict(ln.split(None, 1) for ln in f.read().splitlines() if " " in ln)
             if int(props.get("simd_count", "0")) > 0:
                 n += 1
-    except (OSError, ValueError):
-        return -1
+        except (OSError, ValueError):
+            pass                                       # a GPU this container was not given reads as EPERM (device cgroup): not ours
     try:                                               # a container is usually handed only its own render nodes
         rn = len([d for d in os.listdir("/dev/dri") if d.startswith("renderD")])
         if rn > 0:
@@ -412,6 +416,13 @@ def main(argv=None):
     comm = eng.Comm(None, device) if exchanging and (args.backend == "nccl" or args.force_exchange) and args.coeff_sync != "local" else None
     exchanging = exchanging and args.coeff_sync != "local"
     want_fused = ntl == 1 and not args.fused_fit and args.pipeline in ("fused", "auto")
+    if exchanging and args.same_device and args.pipeline == "auto":
+        # ranks SHARING a GPU (control-flow rehearsal): a K1 launch of the exchange pipeline that polls for its coefficients holds
+        # the whole chip, the other rank's K1 - whose tail has to publish the moments everybody waits for - gets no CU, and only the
+        # polls' 20 s limit ends it (seen in round 4).  One GPU per rank is the pipeline's premise; the rehearsal takes two slots.
+        want_fused = False
+    if exchanging and want_fused and args.reserve_cus < 8:
+        raise SystemExit("[bench] the exchange pipeline needs --reserve-cus >= 8 (one free CU per XCD for the collective and the solve)")
     reserve = args.reserve_cus if exchanging else 0      # CUs kept free for the side stream's kernels (gate, collective, solve)
     fused_note = None
     if want_fused:

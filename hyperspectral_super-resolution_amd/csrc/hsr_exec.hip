@@ -304,6 +304,11 @@ extern "C" int hsr_pipeline_create_exchange(hsr_step_plan* const* slots4, hsr_st
               "%s: rehearsal stand-in of %d us x %d blocks (at most 1000 us, 64 blocks)", who, x->rehearsal_us, x->rehearsal_blocks);
   int rc = fused_geometry(slots4, 4, who);
   if (rc != HSR_OK) return rc;
+  // Not a tuning matter: a K1 launch whose pre-phase polls for coefficients holds every CU it runs on while it waits, and the
+  // kernels it waits for (the collective, the solve) are dispatched next to it only where an XCD has a completely free CU
+  // (measured in round 2).  With fewer free CUs a late peer turns into a wait that only the polls' time limit ends.
+  HSR_REQUIRE(slots4[0]->d.opts.reserved_cus >= 8, HSR_ERR_INVALID, "%s: the plans must leave at least 8 CUs free (hsr_srf_options.reserved_cus >= 8, one "
+              "per XCD) for the side stream's kernels; got %d", who, slots4[0]->d.opts.reserved_cus);
   hsr_pipeline* pl = nullptr;
   rc = pipeline_new(slots4, 4, side_stream, 1, &pl, who);
   if (rc != HSR_OK) return rc;

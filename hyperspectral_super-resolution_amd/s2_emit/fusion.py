@@ -24,6 +24,7 @@ from . import _engine as eng
 from . import _native as nat
 
 COEFF_SYNC_MODES = ("local", "allreduce", "broadcast")
+_HOST_GROUPS: Dict[int, object] = {}     # gloo groups of the host transport (one per caller's group), see SpectralFusion._exchange_desc
 
 
 def _tkey(t):
@@ -390,7 +391,18 @@ class SpectralFusion:
             x.comm = self.comm().handle
             x.host_sum = nat.HOST_SUM_FN(0)
             return x, "rccl"
-        group = self.group
+        # A process group of ITS OWN for the callback thread: its collectives are ordered by the side stream - the same order on
+        # every rank - while the caller's thread goes on using ``group`` (barriers, its own all-reduces).  Sharing one group let the
+        # two threads' collectives pair up differently on different ranks (seen as a gloo abort in bench.py's rehearsal, whose
+        # barrier raced the last tiles' sums).  dist.new_group is collective over the default group: plans are built in the same
+        # order on every rank (SPMD), as the RCCL communicator requires too.
+        world_pg = dist.distributed_c10d._get_default_group()
+        key = id(self.group)
+        ent = _HOST_GROUPS.get(key)
+        if ent is None or ent[0] is not world_pg:          # (a cached group dies with the default group it was made from)
+            ranks = None if self.group is None else dist.get_process_group_ranks(self.group)
+            ent = _HOST_GROUPS[key] = (world_pg, dist.new_group(ranks=ranks, backend="gloo"))
+        group = ent[1]
 
         def host_sum(_user, values, count):
             try:

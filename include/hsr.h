@@ -583,7 +583,10 @@ int64_t hsr_pipeline_count(const hsr_pipeline* pipeline);
  *   hsr_reduce_f64       in-place sum to `root` (other ranks' buffers are left as they were)
  *   hsr_allreduce_u32    in-place sum of uint32 (the histograms of the distributed percentile select, hsr_percentile_hist_region)
  *   hsr_bcast            `bytes` bytes from root's buffer to everybody's
- * A communicator is used by one host thread at a time; collectives must be issued in the same order on every rank. */
+ * A communicator is used by one host thread at a time; collectives must be issued in the same order on every rank.
+ * In a process that also uses PyTorch, import torch BEFORE the first hsr_comm_* call: the library binds the librccl.so.1 that is
+ * already mapped (torch ships its own); the other order leaves two RCCL / rocm_smi copies in the process, which ends in a
+ * double free inside rocm_smi's static destructors at exit. */
 #define HSR_COMM_ID_BYTES 128
 typedef struct hsr_comm hsr_comm;
 int hsr_comm_available(void);                      /* 1 if RCCL could be bound                                  */
@@ -609,8 +612,9 @@ int hsr_bcast(hsr_comm* comm, void* buf_dev, int64_t bytes, int32_t root, hsr_st
  * whole K1 by then) before it reads them.  Tiles whose launch cannot carry the reduction (fewer workgroups than bands,
  * the last tiles at a drain) get it as a launch of their own; results are bit-identical to hsr_step_run with the same
  * collective between reduce and solve.  hsr_pipeline_submit(i) finishes tile i-3; hsr_pipeline_flush the oldest
- * unfinished tile per call.  Use plans with opts.reserved_cus > 0: the side stream's kernels need CUs that the
- * persistent K1 leaves free.
+ * unfinished tile per call.  The plans must have opts.reserved_cus >= 8 (HSR_ERR_INVALID otherwise): a K1 launch whose pre-phase
+ * polls holds its CUs while it waits, and what it waits for - the collective's kernel, the solve - is only dispatched next to
+ * it where an XCD has a free CU.  One GPU per rank: two ranks sharing a GPU starve each other's K1 the same way (big tiles).
  *   mode HSR_SYNC_ALLREDUCE : hsr_allreduce_f64 of the moments, every rank solves (identical bits everywhere)
  *   mode HSR_SYNC_BROADCAST : hsr_reduce_f64 to `root`, solve, hsr_bcast of the coefficients (the north star's wording)
  *   host_sum != NULL (comm == NULL): any other transport - the moments travel to a pinned host buffer, host_sum(user, values,

@@ -153,6 +153,47 @@ def test_batch_plan_host_side():
     assert lib.hsr_batch_plan(tiles, T, nb, deg, None, None, None, 0, ctypes.byref(info)) == 1 and b"16-byte" in lib.hsr_last_error()
 
 
+def test_fused_launch_predicate_and_exchange_validation_host_side():
+    """hsr_srf_fused_launch_supported is pure host code: the one predicate behind hsr_pipeline_create_fused / _exchange (ADVICE r3:
+    Python's looser test let a launch fail with tiles in flight).  And the argument checks of the ABI 5 entry points that need no GPU."""
+    lib = nat.load()
+    from oracle import oracle_np as onp
+    from s2_emit import _engine as eng
+    w, good = onp.synthetic_wavelengths()
+    t12 = eng.build_srf_table(w, onp.synthetic_srf(), good)
+    k0 = (ctypes.c_int32 * t12.nb)(*[int(v) for v in t12.k0])
+    kl = (ctypes.c_int32 * t12.nb)(*[int(v) for v in t12.klen])
+    ok = lambda *a: lib.hsr_srf_fused_launch_supported(*a)
+    assert ok(0, 285, t12.nb, k0, kl, 12, 3, None) == 0 and ok(2, 285, t12.nb, k0, kl, 12, 3, None) == 0
+    assert ok(0, 285, t12.nb, k0, kl, 12, 0, None) == 2 and ok(0, 285, t12.nb, k0, kl, 10, 3, None) == 2      # degree 0; rows of 10 floats
+    assert ok(2, 285, t12.nb, k0, kl, 12, 3, ctypes.byref(nat.SrfOptions(0, 0, 1, 0))) == 2                    # single-buffer uint16 kernel
+    assert ok(1, 285, t12.nb, k0, kl, 12, 3, None) == 1
+    # uint16 tiles with a wide spectrum, 13 bands in rows of 16 and long supports: the two ring buffers no longer fit next to them
+    B = 300
+    k0w = (ctypes.c_int32 * 13)(*[int(i * 10) for i in range(13)])
+    klw = (ctypes.c_int32 * 13)(*([70] * 13))                   # 13 x 80 padded taps = 1040 > the 1024 floats reserved -> no LDS weights
+    assert ok(2, B, 13, k0w, klw, 16, 3, None) == 2 and b"weight taps" in lib.hsr_last_error()
+    klm = (ctypes.c_int32 * 13)(*([40] * 13))                   # 13 x 48 = 624 taps: fit, but 2 x 38 400 B + rows of 16 + taps > 80 KB
+    assert ok(2, B, 13, k0w, klm, 16, 3, None) == 2 and b"80 KB" in lib.hsr_last_error()
+    assert ok(0, B, 13, k0w, klm, 16, 3, None) == 0             # the float32 kernel has no such limit at B = 300
+    assert ok(2, 40, 3, k0w, (ctypes.c_int32 * 3)(8, 8, 8), 4, 2, None) == 2                                   # B < 48: group buffers too small for the ring
+    # exchange pipeline / communicator: argument errors come back as codes, nothing is dereferenced
+    import torch  # noqa: F401  (first: hsr_comm_* binds the librccl.so.1 that is already mapped - PyTorch's own copy; loading ROCm's
+    #                            copy and then PyTorch's puts two rocm_smi instances into the process, a double free at exit)
+    assert lib.hsr_comm_available() in (0, 1)
+    h = ctypes.c_void_p()
+    assert lib.hsr_comm_init(3, 2, (ctypes.c_ubyte * 128)(), ctypes.byref(h)) == 1 and lib.hsr_comm_init(0, 1, None, ctypes.byref(h)) == 1
+    assert lib.hsr_comm_unique_id(None) == 1 and lib.hsr_comm_destroy(None) == 0
+    assert lib.hsr_comm_ranks(None) == -1 and lib.hsr_comm_rank(None) == -1
+    assert lib.hsr_allreduce_f64(None, None, 0, None) == 1 and lib.hsr_bcast(None, None, 0, 0, None) == 1
+    x = nat.Exchange()
+    assert lib.hsr_pipeline_create_exchange(None, None, ctypes.byref(x), ctypes.byref(h)) == 1
+    four = (ctypes.c_void_p * 4)()
+    assert lib.hsr_pipeline_create_exchange(four, ctypes.c_void_p(1), ctypes.byref(x), ctypes.byref(h)) == 1 and b"exactly one" in lib.hsr_last_error()
+    code = ctypes.c_uint32(7)
+    assert lib.hsr_pipeline_status(None, None, ctypes.byref(code)) == 1
+
+
 def test_polyfeat_table_matches_sklearn_order():
     lib = nat.load()
     assert lib.hsr_polyfeat_count(10, 3) == 285 and lib.hsr_polyfeat_count(10, 2) == 65

@@ -818,7 +818,7 @@ class SpectralFusion:
         if self._pipe is not None:
             # tiles of the previous shape still in flight: finish them and keep their outputs - the next submit() / drain() calls
             # return them first, in order (round 3 dropped them here: a mosaic with a ragged last tile lost one or two tiles)
-            self._backlog.extend(self.drain())
+            self._backlog = self.drain()               # (drain() hands over what the backlog already held, in front)
             old, self._pipe = self._pipe, None
             self._native_handles = [e for e in self._native_handles if not any(e[1] is h for _, h in old["handles"])]
             self._destroy_handles(old["handles"])

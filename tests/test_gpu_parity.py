@@ -540,6 +540,79 @@ def test_rccl_exchange_path_single_rank(torch_gpu):
             dist.destroy_process_group()
 
 
+def test_pipeline_fallback_and_shape_change_lose_no_tile(torch_gpu):
+    """ADVICE r3 (both medium).  (1) fuse_apply=True on a geometry the fused launch cannot carry - uint16 tiles with B = 300, 13
+    bands in rows of 16: the two ring buffers do not fit next to the rows - must fall back to the two-slot pipeline AT CREATION
+    (hsr_srf_fused_launch_supported inside hsr_pipeline_create_fused), not fail at the first carrying launch with tiles in flight.
+    (2) a tile of another shape in mid-stream rebuilds the pipeline: the tiles still in flight are finished and come back from the
+    following submit() / drain() calls in order - none is dropped.  (3) plans that share a work buffer are refused."""
+    torch = torch_gpu
+    import ctypes as C
+    from s2_emit import SpectralFusion, _engine as eng, _native as nat
+    g = torch.Generator(device="cuda")
+    g.manual_seed(41)
+    # (1)
+    B = 300
+    w300 = np.linspace(381.0, 2493.0, B).astype(np.float32)
+    srf13 = onp.synthetic_srf()
+    nb = eng.build_srf_table(w300, srf13, None).nb
+    assert nb == 13
+    H, W = 24, 64
+    cubes = [eng.tile_encode_u16(torch.rand((H, W, B), generator=g, device="cuda") * 0.6) for _ in range(2)]
+    reals = [torch.rand((H, W, 16), generator=g, device="cuda") for _ in range(2)]
+    kw = dict(deg=3, min_valid=0.0, min_count=5)
+    pipe = SpectralFusion(w300, srf13, None, fuse_apply=True, **kw)
+    ref = SpectralFusion(w300, srf13, None, **kw)
+    got = []
+    for i in range(5):
+        o = pipe.submit(cubes[i % 2], reals[i % 2])
+        if o is not None:
+            got.append((o.matched.clone(), o.coeffs.clone()))
+    got += [(o.matched.clone(), o.coeffs.clone()) for o in pipe.drain()]
+    assert not pipe._pipe["fused"] and pipe._pipe["S"] == 2 and "80 KB" in pipe.fused_fallback and len(got) == 5
+    for i, (mt, co) in enumerate(got):
+        want = ref.step(cubes[i % 2], reals[i % 2], reuse_buffers=False)
+        assert torch.equal(mt.view(torch.int32), want.matched.view(torch.int32)) and torch.equal(co.view(torch.int64), want.coeffs.view(torch.int64)), i
+    pipe.close()
+    # (2)
+    w, good = onp.synthetic_wavelengths()
+    shapes = [(40, 64), (40, 64), (40, 64), (17, 50), (17, 50), (40, 64), (40, 64), (40, 64)]      # a ragged tile in the middle
+    tiles = [(torch.rand((h, ww, 285), generator=g, device="cuda") * 0.6, torch.rand((h, ww, 12), generator=g, device="cuda")) for h, ww in shapes]
+    for fuse in (False, True):
+        pipe = SpectralFusion(w, srf13, good, fuse_apply=fuse, **kw)
+        ref = SpectralFusion(w, srf13, good, **kw)
+        got = []
+        for c, r in tiles:
+            o = pipe.submit(c, r)
+            if o is not None:
+                got.append((o.matched.clone(), o.coeffs.clone()))
+        got += [(o.matched.clone(), o.coeffs.clone()) for o in pipe.drain()]
+        assert len(got) == len(tiles), (fuse, len(got))
+        for i, ((c, r), (mt, co)) in enumerate(zip(tiles, got)):
+            want = ref.step(c, r, reuse_buffers=False)
+            assert mt.shape == want.matched.shape, (fuse, i)
+            assert torch.equal(mt.view(torch.int32), want.matched.view(torch.int32)) and torch.equal(co.view(torch.int64), want.coeffs.view(torch.int64)), (fuse, i)
+        assert len(pipe._native_handles) <= 5          # the replaced pipelines and their plans were destroyed, not kept until close()
+        pipe.close()
+    # (3)
+    lib = nat.load()
+    plan = SpectralFusion(w, srf13, good, **kw)
+    c, r = tiles[0]
+    npix = c.shape[0] * c.shape[1]
+    r2, rl = plan._real_image(r, npix)
+    imgs = [eng.alloc_image(torch, 12, npix, nat.PIXMAJOR, c.device) for _ in range(6)]
+    wss = [eng.MomentWorkspace(c.device, 12, 3) for _ in range(3)]
+    h0, k0_ = plan._native_plan(c, r2, rl, imgs[0], imgs[1], wss[0])
+    h1, k1_ = plan._native_plan(c, r2, rl, imgs[2], imgs[3], wss[1])
+    h2, k2_ = plan._native_plan(c, r2, rl, imgs[4], imgs[5], wss[1])          # shares slot 1's workspace
+    side = torch.cuda.Stream()
+    ph = C.c_void_p()
+    assert lib.hsr_pipeline_create_fused(h0, h1, h2, C.c_void_p(side.cuda_stream), 0, C.byref(ph)) == 1 and b"share a work buffer" in lib.hsr_last_error()
+    assert lib.hsr_pipeline_create_fused(h0, h1, h1, C.c_void_p(side.cuda_stream), 0, C.byref(ph)) == 1
+    assert lib.hsr_pipeline_create_fused(h0, h1, h2, C.c_void_p(side.cuda_stream), 1, C.byref(ph)) == 2       # no exchange in the three-slot form
+    plan.close()
+
+
 def _one_rank_rccl_group(torch):
     """(created?, dist): a one-rank RCCL group on cuda:0 unless the process already has a group."""
     import os

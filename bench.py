@@ -458,6 +458,12 @@ def main(argv=None):
             fused_note = "self-checked before timing: seven tiles through the fused pipeline carry the bits of step()"
     pipelined = ntl == 1 and (args.pipeline == "on" or want_fused or (args.pipeline == "auto" and exchanging))
     fused = pipelined and want_fused
+    # A resident mosaic (--tiles-per-gpu T > 1) on ONE rank without an exchange goes through the fused per-tile launch with ONE fit per
+    # step (SpectralFusion(group_tiles=T), hsr_pipeline_create_group): T kernels per step on the caller's stream and nothing else;
+    # its coefficients are checked against fuse_mosaic() on the same tiles before anything is timed.  With an exchange (N > 1) the
+    # mosaic keeps the batched five-launch form.
+    mosaic_fused = ntl > 1 and not exchanging and not args.fused_fit and args.pipeline in ("auto", "fused") and ntl <= 64
+    mosaic_note = None
 
     def make_plan(trials):
         return SpectralFusion(prob.emit_w, prob.srf, prob.good_mask, deg=args.deg, min_valid=0.0, min_count=50,
@@ -468,7 +474,8 @@ def main(argv=None):
                               # pipeline's fit; the fused pipeline without an exchange has no side-stream work
                               reserved_cus=(args.reserve_cus if (exchanging or not fused) else 0) if pipelined else 0,
                               u16_fast=args.u16_fast, fused_fit=args.fused_fit, placement_trials=trials,
-                              placement_budget_gb=args.placement_budget_gb, fuse_apply=fused, comm=comm,
+                              placement_budget_gb=args.placement_budget_gb, fuse_apply=fused or mosaic_fused, comm=comm,
+                              group_tiles=ntl if mosaic_fused else 1,
                               rehearsal_collective=(args.fake_collective_us, args.fake_collective_blocks)
                               if (args.force_exchange and args.fake_collective_us > 0) else None)
     real = prob.real            # (H, W, row) band-last, like the cube and the reference's (H, W, C) images
@@ -486,6 +493,11 @@ def main(argv=None):
 
     def runner(plan_, cube_, real_, tiles_):
         def run_step(k1_events=None):
+            if mosaic_fused:                   # one step = T submits: one kernel per tile, one fit per step (the events bracket tile 0's launch)
+                o = None
+                for ti, (c_, r_) in enumerate(tiles_):
+                    o = plan_.submit(c_, r_, k1_events=k1_events if ti == 0 else None)
+                return o
             if ntl > 1:
                 return plan_.fuse_mosaic(tiles_, k1_events=k1_events, resident=True)
             if pipelined:
@@ -503,7 +515,7 @@ def main(argv=None):
                 torch.cuda.synchronize()     # keep the launch queue short
         for _ in range(max(warm, 1)):        # always one untimed pass: code-object load and LDS attributes are setup, not a step
             run_step()
-        if pipelined:
+        if pipelined or mosaic_fused:
             plan_.flush()
         barrier()
         every = max(1, args.event_every)
@@ -513,7 +525,7 @@ def main(argv=None):
         for i in range(steps):
             run_step(ev.get(i))
         host_issue[0] = (time.perf_counter() - t0) / max(1, steps)      # host time to ISSUE a step (the GPU runs behind)
-        if pipelined:
+        if pipelined or mosaic_fused:
             plan_.flush()            # the last tile's apply belongs to the timed region
         barrier()
         return time.perf_counter() - t0, ev
@@ -560,6 +572,34 @@ def main(argv=None):
             prob.cube = cube
         prob.real = real
     tiles = [((pr.cube_u16 if args.cube == "u16" else pr.cube), pr.real) for pr in probs]
+    if mosaic_fused:
+        # self-check: two steps through the group pipeline against fuse_mosaic() (per-tile launches, per-tile moments added in the fixed
+        # order) on the same tiles - coefficients and moments bit for bit, the last tile's matched image too
+        chk = SpectralFusion(prob.emit_w, prob.srf, prob.good_mask, deg=args.deg, min_valid=0.0, min_count=50, clip=True, device=device,
+                             coeff_sync="local", fuse_apply=True, group_tiles=ntl, u16_fast=args.u16_fast)
+        co_ref, tot_ref, outs_ref = chk.fuse_mosaic(tiles)
+        got = []
+        for _ in range(2):
+            got += [o for o in (chk.submit(c_, r_) for c_, r_ in tiles) if o is not None]
+        got += chk.drain()
+        same = len(got) == 2 * ntl and chk._pipe["group"] is not None and all(
+            torch.equal(o.coeffs.view(torch.int64), co_ref.view(torch.int64)) and torch.equal(o.moments.view(torch.int64), tot_ref.view(torch.int64))
+            for o in got) and torch.equal(got[-1].matched.view(torch.int32), outs_ref[-1].matched.view(torch.int32))
+        chk.close()
+        del chk, got, outs_ref
+        if not same:
+            if args.pipeline == "fused":
+                raise SystemExit("[bench] the group pipeline did not reproduce fuse_mosaic() on these tiles")
+            mosaic_fused = False
+            mosaic_note = "auto: the group pipeline's self-check against fuse_mosaic() failed, batched five-launch form used"
+            plan = make_plan(0)
+        else:
+            mosaic_note = "self-checked before timing: two steps through the group pipeline carry the bits of fuse_mosaic()"
+    mosaic_log = None
+    if mosaic_fused and not args.no_input_placement and not args.same_device and args.placement_trials > 1:
+        t_place = time.perf_counter()
+        tiles, mosaic_log = plan.place_mosaic(tiles)
+        mosaic_log["seconds"] = round(time.perf_counter() - t_place, 2)
     run_step = runner(plan, cube, real, tiles)
 
     # Steady state before timing (tools/dbg/ramp.py, profiles/r02_ramp.log): started from a GPU that idled for >= 10 ms,
@@ -578,7 +618,7 @@ def main(argv=None):
     ev2 = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(max(0, args.k1_launches))]
     for pair in ev2:
         out = run_step(pair)
-    if pipelined:
+    if pipelined or mosaic_fused:
         out = plan.flush()
     else:
         out = run_step()
@@ -599,15 +639,18 @@ def main(argv=None):
         # the algorithmic bytes of the dominant kernel are the cube read ONCE (H*W*285*4 per tile) - roofline.achieved
         # and .frac use exactly that over the kernel's time.  What the launch moves beyond it (targets, planes, and in the fused
         # pipelines K3 of an older tile: + 8 x row bytes per pixel) is reported beside it as frac_launch_bytes.
-        alg_bytes = cube_bytes * ntl               # a mosaic step runs K1+K2 of all its tiles in one batched launch
-        launch_bytes = alg_bytes + (H * W * 8 * prob.real.shape[-1] if fused else 0)
+        alg_bytes = cube_bytes * (1 if mosaic_fused else ntl)      # the batched mosaic form runs K1+K2 of all its tiles in one launch
+        launch_bytes = alg_bytes + (H * W * 8 * prob.real.shape[-1] if (fused or mosaic_fused) else 0)
         achieved = alg_bytes / (k1_ms * 1e-3) / 1e9
         carried = ("K1+K2 of tile i + K3 of tile i-3 (pre-phase) + slot reduction of tile i-1 (tail) in one launch, exchange on the side stream"
                    if (fused and exchanging) else "K1+K2 of tile i + K3 of tile i-2 (pre-phase) + fit of tile i-1 (tail) in one launch")
-        roof = {"bound": "hbm", "kernel": (f"srf_kernel<deg,fast,...,APPLY>: {carried}" if fused else "srf_kernel<deg,fast> (K1+K2 fused)")
+        if mosaic_fused:
+            carried = (f"K1+K2 of tile n + K3 of tile n-{ntl + 1} (pre-phase) + slot reduction of tile n-1 (tail; behind a step's last tile also "
+                       f"the sum over the {ntl} tiles and the solve) in one launch, {ntl} launches per step")
+        roof = {"bound": "hbm", "kernel": (f"srf_kernel<deg,fast,...,APPLY>: {carried}" if (fused or mosaic_fused) else "srf_kernel<deg,fast> (K1+K2 fused)")
                 if args.cube == "f32" else
                 "srf_u16_ring_kernel<deg%s> (K1+K2 fused, uint16 tile decode%s)%s" % (
-                    ",...,APPLY" if fused else "", ", fast arithmetic" if args.u16_fast else "", (": " + carried) if fused else ""),
+                    ",...,APPLY" if (fused or mosaic_fused) else "", ", fast arithmetic" if args.u16_fast else "", (": " + carried) if (fused or mosaic_fused) else ""),
                 "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
                 "traffic": None, "traffic_source": None, "algorithmic_bytes": alg_bytes,
                 "algorithmic_bytes_note": "SURVEY 8(d): H*W*285*4 per tile, the cube read exactly once (x tiles per launch)",
@@ -668,13 +711,15 @@ def main(argv=None):
                                          "(no side stream, no events, no reserved CUs); " + str(fused_note)) if fused else
                                         f"one tile deep (two slots, fit on a side stream), {args.reserve_cus} CUs reserved") if pipelined else "off",
                            "exchange_transport": (plan._pipe or {}).get("transport") if pipelined else None,
+                           "mosaic": ({"form": "group pipeline: one kernel per tile, one fit per step" if mosaic_fused else "batched: five launches per step",
+                                       "note": mosaic_note, "placement": mosaic_log} if ntl > 1 else None),
                            "fake_collective": ({"us": args.fake_collective_us, "blocks": args.fake_collective_blocks}
                                                if (args.force_exchange and args.fake_collective_us > 0) else None),
                            "settle": {"ms": args.settle_ms, "untimed_steps": settle_steps,
                                       "note": "untimed load before the W warm-up steps: from idle a 20-step region sits in a "
                                               "power-management transient 6-10 % slower than the continuous-load state"},
                            "pipeline_note": fused_note,
-                           "launches_per_step": 1 if fused else (2 if (args.fused_fit and world == 1 and not args.force_exchange and ntl == 1) else None),
+                           "launches_per_step": ntl if mosaic_fused else 1 if fused else (2 if (args.fused_fit and world == 1 and not args.force_exchange and ntl == 1) else None),
                            "placement": {"trials": plan.placement_trials, "trials_ms": plan.placement_log.get(H * W),
                                          "joint_with_inputs": input_log is not None,
                                          "search_seconds": (input_log or {}).get("seconds"),

@@ -9,6 +9,7 @@
 // The kernels are the ones behind hsr_srf_integrate_moments / hsr_moments_reduce[_solve] / hsr_poly_solve /
 // hsr_poly_apply: same launches, same bits.
 #include <new>
+#include <vector>
 
 #include "hsr_common.h"
 #include "hsr_solve.h"
@@ -25,10 +26,17 @@ struct hsr_step_plan {
   unsigned int seq;               // four slots: sequence number of the tile in this slot (the value of its "ready" word)
 };
 
+enum { kTwoSlot = 0, kFused = 1, kExchange = 2, kGroup = 3 };
 struct hsr_pipeline {
-  hsr_step_plan* slot[4];
-  int nslots;                     // 2: K3(i-1) as its own launch behind K1(i);  3 (fused): K3(i-2) inside K1(i)'s launch;
-                                  // 4 (fused + exchange from C): K3(i-3) inside K1(i)'s launch, see hsr_pipeline_create_exchange
+  std::vector<hsr_step_plan*> slot;
+  int kind;                       // kTwoSlot: K3(i-1) as its own launch behind K1(i);  kFused (3 slots): K3(i-2) inside K1(i)'s launch;
+                                  // kExchange (4 slots): K3(i-3) inside K1(i)'s launch, exchange issued from C (hsr_pipeline_create_exchange);
+                                  // kGroup (T + 2 slots): one fit per group of T tiles, K3(i-T-1) inside K1(i)'s launch (hsr_pipeline_create_group)
+  int nslots;
+  int group_T;                    // kGroup: tiles per fit
+  double* group_moments;          // kGroup: [2][T][nb][M] per-tile moments, by group parity
+  double* group_total;            //         [2][nb][M]
+  double* group_coeffs;           //         [2][nb][deg+1]
   hipStream_t side;
   int64_t n;                      // tiles submitted
   int exchange;                   // two slots, 1: the caller runs the fit (reduce -> collective -> solve) itself between
@@ -221,11 +229,12 @@ static int pipeline_new(hsr_step_plan* const* sl, int nslots, hsr_stream_t side_
   HSR_REQUIRE(side_stream != nullptr, HSR_ERR_INVALID, "%s: the side stream must be a real stream, not the default one", who);
   hsr_pipeline* pl = new (std::nothrow) hsr_pipeline();
   HSR_REQUIRE(pl, HSR_ERR_INVALID, "%s: out of host memory", who);
-  for (int i = 0; i < 4; ++i) {
-    pl->slot[i] = i < nslots ? sl[i] : nullptr;
-    pl->host_moments[i] = nullptr;
-  }
+  pl->slot.assign(sl, sl + nslots);
+  for (int i = 0; i < 4; ++i) pl->host_moments[i] = nullptr;
   pl->nslots = nslots;
+  pl->kind = nslots == 2 ? kTwoSlot : (nslots == 3 ? kFused : kExchange);      // (the create functions set the other kinds)
+  pl->group_T = 0;
+  pl->group_moments = pl->group_total = pl->group_coeffs = nullptr;
   pl->side = (hipStream_t)side_stream;
   pl->n = 0;
   pl->exchange = exchange ? 1 : 0;
@@ -329,9 +338,29 @@ extern "C" int hsr_pipeline_create_exchange(hsr_step_plan* const* slots4, hsr_st
   return HSR_OK;
 }
 
+extern "C" int hsr_pipeline_create_group(hsr_step_plan* const* slots, int32_t nslots, int32_t group_tiles, double* group_moments_dev,
+                                         double* group_total_dev, double* group_coeffs_dev, hsr_stream_t side_stream, hsr_pipeline** out) {
+  const char* who = "hsr_pipeline_create_group";
+  HSR_REQUIRE(slots && out && group_moments_dev && group_total_dev && group_coeffs_dev, HSR_ERR_INVALID, "%s: NULL argument", who);
+  HSR_REQUIRE(group_tiles >= 2 && group_tiles <= 64 && nslots == group_tiles + 2, HSR_ERR_INVALID,
+              "%s: groups of 2 .. 64 tiles and group_tiles + 2 plans needed (got %d tiles, %d plans)", who, group_tiles, nslots);
+  int rc = fused_geometry(slots, nslots, who);
+  if (rc != HSR_OK) return rc;
+  hsr_pipeline* pl = nullptr;
+  rc = pipeline_new(slots, nslots, side_stream, 0, &pl, who);
+  if (rc != HSR_OK) return rc;
+  pl->kind = kGroup;
+  pl->group_T = group_tiles;
+  pl->group_moments = group_moments_dev;
+  pl->group_total = group_total_dev;
+  pl->group_coeffs = group_coeffs_dev;
+  *out = pl;
+  return HSR_OK;
+}
+
 extern "C" void hsr_pipeline_destroy(hsr_pipeline* pl) {
   if (!pl) return;
-  if (pl->nslots == 4) (void)hipStreamSynchronize(pl->side);      // a host_sum callback may still point at this object
+  if (pl->kind == kExchange) (void)hipStreamSynchronize(pl->side);      // a host_sum callback may still point at this object
   for (int k = 0; k < 4; ++k)
     if (pl->host_moments[k]) (void)hipHostFree(pl->host_moments[k]);
   if (pl->sync) (void)hipFree(pl->sync);
@@ -340,7 +369,7 @@ extern "C" void hsr_pipeline_destroy(hsr_pipeline* pl) {
 
 static int finish_slot(hsr_pipeline* pl, hsr_step_plan* p, const uint8_t* mask, hipStream_t main) {
   int rc = HSR_OK;
-  if (pl->nslots == 3) {                       // tail-fit pipeline: everything lives on the caller's stream
+  if (pl->kind == kFused) {                    // tail-fit pipeline: everything lives on the caller's stream
     if (!p->fitted)
       rc = hsr_moments_reduce_solve(p->d.partials_dev, p->slots, p->d.nb, p->d.deg, p->d.min_count, p->d.moments_dev, p->d.coeffs_dev, main);
     p->fitted = true;
@@ -511,6 +540,114 @@ static int finish_exchange_slot(hsr_pipeline* pl, int k, const uint8_t* mask, hi
   return rc;
 }
 
+// ---- T + 2 slots: ONE fit per group of T consecutive tiles (a mosaic held by one GPU) ----------------------------------
+// Launch n = K3 of tile n - (T + 1) as the pre-phase | K1+K2 of tile n | slot reduction of tile n - 1 in the tail; the tail of the launch
+// that follows a group's LAST tile also adds the group's T per-tile moment sets (the tree of hsr_moments_reduce over T slots) and
+// solves.  A tile's K3 therefore rides T + 1 launches later, when its group's polynomial has been ready for at least one launch:
+// nothing but one kernel per tile on the caller's stream, no side stream, no events, no CUs kept free.  Buffers of two
+// consecutive groups never alias (parity).
+static inline size_t group_mom_doubles(const hsr_pipeline* pl) {
+  return (size_t)pl->slot[0]->d.nb * hsr::moment_count(pl->slot[0]->d.deg);
+}
+static inline double* group_entry(const hsr_pipeline* pl, int64_t tile) {      // moments of tile `tile` inside its group's array
+  const int64_t g = tile / pl->group_T, i = tile % pl->group_T;
+  return pl->group_moments + ((size_t)(g & 1) * pl->group_T + (size_t)i) * group_mom_doubles(pl);
+}
+static inline double* group_total_of(const hsr_pipeline* pl, int64_t tile) { return pl->group_total + (size_t)((tile / pl->group_T) & 1) * group_mom_doubles(pl); }
+static inline double* group_coeffs_of(const hsr_pipeline* pl, int64_t tile) {
+  return pl->group_coeffs + (size_t)((tile / pl->group_T) & 1) * pl->slot[0]->d.nb * (pl->slot[0]->d.deg + 1);
+}
+
+// slot reduction of tile `tile` (and, for a group's last tile, the group's fit) as launches of their own
+static int group_fit_standalone(hsr_pipeline* pl, int64_t tile, hipStream_t main) {
+  hsr_step_plan* p = pl->slot[tile % pl->nslots];
+  const hsr_step_desc& d = p->d;
+  int rc = hsr_moments_reduce(d.partials_dev, p->slots, d.nb, d.deg, group_entry(pl, tile), main);
+  if (rc == HSR_OK && tile % pl->group_T == pl->group_T - 1)
+    rc = hsr_moments_reduce_solve(group_entry(pl, tile - (pl->group_T - 1)), pl->group_T, d.nb, d.deg, d.min_count, group_total_of(pl, tile),
+                                  group_coeffs_of(pl, tile), main);
+  p->fitted = true;
+  return rc;
+}
+
+static int submit_group(hsr_pipeline* pl, const void* cube_dev, const float* real_dev, const uint8_t* mask_dev,
+                        const uint8_t* prev_mask_dev, hipStream_t main, int32_t* finished_slot, void* k1_begin_event,
+                        void* k1_end_event) {
+  const int S = pl->nslots, T = pl->group_T;
+  const int64_t n = pl->n;
+  hsr_step_plan* p = pl->slot[n % S];
+  hsr_step_plan* old = n >= T + 1 ? pl->slot[(n - (T + 1)) % S] : nullptr;      // tile n - (T + 1): its K3 rides in this launch
+  hsr_step_plan* last = n >= 1 ? pl->slot[(n - 1) % S] : nullptr;               // tile n - 1: its slot reduction rides in the tail
+  int rc = HSR_OK;
+  hsr_apply_job job{};
+  const bool carry = old && old->pending;
+  if (carry) {
+    job.x_dev = old->d.pseudo_dev;
+    job.out_dev = old->d.matched_dev;
+    job.coeffs_dev = group_coeffs_of(pl, n - (T + 1));
+    job.mask_dev = old->d.apply_mask ? prev_mask_dev : nullptr;
+    job.npix = old->d.npix;
+    job.clip = old->d.clip;
+  }
+  const int grid = hsr_partial_slots(p->d.npix, &p->d.opts);
+  const bool fit_last = last && last->pending && !last->fitted;
+  const bool ride = fit_last && grid >= p->d.nb;
+  if (ride) {
+    job.fit_partials_dev = last->d.partials_dev;
+    job.fit_slots = last->slots;
+    job.fit_moments_dev = group_entry(pl, n - 1);
+    job.fit_coeffs_dev = group_coeffs_of(pl, n - 1);
+    job.fit_min_count = last->d.min_count;
+    job.fit_counter_dev = pl->counter;
+    job.fit_ticket_base = pl->tickets;
+    job.fit_group_tiles = T;
+    job.fit_group_index = (int32_t)((n - 1) % T);
+    job.fit_group_moments_dev = group_entry(pl, (n - 1) - (n - 1) % T);
+    job.fit_group_total_dev = group_total_of(pl, n - 1);
+  } else if (fit_last) {
+    rc = group_fit_standalone(pl, n - 1, main);
+    if (rc != HSR_OK) return rc;
+  }
+  if (k1_begin_event) rc = hsr::check_hip(hipEventRecord((hipEvent_t)k1_begin_event, main), "hsr_pipeline: record K1 begin");
+  if (rc != HSR_OK) return rc;
+  rc = run_k1(p, cube_dev, real_dev, mask_dev, main, (carry || ride) ? &job : nullptr);
+  if (rc != HSR_OK) return rc;
+  if (ride) {
+    HSR_REQUIRE(p->slots == grid, HSR_ERR_INVALID, "hsr_pipeline_submit: the launch used %d workgroups, %d expected", p->slots, grid);
+    pl->tickets += (unsigned int)p->slots;
+    last->fitted = true;
+  }
+  if (k1_end_event) rc = hsr::check_hip(hipEventRecord((hipEvent_t)k1_end_event, main), "hsr_pipeline: record K1 end");
+  if (rc != HSR_OK) return rc;
+  if (carry) {
+    old->pending = false;
+    if (finished_slot) *finished_slot = (int)((n - (T + 1)) % S);
+  }
+  p->pending = true;
+  p->fitted = false;
+  pl->n += 1;
+  return HSR_OK;
+}
+
+// drain: tile i (the oldest unfinished one).  Whole groups only: a group whose last tile has not been submitted has no polynomial.
+static int finish_group_slot(hsr_pipeline* pl, int64_t i, const uint8_t* mask, hipStream_t main) {
+  const int T = pl->group_T;
+  HSR_REQUIRE(pl->n % T == 0, HSR_ERR_INVALID, "hsr_pipeline_flush: %lld tiles submitted, not a whole number of groups of %d - the last group "
+              "has no fit yet", (long long)pl->n, T);
+  int rc = HSR_OK;
+  for (int64_t k = i; k < pl->n && rc == HSR_OK; ++k) {          // every reduction up to the end of the tile's group (only the last tile's can be open)
+    hsr_step_plan* q = pl->slot[k % pl->nslots];
+    if (q->pending && !q->fitted) rc = group_fit_standalone(pl, k, main);
+  }
+  if (rc != HSR_OK) return rc;
+  hsr_step_plan* p = pl->slot[i % pl->nslots];
+  const hsr_step_desc& d = p->d;
+  rc = hsr_poly_apply(d.pseudo_dev, d.out_bs, d.out_ps, d.apply_mask ? mask : nullptr, group_coeffs_of(pl, i), d.nb, d.deg, d.npix, nullptr, d.clip,
+                      d.matched_dev, d.matched_bs, d.matched_ps, main);
+  p->pending = false;
+  return rc;
+}
+
 // Starts tile i in slot i % S and finishes tile i-1 (two slots), i-2 (fused) or i-3 (fused with exchange): its K3.
 // *finished_slot = slot of the finished tile, or -1.  prev_mask_dev: the mask of the tile being finished (only read when the
 // plan applies the mask in K3).
@@ -528,8 +665,9 @@ extern "C" int hsr_pipeline_submit(hsr_pipeline* pl, const void* cube_dev, const
   HSR_REQUIRE(!p->pending, HSR_ERR_INVALID, "hsr_pipeline_submit: slot %d still holds an unfinished tile", cur);
   int rc = HSR_OK;
   if (finished_slot) *finished_slot = -1;
-  if (S == 4) return submit_exchange(pl, cube_dev, real_dev, mask_dev, prev_mask_dev, main, finished_slot, k1_begin_event, k1_end_event);
-  if (S == 3) {
+  if (pl->kind == kExchange) return submit_exchange(pl, cube_dev, real_dev, mask_dev, prev_mask_dev, main, finished_slot, k1_begin_event, k1_end_event);
+  if (pl->kind == kGroup) return submit_group(pl, cube_dev, real_dev, mask_dev, prev_mask_dev, main, finished_slot, k1_begin_event, k1_end_event);
+  if (pl->kind == kFused) {
     // fused: this launch carries K3 of tile n - 2 (slot (n + 1) % 3); its fit has had all of K1(n - 1) to finish
     hsr_step_plan* old = pl->n >= 2 ? pl->slot[(pl->n + 1) % 3] : nullptr;
     hsr_apply_job job{};
@@ -614,7 +752,7 @@ extern "C" int hsr_pipeline_submit(hsr_pipeline* pl, const void* cube_dev, const
 
 // two slots, exchange = 1: the caller has enqueued the fit of the slot submitted last on the side stream.
 extern "C" int hsr_pipeline_fit_done(hsr_pipeline* pl) {
-  HSR_REQUIRE(pl && pl->n > 0 && pl->nslots == 2, HSR_ERR_INVALID, "hsr_pipeline_fit_done: nothing submitted, or not a two-slot pipeline");
+  HSR_REQUIRE(pl && pl->n > 0 && pl->kind == kTwoSlot, HSR_ERR_INVALID, "hsr_pipeline_fit_done: nothing submitted, or not a two-slot pipeline");
   hsr_step_plan* p = pl->slot[(pl->n - 1) % pl->nslots];
   return hsr::check_hip(hipEventRecord(p->ev_fit, pl->side), "hsr_pipeline: record fit");
 }
@@ -627,8 +765,9 @@ extern "C" int hsr_pipeline_flush(hsr_pipeline* pl, const uint8_t* mask_dev, hsr
   for (int64_t i = pl->n >= S - 1 ? pl->n - (S - 1) : 0; i < pl->n; ++i) {
     hsr_step_plan* p = pl->slot[i % S];
     if (!p->pending) continue;
-    int rc = S == 4 ? finish_exchange_slot(pl, (int)(i % S), mask_dev, (hipStream_t)main_stream)
-                    : finish_slot(pl, p, mask_dev, (hipStream_t)main_stream);
+    int rc = pl->kind == kExchange ? finish_exchange_slot(pl, (int)(i % S), mask_dev, (hipStream_t)main_stream)
+             : pl->kind == kGroup  ? finish_group_slot(pl, i, mask_dev, (hipStream_t)main_stream)
+                                   : finish_slot(pl, p, mask_dev, (hipStream_t)main_stream);
     if (rc == HSR_OK && finished_slot) *finished_slot = (int)(i % S);
     return rc;
   }

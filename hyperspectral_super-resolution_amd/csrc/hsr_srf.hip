@@ -103,6 +103,13 @@ struct SrfArgs {
   // finished band into *lazy_ready, which a one-wave gate kernel on the side stream polls; and the K3 pre-phase reads
   // coefficients that a side-stream kernel published by setting *apply_ready to apply_ready_value
   unsigned int* lazy_ready;         // non-NULL: reduce only, publish (no solve)
+  // a fit over a GROUP of T tiles (a mosaic held by one GPU, hsr_apply_job.fit_group_*): lazy_moments is entry lazy_group_index of
+  // lazy_group_moments [T][nb][M]; the tail of the group's LAST tile also adds the T entries (the tree of hsr_moments_reduce
+  // over T slots) and solves: lazy_group_total, lazy_coeffs.  The other tiles' tails write no coefficients.
+  int32_t lazy_group_T;             // 0 / 1: every tile has its own fit
+  int32_t lazy_group_index;
+  const double* lazy_group_moments;
+  double* lazy_group_total;
   const unsigned int* apply_ready;  // non-NULL: poll until (int)(*apply_ready - apply_ready_value) >= 0, then read the coefficients through
   unsigned int apply_ready_value;
   unsigned int* sync_error;         // set to a non-zero code if a poll runs into its time limit (HSR_SYNC_TIMEOUT_S)
@@ -531,6 +538,33 @@ __device__ __forceinline__ void lazy_fit(const SrfArgs& a, unsigned char* smem, 
     return;
   }
   __syncthreads();
+  if (a.lazy_group_T > 1) {                               // one fit over a group of tiles
+    const int T2 = a.lazy_group_T;
+    if (a.lazy_group_index != T2 - 1) return;             // not the group's last tile: its moments are in place, nothing to solve yet
+    // hsr_moments_reduce over T "slots" (the tiles' moments): lane l's sum is 0.0 + entry l (one entry per lane for T <= 64, the
+    // other lanes hold 0.0), then the butterfly over the 64 lane sums - the same adds, hence the bits of the other mosaic forms.
+    // The last tile's own entry comes from LDS (this workgroup has just written it), the others from earlier launches.
+    double* gm = mom + 16 + kSolveWork;
+    if (t < M) {
+      double acc[32];
+#pragma unroll
+      for (int l = 0; l < 32; ++l) {
+        const double lo = l < T2 ? 0.0 + (l == T2 - 1 ? mom[t] : a.lazy_group_moments[((size_t)l * a.nb + b) * M + t]) : 0.0;
+        const int h = l + 32;
+        const double hi = h < T2 ? 0.0 + (h == T2 - 1 ? mom[t] : a.lazy_group_moments[((size_t)h * a.nb + b) * M + t]) : 0.0;
+        acc[l] = lo + hi;
+      }
+#pragma unroll
+      for (int off = 16; off >= 1; off >>= 1)
+#pragma unroll
+        for (int l = 0; l < off; ++l) acc[l] = acc[l] + acc[l + off];
+      gm[t] = acc[0];
+      a.lazy_group_total[(size_t)b * M + t] = acc[0];
+    }
+    __syncthreads();
+    if (t == 0) solve_band_t<DEG, true>(gm, a.lazy_min_count, a.lazy_coeffs + (size_t)b * (DEG + 1), work);
+    return;
+  }
   if (t == 0) solve_band_t<DEG, true>(mom, a.lazy_min_count, a.lazy_coeffs + (size_t)b * (DEG + 1), work);
 }
 
@@ -1890,6 +1924,16 @@ static int srf_moments_entry(const char* who, const void* cube_dev, bool u16, fl
       a.lazy_counter = job->fit_counter_dev;
       a.lazy_base = job->fit_ticket_base;
       a.lazy_ready = job->fit_ready_dev;
+      if (job->fit_group_tiles > 1) {
+        HSR_REQUIRE(job->fit_group_tiles <= 64 && job->fit_group_index >= 0 && job->fit_group_index < job->fit_group_tiles &&
+                        job->fit_group_moments_dev && job->fit_group_total_dev && job->fit_ready_dev == nullptr, HSR_ERR_INVALID,
+                    "%s: group fit of %d tiles (at most 64), index %d, or NULL group buffers, or combined with fit_ready_dev", who,
+                    job->fit_group_tiles, job->fit_group_index);
+        a.lazy_group_T = job->fit_group_tiles;
+        a.lazy_group_index = job->fit_group_index;
+        a.lazy_group_moments = job->fit_group_moments_dev;
+        a.lazy_group_total = job->fit_group_total_dev;
+      }
     }
     if (job->x_dev && job->coeffs_ready_dev) {
       a.apply_ready = job->coeffs_ready_dev;

@@ -428,6 +428,46 @@ def placement_search(first, make, probe, trials: int, pitch_gb: float, device, b
     return keep, [round(t, 4) for t in times]
 
 
+def placement_rank(make, probe, count: int, pitch_gb: float, device, budget_gb: Optional[float] = None, candidate_bytes: int = 0,
+                   stats: Optional[dict] = None):
+    """placement_search for a set of interchangeable buffers (the resident tiles of a mosaic): up to ``count`` candidates from
+    ``make()``, ``pitch_gb`` GB of spacer between consecutive ones (so that they sample different stretches of device memory), each
+    timed with ``probe`` (one untimed + two timed launches).  Returns [(candidate, ms)] for every candidate that fitted the budget,
+    in allocation order - the caller keeps the fastest ones.  Same memory rules as placement_search."""
+    torch = nat.require_gpu()
+    stream = torch.cuda.current_stream(device)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    free0, _total = torch.cuda.mem_get_info(device)
+    budget = 0.5 * free0 if budget_gb is None else min(float(budget_gb) * (1 << 30), float(free0))
+    per_trial = int(pitch_gb * (1 << 30)) + int(candidate_bytes)
+    held, out, spacers = 0, [], []
+    for i in range(max(1, count)):
+        free, _ = torch.cuda.mem_get_info(device)
+        if i > 0 and (held + per_trial > budget or per_trial + (1 << 30) > free):
+            break
+        try:
+            if i > 0 and pitch_gb > 0:
+                spacers.append(torch.empty(int(pitch_gb * (1 << 30)), dtype=torch.uint8, device=device))
+            c = make()
+        except RuntimeError:
+            break
+        held += per_trial
+        probe(c)
+        t = []
+        for _ in range(2):
+            e0.record(stream)
+            probe(c)
+            e1.record(stream)
+            e1.synchronize()
+            t.append(e0.elapsed_time(e1))
+        out.append((c, min(t)))
+    if stats is not None:
+        stats["held_gb"] = stats.get("held_gb", 0.0) + held / (1 << 30)
+        stats["budget_gb"] = budget / (1 << 30)
+    del spacers
+    return out
+
+
 class TileBatch:
     """Device tables and workspaces of one batch of tiles for the three batched launches.
 

@@ -177,6 +177,7 @@ SIGNATURES = {
     "hsr_pipeline_count": (_i64, [_vp]),
     "hsr_pipeline_create_exchange": (C.c_int, [C.POINTER(_vp), _vp, C.POINTER(Exchange), C.POINTER(_vp)]),
     "hsr_pipeline_status": (C.c_int, [_vp, _vp, C.POINTER(C.c_uint32)]),
+    "hsr_pipeline_create_group": (C.c_int, [C.POINTER(_vp), _i32, _i32, _vp, _vp, _vp, _vp, C.POINTER(_vp)]),
     "hsr_srf_fused_launch_supported": (C.c_int, [_i32, _i32, _i32, _pi32, _pi32, _i64, _i32, _popt]),
     "hsr_comm_available": (C.c_int, []),
     "hsr_comm_version": (C.c_int, []),

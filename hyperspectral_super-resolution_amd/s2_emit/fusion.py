@@ -110,7 +110,7 @@ class SpectralFusion:
                  reserved_cus: Optional[int] = None, tile_pixels: int = 0, u16_single_buffer: bool = False,
                  u16_fast: bool = False, placement_trials: int = 0, fused_fit: bool = False,
                  placement_pitch_gb: float = eng.PLACEMENT_PITCH_GB, placement_budget_gb: Optional[float] = None,
-                 side_stream=None, fuse_apply: bool = False, comm=None, rehearsal_collective=None):
+                 side_stream=None, fuse_apply: bool = False, comm=None, rehearsal_collective=None, group_tiles: int = 1):
         """``placement_trials`` (default 0 = OFF: the plan allocates once and never synchronises with the host): opt in to
         the placement search of eng.placement_search for tiles of >= 65 536 pixels - up to min(4, trials) candidate output
         images on the first step()/submit()/step_batch() over a tile size, up to ``trials`` candidate (cube, target, image)
@@ -186,6 +186,13 @@ class SpectralFusion:
         # stream wait on the caller's stream.  The collective is RCCL through the library's own communicator (``comm``: an
         # eng.Comm, or None = built over ``group`` on first use) when the group's backend is nccl; with any other backend (gloo)
         # the moments make a round trip through pinned host memory and torch.distributed sums them there (a host callback).
+        # group_tiles = T > 1 (with fuse_apply, no exchange): submit() fits ONE polynomial per group of T consecutive tiles - a mosaic
+        # held by this GPU (hsr_pipeline_create_group): launch n = K3 of tile n-T-1 | K1+K2 of tile n | slot reduction of tile n-1 (+ the
+        # group's sum and solve) in the tail.  Outputs come T + 1 submits late, with their group's moments and coefficients; drain()
+        # needs whole groups.  Same bits as fuse_mosaic() on the same tiles.
+        self.group_tiles = int(group_tiles)
+        if not 1 <= self.group_tiles <= 64:
+            raise ValueError("group_tiles must be in [1, 64]")
         self._comm = comm
         # one-GPU rehearsals only: (microseconds, workgroups) of a stand-in kernel enqueued where the collective's kernel would run
         # (hsr_exchange.rehearsal_us; a one-rank RCCL all-reduce launches nothing)
@@ -276,6 +283,48 @@ class SpectralFusion:
         self._pipe_images[npix] = outs[1:]
         self.placement_log[npix] = times
         return cube, real, {"joint_ms": times}
+
+    def place_mosaic(self, tiles, oversample: float = 12.0, pitch_gb: float = 0.0):
+        """place_inputs() for the resident tiles of a mosaic (same shapes).  The speed classes of device memory come in stretches of
+        15-70 GB (profiles/r03_placement_mechanism.md) - long enough to hold MANY 1.2 GB tiles - so this samples DENSELY: up to
+        ``oversample`` x T candidate (cube, target) buffer pairs allocated back to back (``pitch_gb`` of spacer between them, 0 by
+        default) within placement_budget_gb, K1 timed on each, the T fastest kept and the tiles copied into them - which tile lands
+        in which buffer does not matter, the buffers are interchangeable.  (A 9.6 GB mosaic allocated in one piece necessarily spans
+        both classes; r03 left "individually probed chunks" open.)  Returns (tiles as (cube, real) in the kept buffers, log).  Needs
+        placement_trials > 1; same bytes, same results."""
+        torch = nat.require_gpu()
+        tiles = [(c, r) for c, r in tiles]
+        T = len(tiles)
+        if self.placement_trials <= 1 or T == 0:
+            return tiles, {}
+        c0, r0 = tiles[0]
+        npix = c0.numel() // c0.shape[-1]
+        img = eng.alloc_image(torch, self.table.nb, npix, self.layout, self.device)
+
+        def k1(cand):
+            c, r = cand
+            rr, rl = self._real_image(r, npix)
+            eng.srf_integrate_moments(c, self.table, rr, self.deg, self.ws, None, self.min_valid, self.min_valid, out=img, reduce=False,
+                                      layout=self.layout, real_layout=rl, scale=self.tile_scale, nodata=self.tile_nodata, opts=self.opts)
+        cand_bytes = c0.numel() * c0.element_size() + r0.numel() * 4
+        per = pitch_gb * (1 << 30) + cand_bytes
+        free, _ = torch.cuda.mem_get_info(self.device)
+        budget = 0.5 * free if self.placement_budget_gb is None else min(self.placement_budget_gb * (1 << 30), free)
+        count = int(min(max(T, oversample * T), max(T, budget // per)))
+        pitch = pitch_gb
+        ranked = eng.placement_rank(lambda: (c0.clone(), r0.clone()), k1, count, pitch, self.device, self.placement_budget_gb, cand_bytes,
+                                    self._placement_stats)
+        ranked += [((c, r), float("inf")) for c, r in tiles[:max(0, T - len(ranked))]]      # too little memory for T candidates: the originals
+        order = sorted(range(len(ranked)), key=lambda i: ranked[i][1])[:T]
+        kept = []
+        for (c, r), i in zip(tiles, order):
+            bc, br = ranked[i][0]
+            if bc is not c:
+                bc.copy_(c)
+                br.copy_(r)
+            kept.append((bc, br))
+        times = [round(t, 4) for _, t in ranked if t != float("inf")]
+        return kept, {"candidate_ms": times, "kept_ms": [round(ranked[i][1], 4) for i in order], "pitch_gb": round(pitch, 2)}
 
     def _exchanges(self) -> bool:
         import torch.distributed as dist
@@ -843,9 +892,12 @@ class SpectralFusion:
         # The C side decides whether a K1 launch of this geometry can carry the older tile's K3 (hsr_srf_fused_launch_supported, called
         # by the create functions); what it cannot see is the cube pointer - uint16 tiles need the 16-byte aligned loader.
         exchange = self._exchanges()
+        if self.group_tiles > 1 and (exchange or not self.fuse_apply or self.layout != nat.PIXMAJOR):
+            raise ValueError("group_tiles > 1 needs fuse_apply=True, the pixel-major layout and no exchange (multi-rank mosaics: fuse_mosaic)")
         fused = (self.fuse_apply and self.layout == nat.PIXMAJOR and
                  (cube.dtype == torch.float32 or (cube.data_ptr() % 16 == 0 and not self.u16_single_buffer)))
-        nslots = (4 if exchange else 3) if fused else 2
+        grouped = fused and not exchange and self.group_tiles > 1
+        nslots = (self.group_tiles + 2 if grouped else (4 if exchange else 3)) if fused else 2
         while len(placed) < nslots:
             placed.append(eng.alloc_image(torch, nb, npix, self.layout, self.device))
         slots, outs, handles = [], [], []
@@ -866,13 +918,23 @@ class SpectralFusion:
             side = self._pick_side_stream(slots, cube, real2, mask)
         ph = C.c_void_p()
         transport = None
-        if fused and exchange:
+        gbuf = None
+        if grouped:
+            T, M = self.group_tiles, 3 * self.deg + 2
+            gbuf = (torch.zeros((2, T, nb, M), dtype=torch.float64, device=self.device), torch.zeros((2, nb, M), dtype=torch.float64, device=self.device),
+                    torch.zeros((2, nb, self.deg + 1), dtype=torch.float64, device=self.device))
+            arr = (C.c_void_p * nslots)(*[sl["plan"] for sl in slots])
+            rc = lib.hsr_pipeline_create_group(arr, nslots, T, gbuf[0].data_ptr(), gbuf[1].data_ptr(), gbuf[2].data_ptr(),
+                                               C.c_void_p(side.cuda_stream), C.byref(ph))
+        elif fused and exchange:
             x, transport = self._exchange_desc()
             arr = (C.c_void_p * 4)(*[sl["plan"] for sl in slots])
             rc = lib.hsr_pipeline_create_exchange(arr, C.c_void_p(side.cuda_stream), C.byref(x), C.byref(ph))
         elif fused:
             rc = lib.hsr_pipeline_create_fused(slots[0]["plan"], slots[1]["plan"], slots[2]["plan"], C.c_void_p(side.cuda_stream),
                                                0, C.byref(ph))
+        if grouped and rc != nat.HSR_OK:
+            nat.check(rc, "hsr_pipeline_create_group")      # a group fit has no two-slot form to fall back to
         if fused and rc != nat.HSR_OK:                 # geometry the fused launch does not cover: the two-slot pipeline
             fused, transport = False, None
             self.fused_fallback = nat.load().hsr_last_error().decode("utf-8", "replace")
@@ -889,7 +951,7 @@ class SpectralFusion:
         handles.append(("pipe", ph))
         self._pipe = dict(key=key, npix=npix, h=ph, slots=slots, outs=outs, side=side, side_handle=C.c_void_p(side.cuda_stream),
                           exchange=exchange, n=0, fin=C.c_int32(-1), fused=fused, S=len(slots), inflight=[], handles=handles,
-                          c_exchange=bool(fused and exchange), transport=transport)
+                          c_exchange=bool(fused and exchange), transport=transport, group=gbuf, done=0)
         return self._pipe
 
     @staticmethod
@@ -951,11 +1013,20 @@ class SpectralFusion:
         if fin.value >= 0:
             st["inflight"].remove(fin.value)
             st["slots"][fin.value]["mask"] = None
-            out = st["outs"][fin.value]
+            out = self._finished(st, fin.value)
         if self._backlog:                        # tiles a pipeline rebuild finished come first
             if out is not None:
                 self._backlog.append(out)
             out = self._backlog.pop(0)
+        return out
+
+    def _finished(self, st, slot) -> FusionOutput:
+        """Output of the tile the pipeline has just finished (tiles finish in submission order)."""
+        out = st["outs"][slot]
+        if st["group"] is not None:                 # a group fit: the tile carries its GROUP's moments and polynomial
+            par = (st["done"] // self.group_tiles) & 1
+            out = FusionOutput(out.names, out.pseudo, st["group"][1][par], st["group"][2][par], out.matched, out.layout)
+        st["done"] += 1
         return out
 
     def pipeline_status(self) -> int:
@@ -982,14 +1053,19 @@ class SpectralFusion:
         fin = st["fin"]
         with eng._launch(st["outs"][0].pseudo) as stream:
             while st["inflight"]:
-                slot = st["inflight"].pop(0)             # oldest first; its mask was kept with the slot
+                slot = st["inflight"][0]                 # oldest first; its mask was kept with the slot
                 mask = st["slots"][slot]["mask"]
-                nat.check(lib.hsr_pipeline_flush(st["h"], None if mask is None else mask.data_ptr(), stream, C.byref(fin)),
-                          "hsr_pipeline_flush")
+                try:
+                    nat.check(lib.hsr_pipeline_flush(st["h"], None if mask is None else mask.data_ptr(), stream, C.byref(fin)),
+                              "hsr_pipeline_flush")
+                except nat.HsrError:
+                    self._backlog = outs                 # what has been finished so far is not lost
+                    raise
                 if fin.value != slot:
                     raise nat.HsrError(f"pipeline out of step: expected slot {slot}, library finished {fin.value}")
+                st["inflight"].pop(0)
                 st["slots"][slot]["mask"] = None
-                outs.append(st["outs"][slot])
+                outs.append(self._finished(st, slot))
         return outs
 
     def flush(self) -> Optional[FusionOutput]:

@@ -145,6 +145,15 @@ typedef struct hsr_apply_job {
   unsigned int coeffs_ready_value;      /* word until it has reached this value (wrap-safe >=), then reads the coefficients through */
   unsigned int reserved2;
   unsigned int* sync_error_dev;  /* optional: receives a non-zero code if a poll runs into its wall-clock limit (20 s)              */
+  /* ABI 5 - ONE fit over a group of T tiles (a mosaic held by one GPU: BASELINE configs[3]/[4] per-GPU work; the reference's tiles,  */
+  /* tiles_helpers/utils.py:223-305, fitted together).  fit_group_tiles >= 2: fit_moments_dev must be entry fit_group_index of       */
+  /* fit_group_moments_dev [T][nb][3deg+2]; the tail writes that entry and - for the group's LAST tile (index T-1) only - adds the T   */
+  /* entries in the fixed order of hsr_moments_reduce over T slots into fit_group_total_dev (nb, 3deg+2) and solves into              */
+  /* fit_coeffs_dev (nb, deg+1).  For the other tiles no coefficients are written.  T <= 64; not together with fit_ready_dev.         */
+  int32_t fit_group_tiles;
+  int32_t fit_group_index;
+  const double* fit_group_moments_dev;
+  double* fit_group_total_dev;
 } hsr_apply_job;
 int hsr_srf_integrate_moments_apply(const float* cube_dev, int64_t npix, int32_t B,
                                     const float* wn_dev, const int32_t* k0, const int32_t* klen, int32_t nb,
@@ -638,6 +647,18 @@ typedef struct hsr_exchange {
 } hsr_exchange;
 int hsr_pipeline_create_exchange(hsr_step_plan* const* slots4, hsr_stream_t side_stream, const hsr_exchange* exchange,
                                  hsr_pipeline** pipeline_out);
+/* ---- the fused pipeline with ONE fit per group of T consecutive tiles (ABI 5) -------------------------------------------
+ * A mosaic held by one GPU (BASELINE.json configs[3]/[4] per-GPU work: the reference's tiles, tiles_helpers/utils.py:223-305, fitted
+ * together - s2_emit/poly_regression.py:59-60 over the pixels of all of them).  group_tiles + 2 plans; launch n on the caller's stream =
+ *     [K3 of tile n-T-1 | K1+K2 of tile n | slot reduction of tile n-1 in the tail (+ the group's sum and solve behind a group's last tile)]
+ * and nothing else: no side stream work, no events, no CUs kept free.  hsr_pipeline_submit(n) finishes tile n-T-1 with ITS group's
+ * polynomial; hsr_pipeline_flush finishes the oldest unfinished tile per call and needs whole groups (n % T == 0).
+ * group_moments_dev [2][T][nb][3deg+2], group_total_dev [2][nb][3deg+2], group_coeffs_dev [2][nb][deg+1] doubles (caller-owned; index 0:
+ * even groups, 1: odd groups): per-tile moments, their fixed-order sum (the tree of hsr_moments_reduce over T slots - the bits of
+ * hsr_moments_reduce_solve on the T per-tile moment sets) and the group's polynomial.  2 <= group_tiles <= 64. */
+int hsr_pipeline_create_group(hsr_step_plan* const* slots, int32_t nslots, int32_t group_tiles, double* group_moments_dev,
+                              double* group_total_dev, double* group_coeffs_dev, hsr_stream_t side_stream,
+                              hsr_pipeline** pipeline_out);
 /* Synchronises `main_stream` and the side stream and reports what the device-side polls and the host callback recorded:
  * *sync_error_out = 0, or 1 (the gate of a tile's moments) / 2 (the coefficients of a K3 pre-phase) ran into the 20 s limit, + 16 = host_sum failed. */
 int hsr_pipeline_status(hsr_pipeline* pipeline, hsr_stream_t main_stream, uint32_t* sync_error_out);

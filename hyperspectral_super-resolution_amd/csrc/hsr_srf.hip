@@ -268,13 +268,29 @@ __device__ __forceinline__ bool any_nonfinite4(const float4& v) {
   return z != z;
 }
 
+// Row length (floats) of the output slab staged in LDS: the image's row when it has no pad columns, the band count otherwise - the
+// pad columns are not staged, the flush writes them as zeros (hsr.h: padded rows are owned by the callee).  13 Sentinel-2 bands in
+// rows of 16 floats: 768 B less LDS per workgroup, which is what keeps TWO workgroups per CU at B = 285 (r03: 82 368 B with the
+// padded slab, one workgroup per CU, K1 0.317 ms instead of 0.238); and an odd row stride is bank-conflict free.
+__host__ __device__ __forceinline__ int stage_row(int nb, int ops) { return ops > nb ? nb : ops; }
+
 // Flush the staged [pixel][band] slab of the previous group: contiguous in HBM, 16 bytes per lane.
 template <int T>
-__device__ __forceinline__ void flush_stage(const float* ostage, float* out, int64_t pix0, int npx, int ops, int t) {
+__device__ __forceinline__ void flush_stage(const float* ostage, float* out, int64_t pix0, int npx, int nb, int ops, int t) {
   const int n4 = (npx * ops) >> 2;  // ops is a multiple of 4
   float4* dst = reinterpret_cast<float4*>(out + pix0 * ops);
-  const float4* src = reinterpret_cast<const float4*>(ostage);
-  for (int i = t; i < n4; i += T) st_stream(dst + i, src[i]);
+  if (ops == nb) {                  // no pad columns: the slab is the rows
+    const float4* src = reinterpret_cast<const float4*>(ostage);
+    for (int i = t; i < n4; i += T) st_stream(dst + i, src[i]);
+    return;
+  }
+  const int q = ops >> 2;           // float4 per row: 1 .. 4
+  for (int i = t; i < n4; i += T) {
+    const int px = q == 4 ? i >> 2 : (q == 2 ? i >> 1 : (q == 1 ? i : i / 3));
+    const int c = (i - px * q) * 4;
+    const float* r = ostage + px * nb + c;
+    st_stream(dst + i, make_float4(c < nb ? r[0] : 0.0f, c + 1 < nb ? r[1] : 0.0f, c + 2 < nb ? r[2] : 0.0f, c + 3 < nb ? r[3] : 0.0f));
+  }
 }
 
 // ---- fixed-order sums of the per-lane power sums over the pixels of a group, without LDS ---------------------------
@@ -392,15 +408,6 @@ __device__ __forceinline__ void flush_moments(double (&acc_m)[2][M], const bool 
         *dst = v[q];
     }
   }
-}
-
-// Pad columns nb..ops-1 of the staged output slab: written once per workgroup with zeros, so that the whole rows the
-// flush stores are defined (hsr.h: padded rows are owned by the callee).
-template <int T>
-__device__ __forceinline__ void zero_stage_pad(float* ostage, int npixels, int nb, int ops, int t) {
-  const int padc = ops - nb;
-  if (padc <= 0) return;
-  for (int i = t; i < npixels * padc; i += T) ostage[(i / padc) * ops + nb + (i % padc)] = 0.0f;
 }
 
 // Tail of a single-tile K1+K2 launch with a.fit set: the slot reduction and the solve without a second launch.
@@ -653,8 +660,9 @@ __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
   const float* wl = reinterpret_cast<const float*>(flags + 64 + (BATCH ? 16 : 0));  // 16-byte aligned
   float* ostage = const_cast<float*>(wl) + (WLDS ? a.wtaps : 0);  // [P][out_ps] output slab (OUTV only)
   const int ops = (int)a.out_ps;
+  const int osr = stage_row(a.nb, ops);                           // row stride of the staged slab (floats)
   static_assert(P == 64, "one pixel per lane: the target stage is indexed by lane");
-  float* ystage = ostage + (OUTV ? P * ops : 0);                  // [nb][64] fit targets of the group (DEG > 0)
+  float* ystage = ostage + (OUTV ? P * osr : 0);                  // [nb][64] fit targets of the group (DEG > 0)
   uint32_t* mstage = reinterpret_cast<uint32_t*>(ystage + a.nb * 64);   // [64] mask bytes, one dword slot per lane
   float* prev_out = nullptr;
   int64_t prev_pix0 = 0;
@@ -702,7 +710,6 @@ __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
         for (int i = t; i < kl; i += T) wlw[a.bands.woff[b] + i] = a.wn[(size_t)b * B + a.bands.k0[b] + i];
       }
     }
-    if (OUTV) zero_stage_pad<T>(ostage, P, a.nb, ops, t);
   };
 
 #ifdef HSR_CONSTANTS_FIRST      // diagnostic variant (tools/dbg/build_variants.sh): round 2's order, for A/B runs
@@ -779,7 +786,7 @@ __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
         stage_constants();
         constants_staged = true;
       }
-      if (OUTV) flush_stage<8 * P>(ostage, prev_out, prev_pix0, prev_npx, ops, t);   // no-op before the first group
+      if (OUTV) flush_stage<8 * P>(ostage, prev_out, prev_pix0, prev_npx, a.nb, ops, t);   // no-op before the first group
       if (BATCH && DEG > 0 && pend) {
         flush_moments<M, P, true, !BATCH>(acc_m, bval, bidx, pend_part, lane);
         pend = false;
@@ -908,7 +915,7 @@ __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
     for (int j = 0; j < kBandSlots; ++j) {
       if (bval[j]) {
         const float acc = accv[j];
-        if (OUTV) ostage[pl * ops + bidx[j]] = acc;
+        if (OUTV) ostage[pl * osr + bidx[j]] = acc;
         else if (pvalid) st_stream(cu.pseudo_dev + bidx[j] * a.out_bs + (pix0 + pl) * a.out_ps, acc);
         if (DEG > 0) {
           const float y = yv[j];
@@ -961,7 +968,7 @@ __global__ __launch_bounds__(8 * P, 4) void srf_kernel(const SrfArgs a) {
     }
 #endif
   }
-  if (OUTV) flush_stage<8 * P>(ostage, prev_out, prev_pix0, prev_npx, ops, t);  // last group (after the barrier)
+  if (OUTV) flush_stage<8 * P>(ostage, prev_out, prev_pix0, prev_npx, a.nb, ops, t);  // last group (after the barrier)
 #ifdef HSR_PHASE_STAMPS
   if (a.stamps && lane == 0)
     for (int k = 0; k < 8; ++k) a.stamps[((size_t)blockIdx.x * NW + wave) * 8 + k] = stamp_acc[k];
@@ -1121,7 +1128,8 @@ __global__ __launch_bounds__(512, 4) void srf_u16_kernel(const SrfArgs a) {
   const bool wlds = a.wtaps > 0;
   float* ostage = const_cast<float*>(wl) + a.wtaps;
   const int ops = (int)a.out_ps;
-  float* ystage = ostage + (OUTV ? P * ops : 0);                  // [nb][64] fit targets of the group (DEG > 0)
+  const int osr = stage_row(a.nb, ops);
+  float* ystage = ostage + (OUTV ? P * osr : 0);                  // [nb][64] fit targets of the group (DEG > 0)
   uint32_t* mstage = reinterpret_cast<uint32_t*>(ystage + a.nb * 64);
   float* prev_out = nullptr;
   int64_t prev_pix0 = 0;
@@ -1153,7 +1161,6 @@ __global__ __launch_bounds__(512, 4) void srf_u16_kernel(const SrfArgs a) {
       for (int i = t; i < kl; i += T) wlw[a.bands.woff[b] + i] = a.wn[(size_t)b * B + a.bands.k0[b] + i];
     }
   }
-  if (OUTV) zero_stage_pad<T>(ostage, P, a.nb, ops, t);
 
   constexpr int M = DEG > 0 ? moment_count(DEG) : 1;
   double acc_m[kBandSlots][M];
@@ -1209,7 +1216,7 @@ __global__ __launch_bounds__(512, 4) void srf_u16_kernel(const SrfArgs a) {
       load_targets();
       if (BATCH && wave == 0 && lane < 16)
         __builtin_amdgcn_global_load_lds((gptr_t)unit_record_addr(a.units, nidx, a.nunits, lane), (lptr_t)ustage, 4, 0, 0);
-      if (OUTV) flush_stage<T>(ostage, prev_out, prev_pix0, prev_npx, ops, t);
+      if (OUTV) flush_stage<T>(ostage, prev_out, prev_pix0, prev_npx, a.nb, ops, t);
       if (BATCH && DEG > 0 && pend) {
         flush_moments<M, P, false, !BATCH>(acc_m, bval, bidx, pend_part, lane);
         pend = false;
@@ -1253,7 +1260,7 @@ __global__ __launch_bounds__(512, 4) void srf_u16_kernel(const SrfArgs a) {
       }
       if (bad) acc = __uint_as_float(0x7fc00000u);
       if (bval[j]) {
-        if (OUTV) ostage[pl * ops + bidx[j]] = acc;
+        if (OUTV) ostage[pl * osr + bidx[j]] = acc;
         else if (pvalid) st_stream(cu.pseudo_dev + bidx[j] * a.out_bs + (pix0 + pl) * a.out_ps, acc);
         if (DEG > 0) {
           const float y = yv[j];
@@ -1279,7 +1286,7 @@ __global__ __launch_bounds__(512, 4) void srf_u16_kernel(const SrfArgs a) {
     }
     lds_barrier();
   }
-  if (OUTV) flush_stage<T>(ostage, prev_out, prev_pix0, prev_npx, ops, t);
+  if (OUTV) flush_stage<T>(ostage, prev_out, prev_pix0, prev_npx, a.nb, ops, t);
   if (DEG > 0 && pend) flush_moments<M, P, false, !BATCH>(acc_m, bval, bidx, pend_part, lane);
   if constexpr (DEG > 0 && !BATCH)
     if (a.fit.tickets) fused_fit<DEG>(a.fit, a.one.part_dev, a.one.slots, a.nb, smem, t);
@@ -1330,6 +1337,7 @@ __global__ __launch_bounds__(512, 4) void srf_u16_ring_kernel(const SrfArgs a) {
   const bool wlds = a.wtaps > 0;
   float* ostage = const_cast<float*>(wl) + a.wtaps;
   const int ops = (int)a.out_ps;
+  const int osr = stage_row(a.nb, ops);
 
   const int t = threadIdx.x;
   const int lane = t & 63;
@@ -1364,7 +1372,6 @@ __global__ __launch_bounds__(512, 4) void srf_u16_ring_kernel(const SrfArgs a) {
         }
       }
     }
-    if (OUTV) zero_stage_pad<T>(ostage, P, a.nb, ops, t);
   };
   constexpr int M = DEG > 0 ? moment_count(DEG) : 1;
   double acc_m[kBandSlots][M];
@@ -1478,7 +1485,7 @@ __global__ __launch_bounds__(512, 4) void srf_u16_ring_kernel(const SrfArgs a) {
       if (same_unit || next_unit) prefetch(nx, ng, cur ^ 1);
     }
     fetch_record(next_unit ? nidx + gridDim.x : nidx, cur ^ 1);
-    if (OUTV) flush_stage<T>(ostage, prev_out, prev_pix0, prev_npx, ops, t);
+    if (OUTV) flush_stage<T>(ostage, prev_out, prev_pix0, prev_npx, a.nb, ops, t);
     if (BATCH && DEG > 0 && pend) {
       flush_moments<M, P, false, !BATCH>(acc_m, bval, bidx, pend_part, lane);
       pend = false;
@@ -1504,7 +1511,7 @@ __global__ __launch_bounds__(512, 4) void srf_u16_ring_kernel(const SrfArgs a) {
       }
       if (bad) acc = __uint_as_float(0x7fc00000u);
       if (bval[j]) {
-        if (OUTV) ostage[pl * ops + bidx[j]] = acc;
+        if (OUTV) ostage[pl * osr + bidx[j]] = acc;
         else if (pvalid) st_stream(cu.pseudo_dev + bidx[j] * a.out_bs + (pix0 + pl) * a.out_ps, acc);
         if (DEG > 0) {
           const float y = yv[j];
@@ -1545,7 +1552,7 @@ __global__ __launch_bounds__(512, 4) void srf_u16_ring_kernel(const SrfArgs a) {
 #endif
   if (OUTV) {
     __syncthreads();
-    flush_stage<T>(ostage, prev_out, prev_pix0, prev_npx, ops, t);
+    flush_stage<T>(ostage, prev_out, prev_pix0, prev_npx, a.nb, ops, t);
   }
   if (DEG > 0 && pend) flush_moments<M, P, false, !BATCH>(acc_m, bval, bidx, pend_part, lane);
   if constexpr (DEG > 0 && !BATCH)
@@ -1565,7 +1572,7 @@ static void ensure_dynamic_lds(K kern, size_t lds, size_t* configured) {
 
 template <int DEG, bool OUTV, bool BATCH, bool FASTU, bool APPLY = false>
 static int launch_srf_u16_ring(const SrfArgs& a, int grid, hipStream_t stream) {
-  const size_t lds = (size_t)2 * 64 * a.B * 2 + 128 * sizeof(uint32_t) + (size_t)a.wtaps * 4 + (OUTV ? (size_t)64 * a.out_ps * 4 : 0);
+  const size_t lds = (size_t)2 * 64 * a.B * 2 + 128 * sizeof(uint32_t) + (size_t)a.wtaps * 4 + (OUTV ? (size_t)64 * stage_row(a.nb, (int)a.out_ps) * 4 : 0);
   auto kern = srf_u16_ring_kernel<DEG, OUTV, BATCH, FASTU, APPLY>;
 #ifdef HSR_PHASE_STAMPS
   const_cast<SrfArgs&>(a).stamps = g_stamp_buffer;
@@ -1580,7 +1587,7 @@ static int launch_srf_u16_ring(const SrfArgs& a, int grid, hipStream_t stream) {
 template <int DEG, bool FAST, bool OUTV, bool BATCH>
 static int launch_srf_u16(const SrfArgs& a, int grid, hipStream_t stream) {
   const size_t lds = (size_t)64 * a.B * 2 + (64 + (BATCH ? 16 : 0)) * sizeof(uint32_t) + (size_t)a.wtaps * 4 +
-                     (OUTV ? (size_t)64 * a.out_ps * 4 : 0) + (DEG > 0 ? target_stage_bytes(a.nb) : 0);
+                     (OUTV ? (size_t)64 * stage_row(a.nb, (int)a.out_ps) * 4 : 0) + (DEG > 0 ? target_stage_bytes(a.nb) : 0);
   auto kern = srf_u16_kernel<DEG, FAST, OUTV, BATCH>;
   static thread_local size_t configured = 0;
   ensure_dynamic_lds(kern, lds, &configured);
@@ -1595,7 +1602,7 @@ static bool out_rows_vectorised(const SrfArgs& a, const float* out) {
 
 // two group buffers must fit twice per CU next to the weights and the output slab: B <= ~300 spectral samples
 static bool u16_ring_fits(const SrfArgs& a, bool outv) {
-  const size_t ring_lds = (size_t)2 * 64 * a.B * 2 + 512 + (size_t)a.wtaps * 4 + (outv ? (size_t)64 * a.out_ps * 4 : 0);
+  const size_t ring_lds = (size_t)2 * 64 * a.B * 2 + 512 + (size_t)a.wtaps * 4 + (outv ? (size_t)64 * stage_row(a.nb, (int)a.out_ps) * 4 : 0);
   return ring_lds <= 80 * 1024;
 }
 
@@ -1636,7 +1643,7 @@ static int dispatch_u16(const SrfArgs& a, int deg, bool fast, bool ring, int gri
 template <int DEG, bool FAST, bool WLDS, int P, bool OUTV, bool BATCH, bool APPLY = false>
 static int launch_srf(const SrfArgs& a, int grid, hipStream_t stream) {
   const size_t lds = (size_t)P * a.ldsB * 4 + (64 + (BATCH ? 16 : 0)) * sizeof(uint32_t) + (WLDS ? (size_t)a.wtaps * 4 : 0) +
-                     (OUTV ? (size_t)P * a.out_ps * 4 : 0) + (DEG > 0 ? target_stage_bytes(a.nb) : 0);
+                     (OUTV ? (size_t)P * stage_row(a.nb, (int)a.out_ps) * 4 : 0) + (DEG > 0 ? target_stage_bytes(a.nb) : 0);
   auto kern = srf_kernel<DEG, FAST, WLDS, P, OUTV, BATCH, APPLY>;
   static thread_local size_t configured = 0;
   ensure_dynamic_lds(kern, lds, &configured);
@@ -1831,7 +1838,7 @@ extern "C" int hsr_srf_fused_launch_supported(int32_t cube_dtype, int32_t B, int
                 "%s: uint16 tiles ride only in the double-buffered kernel (u16_single_buffer = 0, 48 <= B, two %d-byte group buffers + "
                 "%d taps + the %lld-float rows within 80 KB of LDS)", who, 64 * B * 2, a.wtaps, (long long)out_ps);
   } else {
-    const size_t lds = (size_t)64 * a.ldsB * 4 + 64 * sizeof(uint32_t) + (size_t)a.wtaps * 4 + (size_t)64 * out_ps * 4 + hsr::target_stage_bytes(nb);
+    const size_t lds = (size_t)64 * a.ldsB * 4 + 64 * sizeof(uint32_t) + (size_t)a.wtaps * 4 + (size_t)64 * hsr::stage_row(nb, (int)out_ps) * 4 + hsr::target_stage_bytes(nb);
     HSR_REQUIRE(lds <= 160 * 1024, HSR_ERR_UNSUPPORTED, "%s: a 64-pixel group of B=%d samples needs %zu bytes of LDS (160 KB per workgroup)", who, B, lds);
   }
   return HSR_OK;

@@ -2170,7 +2170,24 @@ def test_mosaic_8_tiles_1024_on_one_gpu(torch_gpu):
     for bb in range(nb):
         np.testing.assert_allclose(np.polyval(c2[bb].cpu().numpy(), xs), np.polyval(co[bb], xs), rtol=1e-7, atol=1e-10)
     assert torch.equal(outs2[7].pseudo.view(torch.int32), outs[7].pseudo.view(torch.int32))
-    del outs, outs2, probs
+    # the group pipeline (r04: one kernel per tile, one fit per step; bench.py --tiles-per-gpu 8 at N = 1) at full size: two steps, every
+    # tile with the per-tile form's coefficients, moments and images bit for bit
+    gp = SpectralFusion(p0.emit_w, p0.srf, p0.good_mask, deg=3, min_valid=0.0, min_count=50, fuse_apply=True, group_tiles=T)
+    got = []
+    for _ in range(2):
+        for p in probs:
+            o = gp.submit(p.cube, p.real)
+            if o is not None:
+                got.append((o.coeffs.clone(), o.moments.clone(), o.matched[::4099].clone(), o.pseudo[::4099].clone()))
+    got += [(o.coeffs.clone(), o.moments.clone(), o.matched[::4099].clone(), o.pseudo[::4099].clone()) for o in gp.drain()]
+    torch.cuda.synchronize()
+    assert len(got) == 2 * T
+    for k, (gc, gm, gmat, gps) in enumerate(got):
+        assert torch.equal(gc.view(torch.int64), coeffs.view(torch.int64)) and torch.equal(gm.view(torch.int64), moments.view(torch.int64)), k
+        assert torch.equal(gmat.view(torch.int32), outs[k % T].matched[::4099].view(torch.int32)), k
+        assert torch.equal(gps.view(torch.int32), outs[k % T].pseudo[::4099].view(torch.int32)), k
+    gp.close()
+    del outs, outs2, probs, got
     torch.cuda.empty_cache()
 
 

@@ -176,15 +176,15 @@ def test_bench_real_launcher_path_with_rccl_at_n1():
     assert line["rccl_ranks"] == 1 and line["world_size"] == 1 and line["n_gpus"] == 1
     assert line["config"]["exchange_transport"] == "rccl" and "exchange issued from C" in line["config"]["pipeline"]
     assert line["value"] > 0 and line["roofline"]["frac"] > 0.3
-    # the parent never loaded torch.cuda / HIP: its device count comes from sysfs
-    sys.path.insert(0, ROOT)
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
-    bench = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(bench)
-    assert bench.visible_gpu_count() >= 1
-    import inspect
-    assert "import torch" not in inspect.getsource(bench.self_launch) and "torch" not in inspect.getsource(bench.visible_gpu_count)
+    # the parent never loads torch (hence no HIP): its device count comes from sysfs
+    import subprocess
+    code = ("import sys, importlib.util; spec = importlib.util.spec_from_file_location('bench_mod', %r); b = importlib.util.module_from_spec(spec); "
+            "spec.loader.exec_module(b); a = b.parse_args(['--gpus', '3', '--launcher']); n = b.visible_gpu_count(); rc = b.self_launch(a, ['--gpus', '3']); "
+            "assert 'torch' not in sys.modules, 'the launching parent imported torch'; print(n, rc)" % os.path.join(ROOT, "bench.py"))
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    n, rc = r.stdout.split()[-2:]
+    assert int(n) == 1 and int(rc) == 2 and "--gpus 3 needs 3 visible GPUs" in r.stderr      # one GPU on the box: refused before any rank starts
 
 
 def test_bench_n1_reports_cold_beside_placed():

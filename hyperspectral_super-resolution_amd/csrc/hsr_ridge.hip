@@ -886,6 +886,8 @@ __device__ __forceinline__ void mfma_steps103(const float (&z)[11], int kh, cons
 }
 
 
+// (r04, measured and dropped: two accumulator tiles per wave for T <= 32 - even / odd steps, added at the end - so that a wave always
+// has an independent MFMA to issue: 0.2039 vs 0.2054 ms per Mpixel.  The chain's latency is not what idles the matrix pipe.)
 // the 10 inputs of one pixel.  Pixel-major rows (x_cs == 1, the (N, 10) arrays of predict()) with an even pitch and an 8-byte
 // aligned base are read as five float2 instead of ten scalars: a wave's 32 pixels then touch their 40-byte rows once per 8 bytes
 __device__ __forceinline__ void pred_load10(const PredArgs& a, int64_t pc, float (&x)[10]) {
@@ -1012,6 +1014,86 @@ __global__ __launch_bounds__(256, pred103_occupancy(TT)) void predict103_kernel(
   }
 }
 
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+// ---- the K axis in ORBIT order (r04) ------------------------------------------------------------------------------------------
+// An MFMA's K index is spread over lane groups (two for v_mfma_f32_32x32x2_f32, four for v_mfma_f32_16x16x4_f32), so the lane
+// groups of one instruction need DIFFERENT monomials - compile-time index triples - of their pixel.  Rounds 1-3 formed both
+// products in every lane and picked one (v_cndmask): ~5 VALU per step, and the measurements of r04 say the SIMD does not hide
+// VALU work under its own MFMAs (T <= 32: 64 % matrix-pipe busy with 20 cycles of VALU per 64-cycle MFMA; a 16-target variant with
+// 20 VALU per 64 cycles of MFMA ran SLOWER than the 32-target kernel).  The order of the K axis is free (a sum): the 286 index
+// multisets {a <= b <= c} over the 11 symbols (10 inputs + the constant 1) are grouped into orbits of a symbol permutation sigma
+// of order G = number of lane groups; step s takes one orbit, and lane group g evaluates the orbit's REPRESENTATIVE on its own copy
+// of the inputs, permuted once per tile (Z_g[m] = z[sigma^g(m)]): Z[a] Z[b] Z[c] in group g is the monomial sigma^g(a, b, c).  One code
+// path, ~1.3 v_mul per step, no pick.  Members an orbit repeats (short orbits) meet a zero row of W; the staging loop gathers W's
+// rows in orbit order.   G = 2: sigma = (0 1)(2 3)(4 5)(6 7)(8 9): 146 steps for 143.   G = 4: sigma = (0 1 2 3)(4 5 6 7): 82 for 71.5.
+template <int G>
+constexpr int perm_sym(int m, int g) {
+  if (G == 2) return (m < 10 && (g & 1)) ? (m ^ 1) : m;
+  return m < 4 ? (m + g) & 3 : (m < 8 ? 4 + ((m - 4 + g) & 3) : m);
+}
+template <int G>
+struct Orbits103 {
+  uint8_t rep[160][3];     // representative triple of step s (symbols 0 .. 10; 10 = the constant 1)
+  int16_t src[160][G];     // feature row of W that lane group g's member of the orbit multiplies, -1: none (a repeat, or 1 * 1 * 1)
+  int steps;
+};
+template <int G>
+constexpr Orbits103<G> make_orbits103() {
+  Orbits103<G> o{};
+  bool seen[11][11][11] = {};
+  int n = 0;
+  for (int a = 0; a <= 10; ++a)
+    for (int b = a; b <= 10; ++b)
+      for (int c = b; c <= 10; ++c) {
+        if (seen[a][b][c]) continue;
+        o.rep[n][0] = (uint8_t)a; o.rep[n][1] = (uint8_t)b; o.rep[n][2] = (uint8_t)c;
+        for (int g = 0; g < G; ++g) {
+          int t0 = perm_sym<G>(a, g), t1 = perm_sym<G>(b, g), t2 = perm_sym<G>(c, g);
+          if (t0 > t1) { const int x = t0; t0 = t1; t1 = x; }
+          if (t1 > t2) { const int x = t1; t1 = t2; t2 = x; }
+          if (t0 > t1) { const int x = t0; t0 = t1; t1 = x; }
+          int row = -1;
+          if (!seen[t0][t1][t2]) {
+            seen[t0][t1][t2] = true;
+            for (int f = 0; f < 285; ++f)      // kTab103 lists a monomial's indices in ascending order, padded with 10
+              if (kTab103.v[f][0] == t0 && kTab103.v[f][1] == t1 && kTab103.v[f][2] == t2) row = f;
+          }
+          o.src[n][g] = (int16_t)row;
+        }
+        ++n;
+      }
+  o.steps = n;
+  return o;
+}
+constexpr Orbits103<4> kOrb103 = make_orbits103<4>();
+constexpr Orbits103<2> kOrb2 = make_orbits103<2>();
+static_assert(kOrb103.steps == 82, "orbits of (0 1 2 3)(4 5 6 7) on the 286 index multisets");
+static_assert(kOrb2.steps == 146, "orbits of (0 1)(2 3)(4 5)(6 7)(8 9) on the 286 index multisets");
+constexpr int kStepsOrb = kOrb103.steps, kStepsOrb2 = kOrb2.steps;
+static int16_t* g_orb_rows_dev = nullptr;              // kOrb103.src then kOrb2.src on the device (uploaded by hsr_polyfeat_prepare, not on a launch path)
+
+// the slice kernels' MFMA chain over the orbit-ordered K axis (G = 2): Z is the lane half's permuted copy of the inputs
+template <int TT>
+__device__ __forceinline__ void mfma_steps_orb2(const float (&Z)[11], int kh, const float* __restrict__ wl, int ldwl, int j, f32x16 (&acc)[TT]) {
+  float wc[TT], wn[TT];
+  const float* wr = wl + kh * ldwl + j;              // A[i = target][k] = staged row 2 s + kh
+#pragma unroll
+  for (int q = 0; q < TT; ++q) wc[q] = wr[q * 32];
+#pragma unroll
+  for (int s = 0; s < kStepsOrb2; ++s) {
+    const float bv = Z[kOrb2.rep[s][0]] * Z[kOrb2.rep[s][1]] * Z[kOrb2.rep[s][2]];      // B[k = 2 s + kh][pixel j]
+    if (s + 1 < kStepsOrb2) {
+#pragma unroll
+      for (int q = 0; q < TT; ++q) wn[q] = wr[(size_t)2 * (s + 1) * ldwl + q * 32];
+    }
+#pragma unroll
+    for (int q = 0; q < TT; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x2f32(wc[q], bv, acc[q], 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < TT; ++q) wc[q] = wn[q];
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
 // Many targets (T > 96, e.g. EMIT's 285 bands): the chunked path above re-stages the whole 329 KB of W through LDS for
 // every 128-pixel tile, with nine barriers per tile, and sat at 39 % of the f32-MFMA peak against 50 % for T <= 32 where
 // W is resident.  W does not fit one LDS, but a SLICE of 96 targets does (286 x 96 x 4 = 110 KB): blockIdx.y picks the
@@ -1030,20 +1112,28 @@ __global__ __launch_bounds__(256, pred103_occupancy(TT)) void predict103_kernel(
 #ifndef HSR_SLICE2_WAVES
 #define HSR_SLICE2_WAVES 16
 #endif
-constexpr int slice_waves(int tt) { return tt == 3 ? HSR_SLICE_WAVES : HSR_SLICE2_WAVES; }
+#ifndef HSR_SLICE1_WAVES
+#define HSR_SLICE1_WAVES 16
+#endif
+#ifndef HSR_SLICE1_WGS
+#define HSR_SLICE1_WGS 1
+#endif
+constexpr int slice_waves(int tt) { return tt == 3 ? HSR_SLICE_WAVES : (tt == 1 ? HSR_SLICE1_WAVES : HSR_SLICE2_WAVES); }
+constexpr int slice_wgs(int tt) { return tt == 1 ? HSR_SLICE1_WGS : 1; }       // workgroups per CU
 template <int TT>
-__global__ __launch_bounds__(64 * slice_waves(TT), slice_waves(TT) / 4) void predict103_slice_kernel(const PredArgs a) {
+__global__ __launch_bounds__(64 * slice_waves(TT), (slice_waves(TT) * slice_wgs(TT) + 3) / 4) void predict103_slice_kernel(const PredArgs a, const int16_t* __restrict__ src_rows) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  float* wl = reinterpret_cast<float*>(smem);
+  float* wl = reinterpret_cast<float*>(smem);       // [2 * kStepsOrb2][Tp]: W's rows in orbit order (kOrb2)
   constexpr int Tp = TT * 32;
   constexpr int kSliceThreads = 64 * slice_waves(TT);      // waves per workgroup = waves per CU (one workgroup per CU)
   constexpr int kSlicePix = 32 * slice_waves(TT);          // pixels per tile: 32 per wave
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int j = lane & 31, kh = lane >> 5;
   const int t0 = blockIdx.y * Tp;                   // first target of this workgroup's slice
-  for (int i = t; i < 286 * Tp; i += kSliceThreads) {
+  for (int i = t; i < 2 * kStepsOrb2 * Tp; i += kSliceThreads) {
     const int r = i / Tp, c = i % Tp;
-    wl[i] = t0 + c < a.T ? a.W[(size_t)r * a.ldw + t0 + c] : 0.0f;
+    const int f = src_rows[r];
+    wl[i] = (f >= 0 && t0 + c < a.T) ? a.W[(size_t)f * a.ldw + t0 + c] : 0.0f;
   }
   __syncthreads();
   float bv[TT][16];                                    // bias of this lane's targets: tile-invariant
@@ -1073,13 +1163,19 @@ __global__ __launch_bounds__(64 * slice_waves(TT), slice_waves(TT) / 4) void pre
     }
     bad = bad && a.nan_bad != 0;
     z[10] = 1.0f;
+#pragma unroll
+    for (int c = 0; c < 10; c += 2) {                   // the lane half's copy: kh = 1 swaps the inputs pairwise (sigma of kOrb2)
+      const float lo = z[c], hi = z[c + 1];
+      z[c] = kh ? hi : lo;
+      z[c + 1] = kh ? lo : hi;
+    }
     if ((tile + gridDim.x) * kSlicePix < a.npix) load_inputs(tile + gridDim.x);
     f32x16 acc[TT];
 #pragma unroll
     for (int q = 0; q < TT; ++q)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[q][r] = bv[q][r];
-    mfma_steps103<0, kSteps103, TT>(z, kh, wl, Tp, 0, j, acc);
+    mfma_steps_orb2<TT>(z, kh, wl, Tp, j, acc);
     if (p < a.npix) {
       int64_t ostride = a.out_stride;
       int tmax = a.T;
@@ -1100,9 +1196,123 @@ __global__ __launch_bounds__(64 * slice_waves(TT), slice_waves(TT) / 4) void pre
   }
 }
 
+// Few targets (r04).  v_mfma_f32_32x32x2_f32 puts 32 targets on the M axis, so T = 16 cost what T = 32 costs (r03: 0.189 ms per
+// Mpixel for both).  v_mfma_f32_16x16x4_f32 has the same rate (16 x 16 x 4 x 2 flop in 32 cycles) with 16 targets per tile; a wave
+// holds one tile of 16 targets x two sets of 16 pixels.
+//   A[i = target][k] = W[k][target]: lane (i = lane & 15, g = lane >> 4) reads row 4 s + g of the staged W (64 consecutive LDS words);
+//   B[k][j = pixel]:  lane (j, g) must supply "monomial 4 s + g" of ITS pixel - four DIFFERENT compile-time index triples in the four
+//     lane groups of one instruction.  Two versions that pick per lane were measured and dropped: a ?: chain over the four products
+//     (hipcc wraps every pick in exec-masked branches: 0.173 ms) and bit-mask picks (20 VALU per step against 64 cycles of matrix
+//     pipe, and the SIMD does not hide them: 0.201 ms).  What is built: the ORDER of the K axis is free (a sum), so the 286 index
+//     multisets {a <= b <= c} over the 11 symbols (10 inputs + the constant) are grouped into orbits of the symbol permutation
+//     sigma = (0 1 2 3)(4 5 6 7); step s takes one orbit: lane group g computes the orbit's representative on ITS OWN copy of the
+//     inputs, permuted once per tile (Z_g[m] = z[sigma^g(m)]): Z[a] Z[b] Z[c] in group g IS the monomial sigma^g(a, b, c).  One code
+//     path, two v_mul per step and pixel set, no pick.  82 orbits (66 of four, 6 of two, 10 fixed) instead of 286 / 4 = 71.5 steps:
+//     the repeated members of short orbits meet a zero row of W.  The staging loop gathers W's rows in orbit order.
+//   D[i][j]: lane (j, g) holds targets 4 g + r, r = 0 .. 3, of pixel j: 64-byte store segments per target.
+// One 16-wave workgroup per CU, W staged once.  (Three such tiles for 33 <= T <= 48 were measured too: 82 x 6 MFMAs of 32 cycles are
+// no better than the 64-target slice's 143 x 2 of 64; those T keep the slice kernel.)
+#ifndef HSR_X16_WAVES
+#define HSR_X16_WAVES 12
+#endif
+#ifndef HSR_X16_WGS
+#define HSR_X16_WGS 2
+#endif
+constexpr int kX16Waves = HSR_X16_WAVES, kX16Wgs = HSR_X16_WGS;     // 2 x 12 waves per CU = 6 per SIMD at <= 80 VGPRs (r04: 16 x 1: 0.132 ms per Mpixel)
+__global__ __launch_bounds__(64 * kX16Waves, kX16Wgs) void predict103_x16_kernel(const PredArgs a, const int16_t* __restrict__ src_rows) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* wl = reinterpret_cast<float*>(smem);          // [4 * kStepsOrb][16]
+  constexpr int kPix = 32 * kX16Waves;                 // pixels per workgroup tile: 32 per wave
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int i = lane & 15, g = lane >> 4;
+  for (int e = t; e < 4 * kStepsOrb * 16; e += 64 * kX16Waves) {
+    const int r = e >> 4, c = e & 15;
+    const int f = src_rows[r];
+    wl[e] = (f >= 0 && c < a.T) ? a.W[(size_t)f * a.ldw + c] : 0.0f;
+  }
+  __syncthreads();
+  float bias[4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r) bias[r] = 4 * g + r < a.T ? a.bias[4 * g + r] : 0.0f;
+  float xn[2][10];
+  auto load_inputs = [&](int64_t tile_) {
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int64_t p_ = tile_ * kPix + wave * 32 + h * 16 + i;
+      pred_load10(a, p_ < a.npix ? p_ : a.npix - 1, xn[h]);
+    }
+  };
+  if ((int64_t)blockIdx.x * kPix < a.npix) load_inputs(blockIdx.x);
+  for (int64_t tile = blockIdx.x; tile * kPix < a.npix; tile += gridDim.x) {
+    float Z[2][11];                                    // this lane group's permuted copy of the standardised inputs
+    bool bad[2] = {false, false};
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      float z[8];
+#pragma unroll
+      for (int c = 0; c < 10; ++c) {
+        const float xr = xn[h][c];
+        bad[h] = bad[h] || pred_bad_input(xr, a.use_nodata, a.nodata);
+        const float zc = (xr - a.mean[c]) * a.inv[c];
+        if (c < 8) z[c] = zc; else Z[h][c] = zc;
+      }
+      bad[h] = bad[h] && a.nan_bad != 0;
+      Z[h][10] = 1.0f;
+#pragma unroll
+      for (int m = 0; m < 8; ++m) {                    // Z[m] = z[sigma^g(m)]: a rotation inside each block of four
+        const int b4 = m & 4, r4 = m & 3;
+        const float v0 = z[b4 + r4], v1 = z[b4 + ((r4 + 1) & 3)], v2 = z[b4 + ((r4 + 2) & 3)], v3 = z[b4 + ((r4 + 3) & 3)];
+        Z[h][m] = g == 0 ? v0 : (g == 1 ? v1 : (g == 2 ? v2 : v3));
+      }
+    }
+    if ((tile + gridDim.x) * kPix < a.npix) load_inputs(tile + gridDim.x);
+    f32x4 acc[2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[h][r] = bias[r];
+    const float* wr = wl + g * 16 + i;
+    float wc = wr[0], wn = 0.0f;
+#pragma unroll
+    for (int s = 0; s < kStepsOrb; ++s) {
+      const float b0 = Z[0][kOrb103.rep[s][0]] * Z[0][kOrb103.rep[s][1]] * Z[0][kOrb103.rep[s][2]];
+      const float b1 = Z[1][kOrb103.rep[s][0]] * Z[1][kOrb103.rep[s][1]] * Z[1][kOrb103.rep[s][2]];
+      if (s + 1 < kStepsOrb) wn = wr[(s + 1) * 64];
+      acc[0] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc, b0, acc[0], 0, 0, 0);
+      acc[1] = __builtin_amdgcn_mfma_f32_16x16x4f32(wc, b1, acc[1], 0, 0, 0);
+      wc = wn;
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    int64_t ostride = a.out_stride;
+    int tmax = a.T;
+    asm volatile("" : "+s"(ostride), "+s"(tmax));      // keep the addressing inside the loop (see predict103_kernel)
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int64_t p = tile * kPix + wave * 32 + h * 16 + i;
+      if (p < a.npix) {
+        float* orow = a.out + (size_t)(4 * g) * ostride + p;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = predict_activation(acc[h][r], a.act);
+          if (bad[h]) v = __uint_as_float(0x7fc00000u);
+          if (4 * g + r < tmax) orow[(size_t)r * ostride] = v;
+        }
+      }
+    }
+  }
+}
+
+static void launch_predict103_x16(const PredArgs& a, hipStream_t s) {
+  const size_t lds = (size_t)4 * kStepsOrb * 16 * 4;
+  constexpr int pix = 32 * kX16Waves;
+  int64_t tiles = (a.npix + pix - 1) / pix;
+  const int gx = (int)(tiles < 256 * kX16Wgs ? tiles : 256 * kX16Wgs);
+  hipLaunchKernelGGL(predict103_x16_kernel, dim3(gx), dim3(64 * kX16Waves), lds, s, a, g_orb_rows_dev);
+}
+
 template <int TT>
 static void launch_predict103_slices(const PredArgs& a, int slices, hipStream_t s) {
-  const size_t lds = (size_t)286 * TT * 32 * 4;
+  const size_t lds = (size_t)2 * kStepsOrb2 * TT * 32 * 4;
   static thread_local bool configured = false;
   if (!configured) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(predict103_slice_kernel<TT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1111,10 +1321,10 @@ static void launch_predict103_slices(const PredArgs& a, int slices, hipStream_t 
   }
   constexpr int pix = 32 * slice_waves(TT);
   int64_t tiles = (a.npix + pix - 1) / pix;
-  int gx = 256 / slices;                       // one workgroup per CU in all (73 / 110 KB of LDS each)
+  int gx = 256 * slice_wgs(TT) / slices;       // one workgroup per CU in all (73 / 110 KB of LDS each; T <= 32: slice_wgs)
   if (gx < 1) gx = 1;
   if (tiles < gx) gx = (int)tiles;
-  hipLaunchKernelGGL(predict103_slice_kernel<TT>, dim3(gx, slices), dim3(64 * slice_waves(TT)), lds, s, a);
+  hipLaunchKernelGGL(predict103_slice_kernel<TT>, dim3(gx, slices), dim3(64 * slice_waves(TT)), lds, s, a, g_orb_rows_dev + 4 * kStepsOrb);
 }
 
 template <int TT, bool WHOLE>
@@ -1135,8 +1345,14 @@ static void launch_predict103(const PredArgs& a, hipStream_t s) {
 
 // returns false when the shape is not covered (caller falls back to the generic kernel)
 static bool try_predict103(const PredArgs& a, hipStream_t s) {
-  if (a.n_in != 10 || a.nfeat != 285) return false;
+  if (a.n_in != 10 || a.nfeat != 285 || g_orb_rows_dev == nullptr) return false;
   const int tt = a.ttiles;
+#ifndef HSR_PRED_NO_X16
+  if (a.T <= 16) {                                        // 16-target tiles (v_mfma_f32_16x16x4_f32)
+    launch_predict103_x16(a, s);
+    return true;
+  }
+#endif
 #ifdef HSR_PRED_CHUNKED
   if (tt == 1) launch_predict103<1, true>(a, s);          // diagnostic builds: four 4-wave workgroups per CU, each with its own copy of W
 #else
@@ -1169,6 +1385,18 @@ static int ensure_table(int n_in, int degree) {
   g_table_nin = n_in;
   g_table_deg = degree;
   g_table_nfeat = nf;
+  if (g_orb_rows_dev == nullptr) {                     // the orbit orders of the predict103 kernels' K axis, once per process
+    std::vector<int16_t> rows((size_t)4 * kStepsOrb + (size_t)2 * kStepsOrb2);
+    for (int st = 0; st < kStepsOrb; ++st)
+      for (int g = 0; g < 4; ++g) rows[(size_t)4 * st + g] = kOrb103.src[st][g];
+    for (int st = 0; st < kStepsOrb2; ++st)
+      for (int g = 0; g < 2; ++g) rows[(size_t)4 * kStepsOrb + 2 * st + g] = kOrb2.src[st][g];
+    if (hipMalloc(&g_orb_rows_dev, rows.size() * sizeof(int16_t)) != hipSuccess ||
+        hipMemcpy(g_orb_rows_dev, rows.data(), rows.size() * sizeof(int16_t), hipMemcpyHostToDevice) != hipSuccess) {
+      (void)hipGetLastError();
+      g_orb_rows_dev = nullptr;                        // without it the notebook's shape takes the generic kernel
+    }
+  }
   return nf;
 }
 

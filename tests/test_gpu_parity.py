@@ -882,10 +882,11 @@ def _a9_problem(rng, N, Cin, T):
     return X, Y
 
 
-@pytest.mark.parametrize("T", [33, 64, 96, 97, 128, 130, 192, 285])
+@pytest.mark.parametrize("T", [5, 16, 33, 41, 48, 64, 96, 97, 128, 130, 192, 285])
 def test_predict103_kernel_families_vs_oracle(torch_gpu, T):
     """Every many-target predict kernel of the notebook's shape (10 inputs, degree 3; Spectral_matching.ipynb raw :192-213,
-    :475-490 generalised to T targets) against the float64 oracle, NOT against itself: T 33-64 runs one 64-target slice of
+    :475-490 generalised to T targets) against the float64 oracle, NOT against itself: T <= 16 and 33-48 run the 16-target tiles of
+    predict103_x16_kernel<1 / 3> (v_mfma_f32_16x16x4_f32, r04), T 49-64 one 64-target slice of
     predict103_slice_kernel<2>, 65-96 one 96-target slice of <3>, above that as few and as narrow slices as T allows (97 and
     128: two of 64; 130, 192: two of 96; 285: three of 96) (hsr_ridge.hip).  Two views:
       (a) the kernels alone - the ORACLE'S model loaded with from_params, so a wrong W-slice offset or target-tile epilogue

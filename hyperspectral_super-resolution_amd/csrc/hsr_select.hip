@@ -7,6 +7,8 @@
 // Each pass streams the planes once: 3 x 4 B per masked sample, ~4 % of the cube's bytes.
 // The final interpolation mirrors NumPy's _lerp bit for bit:
 //   d = float32(b - a);  t < 0.5 ? a + d*t : b - d*(1 - t)   (float64), NaN if any masked NaN.
+#include <type_traits>
+
 #include "hsr_common.h"
 #include "hsr_select_dev.h"
 
@@ -43,15 +45,15 @@ constexpr int kRowsThreads = HSR_ROWS_THREADS;    // workgroup of select_hist_ro
 // per load, two loads in flight per thread.  The first version walked the plane sample by sample behind a
 // dependent mask-byte load and ran at 1.4 TB/s.
 // MODE 0: any strides, one sample per load.  MODE 1: VEC above.  (Band-last rows of 4 floats: select_hist_rows4_kernel.)
+// One radix pass of channel c over the pixels of workgroup `bid` of `nblk` (kSelThreads threads): LDS-privatised histogram in
+// h[NB] (+ *nancp), flushed to the global one with integer atomics.  Shared by the per-pass kernels and the one-launch form.
 template <int PASS, int MODE>
-__global__ __launch_bounds__(kSelThreads) void select_hist_kernel(const SelArgs a) {
+__device__ __forceinline__ void hist_pass_planes(const SelArgs& a, int c, int bid, int nblk, uint32_t* h, uint32_t* nancp) {
   constexpr bool VEC = MODE == 1;
   constexpr int NBINS = PASS == 1 ? kBins1 : (PASS == 2 ? kBins2 : kBins3);
   constexpr int CP = PASS == 1 ? kPass1Copies : 1;
   constexpr int NB = PASS == 1 ? kBins1 * CP : NBINS * kLdsQ;
-  __shared__ uint32_t h[NB];
-  __shared__ uint32_t nanc;
-  const int c = blockIdx.y;
+  uint32_t& nanc = *nancp;
   for (int i = threadIdx.x; i < NB; i += kSelThreads) h[i] = 0u;
   if (threadIdx.x == 0) nanc = 0u;
   uint32_t pre[kQ] = {0u, 0u, 0u, 0u};
@@ -65,13 +67,13 @@ __global__ __launch_bounds__(kSelThreads) void select_hist_kernel(const SelArgs 
                           : (PASS == 2 ? a.hist2 + (size_t)c * kQ * kBins2 : a.hist3 + (size_t)c * kQ * kBins3);
   __syncthreads();
   const float* x = a.x + (size_t)c * a.cs;
-  const int64_t stride = (int64_t)gridDim.x * kSelThreads;
+  const int64_t stride = (int64_t)nblk * kSelThreads;
   if (VEC) {
     const int64_t n4 = a.npix >> 2;
     const float4* x4 = reinterpret_cast<const float4*>(x);
     const uint32_t* m4 = reinterpret_cast<const uint32_t*>(a.mask);
     // whole-wave trip count: hist_add_wave uses ballots, so every lane of a wave runs every iteration
-    const int64_t first = (int64_t)blockIdx.x * kSelThreads + (threadIdx.x & ~63);
+    const int64_t first = (int64_t)bid * kSelThreads + (threadIdx.x & ~63);
     for (int64_t base = first; base < n4; base += 2 * stride) {
       const int64_t i0 = base + (threadIdx.x & 63), i1 = i0 + stride;
       const bool on0 = i0 < n4, on1 = i1 < n4;
@@ -94,14 +96,14 @@ __global__ __launch_bounds__(kSelThreads) void select_hist_kernel(const SelArgs 
       hist_sample<PASS, CP>(h, &nanc, pre, second, g, v1.z, (mk1 & 0x00ff0000u) != 0u);
       hist_sample<PASS, CP>(h, &nanc, pre, second, g, v1.w, (mk1 & 0xff000000u) != 0u);
     }
-    if (blockIdx.x == 0 && threadIdx.x < 64) {   // up to 3 tail samples, one wave (ballots need the whole wave)
+    if (bid == 0 && threadIdx.x < 64) {   // up to 3 tail samples, one wave (ballots need the whole wave)
       const int64_t p = n4 * 4 + threadIdx.x;
       const bool on = p < a.npix;
       const float v = on ? x[p] : 0.0f;
       hist_sample<PASS, CP>(h, &nanc, pre, second, g, v, on && (!a.mask || a.mask[p] != 0));
     }
   } else {
-    const int64_t first = (int64_t)blockIdx.x * kSelThreads + (threadIdx.x & ~63);
+    const int64_t first = (int64_t)bid * kSelThreads + (threadIdx.x & ~63);
     for (int64_t base = first; base < a.npix; base += stride) {
       const int64_t p = base + (threadIdx.x & 63);
       const bool on = p < a.npix && (!a.mask || a.mask[p] != 0);
@@ -122,18 +124,25 @@ __global__ __launch_bounds__(kSelThreads) void select_hist_kernel(const SelArgs 
   if (PASS == 1 && threadIdx.x == 0 && nanc) atomicAdd(&a.hist1[(size_t)c * kHist1 + kBins1], nanc);
 }
 
+template <int PASS, int MODE>
+__global__ __launch_bounds__(kSelThreads) void select_hist_kernel(const SelArgs a) {
+  constexpr int NBINS = PASS == 1 ? kBins1 : (PASS == 2 ? kBins2 : kBins3);
+  constexpr int NB = PASS == 1 ? kBins1 * kPass1Copies : NBINS * kLdsQ;
+  __shared__ uint32_t h[NB];
+  __shared__ uint32_t nanc;
+  hist_pass_planes<PASS, MODE>(a, blockIdx.y, blockIdx.x, gridDim.x, h, &nanc);
+}
+
 // Band-last rows of exactly 4 floats (the RGB + pad images of the driver): ONE pass over the image per radix pass
 // for all channels - a 16-byte load per pixel, the histograms of all nb <= 4 channels side by side in LDS (24 / 96 /
 // 48 KB for three channels).  Walking the image once per channel, sample by sample (MODE 0), ran at ~1.1 TB/s on the
 // 6144 x 6144 x 4 image and was half of match_pair's time; loading whole rows once per channel was worse still
 // (the channel passes do not share L2 lines in time: 3x the traffic).
 template <int PASS>
-__global__ __launch_bounds__(kRowsThreads) void select_hist_rows4_kernel(const SelArgs a) {
+__device__ __forceinline__ void hist_pass_rows4(const SelArgs& a, int bid, int nblk, uint32_t* hall /*[nb][NB]*/, uint32_t (&nanc)[4],
+                                                uint32_t (&pre_s)[4][kQ]) {
   constexpr int NBINS = PASS == 1 ? kBins1 : (PASS == 2 ? kBins2 : kBins3);
   constexpr int NB = PASS == 1 ? kBins1 : NBINS * kLdsQ;
-  extern __shared__ uint32_t hall[];          // [nb][NB]
-  __shared__ uint32_t nanc[4];
-  __shared__ uint32_t pre_s[4][kQ];
   const int nb = a.nb;
   for (int i = threadIdx.x; i < nb * NB; i += kRowsThreads) hall[i] = 0u;
   if (threadIdx.x < 4) nanc[threadIdx.x] = 0u;
@@ -158,8 +167,8 @@ __global__ __launch_bounds__(kRowsThreads) void select_hist_rows4_kernel(const S
   }
   const float4* rows = reinterpret_cast<const float4*>(a.x);
   constexpr int U = 4;
-  const int64_t stride = (int64_t)gridDim.x * kRowsThreads;
-  const int64_t first = (int64_t)blockIdx.x * kRowsThreads + (threadIdx.x & ~63);
+  const int64_t stride = (int64_t)nblk * kRowsThreads;
+  const int64_t first = (int64_t)bid * kRowsThreads + (threadIdx.x & ~63);
   for (int64_t base = first; base < a.npix; base += U * stride) {   // wave-uniform trip count (ballots inside)
     float4 v[U];
     bool on[U];
@@ -196,6 +205,14 @@ __global__ __launch_bounds__(kRowsThreads) void select_hist_rows4_kernel(const S
 }
 
 template <int PASS>
+__global__ __launch_bounds__(kRowsThreads) void select_hist_rows4_kernel(const SelArgs a) {
+  extern __shared__ uint32_t hall[];          // [nb][NB]
+  __shared__ uint32_t nanc[4];
+  __shared__ uint32_t pre_s[4][kQ];
+  hist_pass_rows4<PASS>(a, blockIdx.x, gridDim.x, hall, nanc, pre_s);
+}
+
+template <int PASS>
 static void launch_rows4(const SelArgs& a, hipStream_t s) {
   constexpr int NB = PASS == 1 ? kBins1 : (PASS == 2 ? kBins2 * kLdsQ : kBins3 * kLdsQ);
   const size_t lds = (size_t)a.nb * NB * sizeof(uint32_t);
@@ -212,54 +229,69 @@ static void launch_rows4(const SelArgs& a, hipStream_t s) {
 }
 
 // Locate, for one histogram of `nbins` (multiple of 256) bins, the bin holding 0-based rank r:
-// returns bin and the rank remaining inside it.  Whole 256-thread block cooperates.
+// returns bin and the rank remaining inside it.  The first 256 threads of the workgroup cooperate (`act`); every thread of the
+// workgroup must call it (barriers).
 __device__ void block_locate(const uint32_t* hist, int nbins, uint32_t r, uint32_t* scratch /*[256]*/,
-                             uint32_t* out_bin, uint32_t* out_rem) {
+                             uint32_t* out_bin, uint32_t* out_rem, bool act) {
   const int per = nbins / 256;
-  const int t = threadIdx.x;
+  const int t = act ? threadIdx.x : 0;
+  const int lane = threadIdx.x & 63;
   uint32_t local = 0;
-  for (int i = 0; i < per; ++i) local += hist[t * per + i];
-  scratch[t] = local;
-  __syncthreads();
-  for (int off = 1; off < 256; off <<= 1) {  // inclusive Hillis-Steele scan
-    const uint32_t add = t >= off ? scratch[t - off] : 0u;
-    __syncthreads();
-    scratch[t] += add;
-    __syncthreads();
+  if (act)
+    for (int i = 0; i < per; ++i) local += hist[t * per + i];
+  // inclusive scan over the 256 per-thread sums: inside each of the four waves by shuffles, then the three wave totals (r04: the
+  // 16-barrier Hillis-Steele scan through LDS was most of a scan kernel's ~4 us and of the one-workgroup select's 28 us)
+  uint32_t v = local;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const uint32_t n = __shfl_up(v, off, 64);
+    if (lane >= off) v += n;
   }
-  const uint32_t incl = scratch[t];
-  uint32_t before = incl - local;
-  if (r >= before && r < incl) {  // exactly one thread
-    for (int i = 0; i < per; ++i) {
-      const uint32_t cnt = hist[t * per + i];
-      if (r < before + cnt) {
-        *out_bin = (uint32_t)(t * per + i);
-        *out_rem = r - before;
-        break;
+  if (act && lane == 63) scratch[t >> 6] = v;
+  __syncthreads();
+  if (act) {
+    uint32_t base = 0;
+    for (int w = 0; w < (t >> 6); ++w) base += scratch[w];
+    const uint32_t incl = v + base;
+    uint32_t before = incl - local;
+    if (r >= before && r < incl) {  // exactly one thread
+      for (int i = 0; i < per; ++i) {
+        const uint32_t cnt = hist[t * per + i];
+        if (r < before + cnt) {
+          *out_bin = (uint32_t)(t * per + i);
+          *out_rem = r - before;
+          break;
+        }
+        before += cnt;
       }
-      before += cnt;
     }
   }
   __syncthreads();
 }
 
+struct ScanLds {
+  uint32_t scratch[256];
+  uint32_t bins[kQ], rems[kQ], ranks[kQ];
+  uint32_t total;
+};
+
+// Scan of pass PASS for channel c by one workgroup (its first 256 threads; all threads must call).
 template <int PASS>
-__global__ __launch_bounds__(256) void select_scan_kernel(const SelArgs a, double qlo, double qhi, double* lohi) {
-  __shared__ uint32_t scratch[256];
-  __shared__ uint32_t bins[kQ], rems[kQ], ranks[kQ];
-  __shared__ uint32_t total;
-  const int c = blockIdx.x;
+__device__ __forceinline__ void scan_pass(const SelArgs& a, int c, double qlo, double qhi, double* lohi, ScanLds& L) {
+  const bool act = threadIdx.x < 256;
   SelState* st = a.state + c;
   if (PASS == 1) {
     // total masked count, then the four ranks NumPy would index
-    uint32_t local = 0;
-    for (int i = threadIdx.x; i < kBins1; i += 256) local += a.hist1[(size_t)c * kHist1 + i];
-    scratch[threadIdx.x] = local;
+    if (act) {
+      uint32_t local = 0;
+      for (int i = threadIdx.x; i < kBins1; i += 256) local += a.hist1[(size_t)c * kHist1 + i];
+      L.scratch[threadIdx.x] = local;
+    }
     __syncthreads();
     if (threadIdx.x == 0) {
       uint32_t n = 0;
-      for (int i = 0; i < 256; ++i) n += scratch[i];
-      total = n;
+      for (int i = 0; i < 256; ++i) n += L.scratch[i];
+      L.total = n;
       st->n = n;
       st->nan_count = a.hist1[(size_t)c * kHist1 + kBins1];
       const double q[2] = {qlo, qhi};
@@ -281,18 +313,18 @@ __global__ __launch_bounds__(256) void select_scan_kernel(const SelArgs a, doubl
             g = vi - f;
           }
         }
-        ranks[2 * j] = prev;
-        ranks[2 * j + 1] = next;
+        L.ranks[2 * j] = prev;
+        L.ranks[2 * j + 1] = next;
         st->gamma[j] = g;
       }
     }
     __syncthreads();
-    if (total == 0) return;
+    if (L.total == 0) return;
     for (int q = 0; q < kQ; ++q) {
-      block_locate(a.hist1 + (size_t)c * kHist1, kBins1, ranks[q], scratch, &bins[q], &rems[q]);
+      block_locate(a.hist1 + (size_t)c * kHist1, kBins1, L.ranks[q], L.scratch, &L.bins[q], &L.rems[q], act);
       if (threadIdx.x == 0) {
-        st->prefix[q] = bins[q];
-        st->rem[q] = rems[q];
+        st->prefix[q] = L.bins[q];
+        st->rem[q] = L.rems[q];
       }
       __syncthreads();
     }
@@ -307,13 +339,13 @@ __global__ __launch_bounds__(256) void select_scan_kernel(const SelArgs a, doubl
     for (int q = 0; q < kQ; ++q) {
       int src = q;                                   // the first query of the run of equal prefixes: the one that was histogrammed
       while (src > 0 && st->prefix[src - 1] == st->prefix[q]) --src;
-      block_locate(hist + (size_t)src * NBINS, NBINS, st->rem[q], scratch, &bins[q], &rems[q]);
+      block_locate(hist + (size_t)src * NBINS, NBINS, st->rem[q], L.scratch, &L.bins[q], &L.rems[q], act);
       __syncthreads();
     }
     if (threadIdx.x == 0) {
       for (int q = 0; q < kQ; ++q) {
-        st->prefix[q] = (st->prefix[q] << SHIFT) | bins[q];
-        st->rem[q] = rems[q];
+        st->prefix[q] = (st->prefix[q] << SHIFT) | L.bins[q];
+        st->rem[q] = L.rems[q];
       }
       if (PASS == 3) {
         for (int j = 0; j < 2; ++j) {
@@ -329,6 +361,144 @@ __global__ __launch_bounds__(256) void select_scan_kernel(const SelArgs a, doubl
   }
 }
 
+template <int PASS>
+__global__ __launch_bounds__(256) void select_scan_kernel(const SelArgs a, double qlo, double qhi, double* lohi) {
+  __shared__ ScanLds L;
+  scan_pass<PASS>(a, blockIdx.x, qlo, qhi, lohi, L);
+}
+
+// ---- tiny images: the whole select of a channel inside ONE workgroup (r04) --------------------------------------------------
+// The reference's own tiles are 100 x 100 pixels (tiles_helpers/utils.py:223-305): seven dependent launches (memset, 3 x (histogram,
+// scan)) cost ~42 us of launch latency for 120 KB of data.  Up to 32 768 pixels a channel's masked samples fit the registers of one
+// 1024-thread workgroup (32 keys per thread): three radix passes over the registers with LDS histograms and the same rank / locate /
+// lerp code as the scans - exact order statistics are unique, so the limits are those of the multi-launch path bit for bit.  One
+// launch, no workspace traffic.  (Measured and dropped on the way: a co-resident grid running the six phases of larger images
+// with spinning grid barriers in one launch - the agent-scope fences of five barriers cost more than six launch boundaries:
+// 53 us against 42 at 100 x 100, 90 against 57 at 1024 x 1024.)
+constexpr int kTinyKeys = 32;
+constexpr int64_t kTinyMaxPix = (int64_t)kTinyKeys * kSelThreads;
+
+__global__ __launch_bounds__(kSelThreads) void select_tiny_kernel(const SelArgs a, double qlo, double qhi, double* lohi) {
+  __shared__ uint32_t h[kQ * kBins2];           // pass 1: [2048]; pass 2: [kQ][2048]; pass 3: [kQ][1024]
+  __shared__ ScanLds L;
+  __shared__ uint32_t pre[kQ], rem[kQ], nan_s;
+  __shared__ double gam[2];
+  const int c = blockIdx.x, t = threadIdx.x;
+  const bool act = t < 256;
+  const float* x = a.x + (size_t)c * a.cs;
+  uint32_t key[kTinyKeys];
+  uint32_t use = 0u;
+#pragma unroll
+  for (int i = 0; i < kTinyKeys; ++i) {
+    const int64_t p = (int64_t)i * kSelThreads + t;
+    const bool on = p < a.npix && (!a.mask || a.mask[p] != 0);
+    const float v = on ? x[p * a.ps] : 0.0f;
+    key[i] = f32_key(v);
+    use |= on ? (1u << i) : 0u;
+  }
+  for (int i = t; i < kBins1; i += kSelThreads) h[i] = 0u;
+  if (t == 0) nan_s = 0u;
+  __syncthreads();
+  uint32_t nans = 0;
+#pragma unroll
+  for (int i = 0; i < kTinyKeys; ++i)
+    if (use & (1u << i)) {
+      atomicAdd(&h[key[i] >> 21], 1u);
+      const float v = key_f32(key[i]);
+      nans += v != v ? 1u : 0u;
+    }
+  if (nans) atomicAdd(&nan_s, nans);
+  __syncthreads();
+  // ranks, as scan_pass<1>
+  if (act) {
+    uint32_t local = 0;
+    for (int i = t; i < kBins1; i += 256) local += h[i];
+    L.scratch[t] = local;
+  }
+  __syncthreads();
+  if (t == 0) {
+    uint32_t n = 0;
+    for (int i = 0; i < 256; ++i) n += L.scratch[i];
+    L.total = n;
+    const double q[2] = {qlo, qhi};
+    for (int j = 0; j < 2; ++j) {
+      uint32_t prev = 0, next = 0;
+      double g = 0.0;
+      if (n > 0) {
+        const double vi = (double)(n - 1) * q[j];
+        if (vi >= (double)(n - 1)) {
+          prev = next = n - 1;
+          g = vi - floor(vi);
+        } else if (vi < 0.0) {
+          prev = next = 0;
+          g = vi - floor(vi);
+        } else {
+          const double f = floor(vi);
+          prev = (uint32_t)f;
+          next = prev + 1;
+          g = vi - f;
+        }
+      }
+      L.ranks[2 * j] = prev;
+      L.ranks[2 * j + 1] = next;
+      gam[j] = g;
+    }
+  }
+  __syncthreads();
+  if (L.total == 0) {
+    if (t == 0) lohi[2 * c] = lohi[2 * c + 1] = __longlong_as_double(0x7ff8000000000000LL);
+    return;
+  }
+  for (int q = 0; q < kQ; ++q) {
+    block_locate(h, kBins1, L.ranks[q], L.scratch, &L.bins[q], &L.rems[q], act);
+    if (t == 0) {
+      pre[q] = L.bins[q];
+      rem[q] = L.rems[q];
+    }
+    __syncthreads();
+  }
+  // passes 2 and 3: one histogram per query (no sharing of equal prefixes: LDS has room)
+#pragma unroll
+  for (int pass = 2; pass <= 3; ++pass) {
+    const int nbins = pass == 2 ? kBins2 : kBins3;
+    const int sh_key = pass == 2 ? 21 : 10, sh_bin = pass == 2 ? 10 : 0;
+    const uint32_t bmask = pass == 2 ? 2047u : 1023u;
+    for (int i = t; i < kQ * nbins; i += kSelThreads) h[i] = 0u;
+    __syncthreads();
+    const uint32_t p0 = pre[0], p1 = pre[1], p2 = pre[2], p3 = pre[3];
+#pragma unroll
+    for (int i = 0; i < kTinyKeys; ++i)
+      if (use & (1u << i)) {
+        const uint32_t k = key[i], kk = k >> sh_key, bin = (k >> sh_bin) & bmask;
+        if (kk == p0) atomicAdd(&h[bin], 1u);
+        if (kk == p1) atomicAdd(&h[nbins + bin], 1u);
+        if (kk == p2) atomicAdd(&h[2 * nbins + bin], 1u);
+        if (kk == p3) atomicAdd(&h[3 * nbins + bin], 1u);
+      }
+    __syncthreads();
+    for (int q = 0; q < kQ; ++q) {
+      block_locate(h + q * nbins, nbins, rem[q], L.scratch, &L.bins[q], &L.rems[q], act);
+      __syncthreads();
+    }
+    if (t == 0)
+      for (int q = 0; q < kQ; ++q) {
+        pre[q] = (pre[q] << (pass == 2 ? 11 : 10)) | L.bins[q];
+        rem[q] = L.rems[q];
+      }
+    __syncthreads();
+  }
+  if (t == 0) {
+    for (int j = 0; j < 2; ++j) {
+      const float va = key_f32(pre[2 * j]), vb = key_f32(pre[2 * j + 1]);
+      const double tt = gam[j];
+      const float d = vb - va;  // NumPy subtracts in the array dtype (float32)
+      double r = tt >= 0.5 ? (double)vb - (double)d * (1.0 - tt) : (double)va + (double)d * tt;
+      if (nan_s) r = __longlong_as_double(0x7ff8000000000000LL);
+      lohi[2 * c + j] = r;
+    }
+  }
+}
+
 static size_t hist1_bytes(int nb) { return (size_t)nb * kHist1 * 4; }
 static size_t hist2_bytes(int nb) { return (size_t)nb * kQ * kBins2 * 4; }
 static size_t hist3_bytes(int nb) { return (size_t)nb * kQ * kBins3 * 4; }
@@ -340,7 +510,8 @@ using namespace hsr;
 
 extern "C" size_t hsr_percentile_work_bytes(int32_t nb) {
   if (nb < 1) nb = 1;
-  return hist1_bytes(nb) + hist2_bytes(nb) + hist3_bytes(nb) + state_bytes(nb) + 64;
+  // + 128 spare bytes behind the histograms: [0, 64) the compaction counters of passes 2 / 3
+  return ((state_bytes(nb) + 7) & ~(size_t)7) + hist1_bytes(nb) + hist2_bytes(nb) + hist3_bytes(nb) + 128;
 }
 
 static int select_setup(SelArgs& a, const float* x_dev, int64_t x_bs, int64_t x_ps, const uint8_t* mask_dev,
@@ -365,6 +536,8 @@ static int select_setup(SelArgs& a, const float* x_dev, int64_t x_bs, int64_t x_
   a.hist3 = (uint32_t*)w;
   return HSR_OK;
 }
+
+static unsigned int* select_spare(const SelArgs& a) { return a.hist3 + hist3_bytes(a.nb) / 4; }       // the 128 spare bytes
 
 static dim3 select_grid(int64_t npix, int nb) {
   int64_t gx = (npix + kSelThreads * 8 - 1) / (kSelThreads * 8);
@@ -443,7 +616,21 @@ extern "C" int hsr_percentile_limits(const float* x_dev, int64_t x_bs, int64_t x
                                      double* lohi_dev, hsr_stream_t stream) {
   HSR_REQUIRE(x_dev && work_dev && lohi_dev, HSR_ERR_INVALID, "hsr_percentile_limits: NULL pointer");
   HSR_REQUIRE(npix >= 1, HSR_ERR_UNSUPPORTED, "hsr_percentile_limits: npix=%lld", (long long)npix);
+  HSR_REQUIRE(pmin >= 0.0 && pmin <= 100.0 && pmax >= 0.0 && pmax <= 100.0, HSR_ERR_INVALID,
+              "hsr_percentile_limits: percentiles must be in the range [0, 100]");
+  HSR_REQUIRE(npix < ((int64_t)1 << 31), HSR_ERR_UNSUPPORTED, "hsr_percentile_limits: npix=%lld", (long long)npix);
+  HSR_REQUIRE((x_ps == 1 && x_bs >= npix) || (x_bs == 1 && x_ps >= nb), HSR_ERR_INVALID,
+              "hsr_percentile_limits: strides are neither band-major nor pixel-major");
+  if (npix <= kTinyMaxPix) {                       // a channel fits one workgroup's registers: one launch, no workspace traffic
+    SelArgs a;
+    int rc0 = select_setup(a, x_dev, x_bs, x_ps, mask_dev, npix, nb, work_dev, "hsr_percentile_limits");
+    if (rc0 != HSR_OK) return rc0;
+    hipLaunchKernelGGL(select_tiny_kernel, dim3(nb), dim3(kSelThreads), 0, (hipStream_t)stream, a, pmin / 100.0, pmax / 100.0, lohi_dev);
+    HSR_LAUNCH_CHECK("select_tiny_kernel");
+    return HSR_OK;
+  }
   int rc = hsr_percentile_begin(work_dev, nb, stream);
+  if (rc != HSR_OK) return rc;
   for (int pass = 1; pass <= 3 && rc == HSR_OK; ++pass) {
     rc = hsr_percentile_hist(pass, x_dev, x_bs, x_ps, mask_dev, npix, nb, work_dev, stream);
     if (rc == HSR_OK) rc = hsr_percentile_scan(pass, nb, pmin, pmax, work_dev, lohi_dev, stream);

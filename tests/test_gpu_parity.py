@@ -348,6 +348,25 @@ def test_percentile_limits_random_planes(torch_gpu):
     pn[0, 10] = np.nan
     got = eng.percentile_limits(torch.from_numpy(pn).cuda(), None, 2, 98).cpu().numpy()
     assert np.isnan(got[0]).all() and not np.isnan(got[1:]).any()
+    # tiny images (r04): up to 32 768 pixels a channel is selected inside one workgroup's registers (select_tiny_kernel) - the sizes of
+    # the reference's own tiles; 32 769 takes the multi-launch path again.  Same checks: planes and rows of 4, masks, ties, NaN, no sample
+    for n in (1, 2, 63, 10000, 32768, 32769):
+        pl = planes[:, :n].copy()
+        for frac in (0.6, 1.0):
+            mask = rng.random(n) < frac
+            mask[0] = True
+            for pmin, pmax in ((2, 98), (0, 100), (37.5, 62.5)):
+                got = eng.percentile_limits(torch.from_numpy(pl).cuda(), torch.from_numpy(mask.view(np.uint8)).cuda(), pmin, pmax).cpu().numpy()
+                np.testing.assert_array_equal(got, np.array([np.percentile(p[mask], [pmin, pmax]) for p in pl]), err_msg=f"n={n}")
+                rw = np.ascontiguousarray(rows[:n])
+                got = eng.percentile_limits(torch.from_numpy(rw).cuda(), torch.from_numpy(mask.view(np.uint8)).cuda(), pmin, pmax, "pixmajor", nb=3).cpu().numpy()
+                np.testing.assert_array_equal(got, np.array([np.percentile(rw[mask, c], [pmin, pmax]) for c in range(3)]), err_msg=f"rows n={n}")
+        if n > 2:
+            pl[1, n // 2] = np.nan
+            got = eng.percentile_limits(torch.from_numpy(pl).cuda(), None, 2, 98).cpu().numpy()
+            assert np.isnan(got[1]).all() and not np.isnan(got[[0, 2, 3, 4]]).any(), n
+            none = torch.zeros(n, dtype=torch.uint8, device="cuda")
+            assert np.isnan(eng.percentile_limits(torch.from_numpy(pl).cuda(), none, 2, 98).cpu().numpy()).all()
 
 
 # ---------------------------------------------------------------------------------------------

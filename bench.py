@@ -94,8 +94,14 @@ def parse_args(argv=None):
                     help="untimed load before the warm-up, to reach the GPU's settled power state: settle_ms / 0.25 steps per tile (0: none)")
     ap.add_argument("--no-input-placement", action="store_true",
                     help="keep the synthetic cube / target where the allocator first put them (no placement trials for inputs)")
-    ap.add_argument("--placement-trials", type=int, default=12,
-                    help="candidate allocations the placement search may time (0: none; the search is opt-in in the library)")
+    ap.add_argument("--placement-trials", type=int, default=96,
+                    help="candidate allocations the placement search may time (0: none; the search is opt-in in the library).  r04: 96 "
+                         "candidates BACK TO BACK (--placement-pitch-gb 0) - a dense map of ~140 GB of device memory, whose fast stretches "
+                         "are 15-25 GB long - instead of 12 candidates 16 GB apart: the sparse search landed in a slow stretch in one of "
+                         "two runs on the same box (0.2347 / 0.2136 ms per step against 0.2125 / 0.2142 dense)")
+    ap.add_argument("--placement-pitch-gb", type=float, default=0.0,
+                    help="spacer between consecutive candidate allocations of the placement search (0 = candidates back to back: a dense "
+                         "map; the library's own default for sparse searches is 16 GB)")
     ap.add_argument("--placement-budget-gb", type=float, default=200.0,
                     help="device memory the placement search may hold (spacers + candidates); the library's own default is half "
                          "of the free memory")
@@ -475,6 +481,7 @@ def main(argv=None):
                               reserved_cus=(args.reserve_cus if (exchanging or not fused) else 0) if pipelined else 0,
                               u16_fast=args.u16_fast, fused_fit=args.fused_fit, placement_trials=trials,
                               placement_budget_gb=args.placement_budget_gb, fuse_apply=fused or mosaic_fused, comm=comm,
+                              placement_pitch_gb=args.placement_pitch_gb,
                               group_tiles=ntl if mosaic_fused else 1,
                               rehearsal_collective=(args.fake_collective_us, args.fake_collective_blocks)
                               if (args.force_exchange and args.fake_collective_us > 0) else None)
@@ -725,8 +732,9 @@ def main(argv=None):
                                          "search_seconds": (input_log or {}).get("seconds"),
                                          "pitch_gb": plan.placement_pitch_gb, "budget_gb": args.placement_budget_gb,
                                          "held_gb": round(plan.placement_held_gb, 1),
-                                         "note": f"before the warm-up K1 is timed on candidate allocations, {plan.placement_pitch_gb:g} GB "
-                                                 f"apart, of (cube copy, target copy, output image); the fastest set is kept "
+                                         "note": f"before the warm-up K1 is timed on {plan.placement_trials} candidate allocations, " +
+                                                 (f"{plan.placement_pitch_gb:g} GB apart" if plan.placement_pitch_gb > 0 else "back to back (a dense map)") +
+                                                 f", of (cube copy, target copy, output images); the fastest set is kept "
                                                  f"(profiles/r02_two_speeds.md, r03_placement_mechanism.md); same bytes, bit-identical "
                                                  f"results; line['cold'] is the step without any of this"},
                            "backend": (args.backend if world > 1 else "none") +

@@ -191,7 +191,7 @@ def test_bench_n1_reports_cold_beside_placed():
     """The driver's N = 1 command: cold (first allocations, no trials, no settle) and placed numbers in one line, the
     traffic figure labelled with its source."""
     import json
-    r = _bench("--gpus", "1", "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-probe", "--placement-trials", "3")
+    r = _bench("--gpus", "1", "--steps", "5", "--warmup", "2", "--no-cpu-baseline", "--no-probe", "--placement-trials", "3", "--placement-pitch-gb", "16")
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads(r.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["scaling"] == "weak" and line["rccl_ranks"] is None

@@ -25,7 +25,9 @@ def main():
     ap.add_argument("--graph", action="store_true")
     ap.add_argument("--ranks", default="1,2,4,8")
     ap.add_argument("--sync-every", type=int, default=0, help="synchronise the device every K calls inside the timed loop (bounds the host's run-ahead)")
-    ap.add_argument("--modes", default="operators,step,submit,fused")
+    ap.add_argument("--modes", default="operators,step,submit,fused,exchange,exchange15",
+                    help="exchange: the four-slot exchange pipeline over a one-rank RCCL communicator (collective issued from C, 8 CUs reserved); "
+                         "exchange15: the same with a 15 us stand-in kernel where the collective of an N-rank run would be resident")
     ap.add_argument("--reserve", type=int, default=-1, help="CUs left free of K1 workgroups (-1: 8 in the pipelined modes, 0 otherwise)")
     ap.add_argument("--rows", default=None, help="comma-separated row counts instead of 1024 / ranks (pipeline resonance sweeps)")
     ap.add_argument("--host-cost", action="store_true", help="also time the ISSUE of 200 calls per mode on the 1024-row tile (GPU slower than host: the loop time is the host cost per call)")
@@ -34,6 +36,10 @@ def main():
     from s2_emit import SpectralFusion
     from s2_emit.synthetic import device_problem
     dev = torch.device("cuda:0")
+    if "exchange" in a.modes:
+        import torch.distributed as dist
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:29531", rank=0, world_size=1, device_id=dev)
     rows = []
     full = None
     cases = [(1024 // int(x), int(x)) for x in a.ranks.split(",")] if a.rows is None else [(int(r), 1024 / int(r)) for r in a.rows.split(",")]
@@ -41,9 +47,11 @@ def main():
         p = device_problem(H, 1024, 285, deg=3, seed=H, device=dev)
         res = {"ranks": n, "rows": H}
         for mode in tuple(a.modes.split(",")) + (("graph",) if a.graph else ()):
+            exch = mode.startswith("exchange")
             plan = SpectralFusion(p.emit_w, p.srf, p.good_mask, deg=3, min_valid=0.0, min_count=50, device=dev,
-                                  reserved_cus=(8 if mode == "submit" else 0) if a.reserve < 0 else a.reserve,
-                                  fuse_apply=mode == "fused")
+                                  reserved_cus=(8 if (mode == "submit" or exch) else 0) if a.reserve < 0 else a.reserve,
+                                  fuse_apply=mode == "fused" or exch, coeff_sync="allreduce" if exch else "local", force_exchange=exch,
+                                  rehearsal_collective=(15, 2) if mode == "exchange15" else None)
             if mode == "graph":
                 plan.step(p.cube, p.real)
                 torch.cuda.synchronize()
@@ -51,7 +59,7 @@ def main():
                 with torch.cuda.graph(g):
                     plan.step(p.cube, p.real)
                 run = g.replay
-            elif mode in ("submit", "fused"):
+            elif mode in ("submit", "fused") or exch:
                 run = lambda: plan.submit(p.cube, p.real)
             elif mode == "operators":            # the operator-by-operator Python path (what step() was before the executor)
                 import torch as _t
@@ -62,14 +70,14 @@ def main():
             for _ in range(max(50, int(300 * n))):          # settle (profiles/r02_ramp.log) + warm-up
                 run()
             if a.host_cost and H == 1024 and mode != "graph":
-                if mode in ("submit", "fused"):
+                if mode in ("submit", "fused") or exch:
                     plan.flush()
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
                 for _ in range(200):
                     run()
                 res[mode + "_host"] = round((time.perf_counter() - t0) / 200 * 1e6, 2)      # issue only: no sync inside
-            if mode in ("submit", "fused"):
+            if mode in ("submit", "fused") or exch:
                 plan.flush()
             torch.cuda.synchronize()
             t0 = time.perf_counter()
@@ -77,10 +85,11 @@ def main():
                 run()
                 if a.sync_every and (i + 1) % a.sync_every == 0:
                     torch.cuda.synchronize()
-            if mode in ("submit", "fused"):
+            if mode in ("submit", "fused") or exch:
                 plan.flush()
             torch.cuda.synchronize()
             dt = (time.perf_counter() - t0) / a.steps
+            plan.close()
             # host issue rate alone: the same loop without waiting for the GPU at the end is bounded by it
             res[mode + "_us"] = round(dt * 1e6, 2)
         rows.append(res)

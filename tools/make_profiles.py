@@ -55,7 +55,8 @@ def main():
     # ---- headline
     subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_summary.py"), tag, os.path.join(src, "trace"), os.path.join(src, "pmc")],
                    stdout=subprocess.DEVNULL, check=True)
-    for name in ("bench_n1.json", "bench_under_rocprof.json", "bench_u16.json", "bench_u16_fast.json", "bench_mosaic8.json"):
+    for name in ("bench_n1.json", "bench_under_rocprof.json", "bench_u16.json", "bench_u16_fast.json", "bench_mosaic8.json", "bench_mosaic8_batched.json",
+                 "bench_force_exchange.json", "bench_launcher.json"):
         if os.path.isfile(os.path.join(src, name)):
             shutil.copy(os.path.join(src, name), os.path.join(P, f"{tag}_{name}.log"))
     f = glob.glob(os.path.join(src, "trace", "*kernel_stats.csv"))
@@ -84,6 +85,50 @@ def main():
         out.append(f"\nThe driver's command with `--placement-trials 0 --settle-ms 0` (what a caller who just allocates and runs gets, timed region "
                    f"started from an idle GPU): {d['ms_per_step']} ms/step, K1+K2 {d['roofline']['kernel_ms']} ms.")
     open(os.path.join(P, f"{tag}_fresh_processes.md"), "w").write("\n".join(out) + "\n")
+    # ---- exchange pipeline (r04)
+    def read(name):
+        pth = os.path.join(src, name)
+        return open(pth, errors="replace").read() if os.path.isfile(pth) else ""
+    sw = read("exchange_sweep.md")
+    if sw:
+        out = [f"# {tag}: the fused pipeline WITH the exchange, issued from C (hsr_pipeline_create_exchange; one-rank RCCL communicator through hsr_comm_*)\n",
+               "`tools/bench_sweep.py`: one fresh `bench.py --steps 50 --warmup 5 --no-cpu-baseline --no-probe <arguments>` process per row, one box, back to back.  "
+               "`--force-exchange`: the multi-rank code path with a one-rank communicator (RCCL launches no kernel for one rank); `--fake-collective-us 15`: a stand-in "
+               "kernel (2 or 8 workgroups of 256 threads, 48 KB LDS) resident for 15 us where the collective's kernel would run; `--pipeline on`: round 3's two-slot "
+               "pipeline (collective through torch.distributed); `--height 128`: the row block of an 8-way strong-scaling run.\n", sw]
+        tl = read("exchange_timeline.md")
+        if tl:
+            out += ["## Where the side stream's kernels run (`rocprofv3 --kernel-trace` of `bench.py --force-exchange --fake-collective-us 15`, `tools/exchange_timeline.py`)\n",
+                    "```", tl.rstrip(), "```\n"]
+        d = jload(os.path.join(src, "bench_launcher.json"))
+        if d:
+            out.append("`python bench.py --gpus 1 --launcher --force-exchange` (parent -> torchrun -> rank -> RCCL group from the launcher's rendezvous -> hsr_comm_init): " +
+                       json.dumps({k: d[k] for k in ("value", "ms_per_step", "rccl_ranks", "world_size", "host_issue_us_per_step") if k in d} |
+                                  {"exchange_transport": d["config"].get("exchange_transport")}) + "\n")
+        open(os.path.join(P, f"{tag}_exchange_pipeline.md"), "w").write("\n".join(out) + "\n")
+    # ---- mosaic (r04)
+    out = [f"# {tag}: resident mosaic on one GPU (`bench.py --tiles-per-gpu T`: T x 1024 x 1024 x 285 tiles, ONE fit per step; BASELINE configs[3]/[4] per-GPU work)\n",
+           "| run | form | ms/step | kernel ms | frac (cube bytes / kernel time) | step_frac_of_peak | placement (kept ms) |", "|---|---|---|---|---|---|---|"]
+    anym = False
+    for name in ("bench_mosaic8.json", "bench_mosaic8_batched.json", "bench_mosaic4.json"):
+        d = jload(os.path.join(src, name))
+        if d:
+            anym = True
+            mo = d["config"].get("mosaic") or {}
+            out.append(f"| {name} | {mo.get('form')} | {d['ms_per_step']} | {d['roofline']['kernel_ms']} | {d['roofline']['frac']} | {d['roofline']['step_frac_of_peak']} | "
+                       f"{(mo.get('placement') or {}).get('kept_ms')} |")
+    d = jload(os.path.join(src, "bench_mosaic8.json"))
+    if d and (d["config"].get("mosaic") or {}).get("placement"):
+        out.append("\nDense map of device memory seen by K1 (ms per launch on 1.25 GB candidates allocated back to back; `place_mosaic`):\n\n```\n" +
+                   json.dumps(d["config"]["mosaic"]["placement"].get("candidate_ms")) + "\n```")
+    if anym:
+        open(os.path.join(P, f"{tag}_mosaic.md"), "w").write("\n".join(out) + "\n")
+    # ---- small select, 13 bands (r04)
+    for name, dst, head in (("sel_small.log", f"{tag}_select_small.md", "hsr_percentile_limits through ctypes with a preallocated workspace (tools/dbg/sel_small_c.py): GPU time per call"),
+                            ("nb13.log", f"{tag}_k1_13_bands.md", "K1+K2 with 12 bands (rows of 12) and with all 13 Sentinel-2 bands (rows of 16) - tools/dbg/k1_nb13.py")):
+        txt = read(name)
+        if txt:
+            open(os.path.join(P, dst), "w").write(f"# {tag}: {head}\n\n```\n" + "".join(l for l in txt.splitlines(True) if "amdgpu.ids" not in l) + "```\n")
     # ---- batch
     out = [f"# {tag}: batched small tiles (tools/bench_batch.py; 100 x 100 x 285 tiles, deg 3)\n"]
     for name in ("batch_f32.json", "batch_u16.json", "batch_f32_t64.json"):

@@ -43,9 +43,10 @@ def main():
         cube = 1024 * 1024 * 285 * (2 if "u16" in srf[0] else 4)
         fusedk = srf[0].rstrip().endswith("false, true>")          # the fused pipeline's launch also carries K3 of an older tile
         algo = cube + (1024 * 1024 * 8 * 12 if fusedk else 0)
-        out.append(f"\nDominant kernel `{srf[0]}`: {avg/1e3:.1f} us average -> {algo/avg:.0f} GB/s of algorithmic bytes "
-                   f"({algo} B per launch: the cube{' + 96 B per pixel of K3 (pseudo read, matched written; 12 channels)' if fusedk else ''}) "
-                   f"= {algo/avg/8000*100:.1f} % of 8 TB/s.\n")
+        out.append(f"\nDominant kernel `{srf[0]}`: {avg/1e3:.2f} us average -> SURVEY 8(d) algorithmic bytes = the cube read once = {cube} B per launch "
+                   f"-> {cube/avg:.0f} GB/s = **{cube/avg/8000:.4f} of 8 TB/s** (bench.py's roofline.frac)."
+                   + (f"  With the K3 of an older tile the launch also carries (96 B per pixel: pseudo read, matched written; 12 channels) "
+                      f"{algo} B -> {algo/avg:.0f} GB/s = {algo/avg/8000:.4f} (roofline.frac_launch_bytes)." if fusedk else "") + "\n")
     traffic = {}
     if pmc_dir:
         out.append("## PMC passes (`rocprofv3 --pmc <counters> --kernel-trace`), averages per launch\n")

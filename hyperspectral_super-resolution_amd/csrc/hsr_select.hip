@@ -372,7 +372,11 @@ __global__ __launch_bounds__(256) void select_scan_kernel(const SelArgs a, doubl
 // scan)) cost ~42 us of launch latency for 120 KB of data.  Up to 32 768 pixels a channel's masked samples fit the registers of one
 // 1024-thread workgroup (32 keys per thread): three radix passes over the registers with LDS histograms and the same rank / locate /
 // lerp code as the scans - exact order statistics are unique, so the limits are those of the multi-launch path bit for bit.  One
-// launch, no workspace traffic.  (Measured and dropped on the way: a co-resident grid running the six phases of larger images
+// launch, no workspace traffic.  (Measured and dropped on the way, r04.  (1) COMPACTION: pass 2 appending the keys of the
+// samples that match a channel's pass-1 prefix to a buffer (wave-private LDS staging, one global atomic per 192 keys) so that pass 3
+// reads those instead of the image: the top 11 key bits are sign + exponent + 2 mantissa bits, so on reflectance-like data in [0, 1) a
+// prefix bin holds ~12 % of the samples, not N / 2048, and the per-sample ballot / rank / staging more than doubled pass 2: 1033 us
+// instead of 358 on three 6144 x 6144 planes, 2511 instead of 520 on band-last rows.  (2) a co-resident grid running the six phases of larger images
 // with spinning grid barriers in one launch - the agent-scope fences of five barriers cost more than six launch boundaries:
 // 53 us against 42 at 100 x 100, 90 against 57 at 1024 x 1024.)
 constexpr int kTinyKeys = 32;

@@ -202,6 +202,7 @@ class SpectralFusion:
         self._native: Dict[tuple, object] = {}       # prepared launches of step(), by _native_key
         self._native_handles: list = []              # ("plan" | "pipe", handle) to destroy with the plan
         self._pipe_images: Dict[int, list] = {}      # output images placed by place_inputs() for the pipeline's two slots
+        self._pipe_matched: Dict[int, list] = {}     # ... and K3 output images placed by place_mosaic()
         self.ws = eng.MomentWorkspace(self.device, self.table.nb, deg)
         self.table.device_weights(self.device)
         self._buf: Dict[int, Tuple[object, object]] = {}
@@ -324,7 +325,25 @@ class SpectralFusion:
                 br.copy_(r)
             kept.append((bc, br))
         times = [round(t, 4) for _, t in ranked if t != float("inf")]
-        return kept, {"candidate_ms": times, "kept_ms": [round(ranked[i][1], 4) for i in order], "pitch_gb": round(pitch, 2)}
+        log = {"candidate_ms": times, "kept_ms": [round(ranked[i][1], 4) for i in order], "pitch_gb": round(pitch, 2)}
+        # the images of the group pipeline (T + 2 slots, a K1 output and a K3 output each): 50 MB apiece, ranked the same way - K1 on the
+        # fastest cube writing into each of 3 x as many candidates as needed - and handed to the pipeline the next submit() builds
+        if self.fuse_apply and self.group_tiles == T and npix not in self._pipe_images:
+            need = 2 * (T + 2)
+            fast = kept[0]
+
+            def k1img(cand):
+                rr, rl = self._real_image(fast[1], npix)
+                eng.srf_integrate_moments(fast[0], self.table, rr, self.deg, self.ws, None, self.min_valid, self.min_valid, out=cand, reduce=False,
+                                          layout=self.layout, real_layout=rl, scale=self.tile_scale, nodata=self.tile_nodata, opts=self.opts)
+            imgs = eng.placement_rank(lambda: eng.alloc_image(torch, self.table.nb, npix, self.layout, self.device), k1img, 3 * need, 0.0, self.device,
+                                      self.placement_budget_gb, img.numel() * 4, self._placement_stats)
+            if len(imgs) >= need:
+                best = sorted(range(len(imgs)), key=lambda i: imgs[i][1])[:need]
+                self._pipe_images[npix] = [imgs[i][0] for i in best[:T + 2]]
+                self._pipe_matched[npix] = [imgs[i][0] for i in best[T + 2:]]
+                log["image_ms"] = [round(imgs[i][1], 4) for i in best]
+        return kept, log
 
     def _exchanges(self) -> bool:
         import torch.distributed as dist
@@ -901,9 +920,10 @@ class SpectralFusion:
         while len(placed) < nslots:
             placed.append(eng.alloc_image(torch, nb, npix, self.layout, self.device))
         slots, outs, handles = [], [], []
+        placed_m = list(self._pipe_matched.pop(npix, []))
         for k in range(nslots):
             ws = eng.MomentWorkspace(self.device, nb, self.deg)
-            matched = eng.alloc_image(torch, nb, npix, self.layout, self.device)
+            matched = placed_m[k] if k < len(placed_m) else eng.alloc_image(torch, nb, npix, self.layout, self.device)
             h, keep = self._native_plan(cube, real2, real_layout, placed[k], matched, ws)
             handles.append(("plan", h))
             slots.append(dict(plan=h, ws=ws, keep=keep, mask=None))
@@ -912,8 +932,11 @@ class SpectralFusion:
             side = self.side_stream
         elif fused and not exchange:                   # the three-slot pipeline has no side-stream work: nothing to choose
             side = torch.cuda.Stream(device=self.device)
-        elif fused:                                    # gate -> collective -> solve: a queue of its own (high priority gets one)
-            side = torch.cuda.Stream(device=self.device, priority=-1)
+        elif fused:
+            # gate -> collective -> solve run under K1 on this stream: chosen by MEASUREMENT like the two-slot pipeline's (some of a
+            # process's high-priority streams are served by a hardware queue on which side work next to the persistent K1 costs
+            # ~100 us per step: r04 shard curve, 338 us per 1024-row step on the 5th such stream of the process against 229)
+            side = self._pick_side_stream(slots, cube, real2, mask)
         else:
             side = self._pick_side_stream(slots, cube, real2, mask)
         ph = C.c_void_p()

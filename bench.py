@@ -495,6 +495,9 @@ def main(argv=None):
 
     def barrier():
         if world > 1:
+            # everything this rank has enqueued - the side stream's collectives on the library's own communicator included - is done
+            # BEFORE torch's communicator starts its barrier kernel: two RCCL communicators never have kernels in flight together
+            torch.cuda.synchronize()
             dist.barrier()
         torch.cuda.synchronize()
 

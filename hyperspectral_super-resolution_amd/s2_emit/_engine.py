@@ -409,7 +409,23 @@ def placement_search(first, make, probe, trials: int, pitch_gb: float, device, b
             e1.synchronize()
             t.append(e0.elapsed_time(e1))
         times.append(min(t))
-    best = min(range(len(times)), key=times.__getitem__)
+    # The fastest of many candidates by two launches each is partly the luckiest: the best few are timed again, six launches each,
+    # and the median decides (r04: with 96 dense candidates a 20-step run landed on 0.2207-0.2299 ms where the 100-step runs of the
+    # same box gave 0.2120-0.2146).
+    if len(times) > 3:
+        finals = {}
+        for i in sorted(range(len(times)), key=times.__getitem__)[:8]:
+            t = []
+            for _ in range(6):
+                e0.record(stream)
+                probe(cands[i])
+                e1.record(stream)
+                e1.synchronize()
+                t.append(e0.elapsed_time(e1))
+            finals[i] = sorted(t)[len(t) // 2]
+        best = min(finals, key=finals.__getitem__)
+    else:
+        best = min(range(len(times)), key=times.__getitem__)
     keep = cands[best]
     if stats is not None:
         stats["held_gb"] = stats.get("held_gb", 0.0) + held / (1 << 30)
@@ -429,7 +445,7 @@ def placement_search(first, make, probe, trials: int, pitch_gb: float, device, b
 
 
 def placement_rank(make, probe, count: int, pitch_gb: float, device, budget_gb: Optional[float] = None, candidate_bytes: int = 0,
-                   stats: Optional[dict] = None):
+                   stats: Optional[dict] = None, retime: int = 0):
     """placement_search for a set of interchangeable buffers (the resident tiles of a mosaic): up to ``count`` candidates from
     ``make()``, ``pitch_gb`` GB of spacer between consecutive ones (so that they sample different stretches of device memory), each
     timed with ``probe`` (one untimed + two timed launches).  Returns [(candidate, ms)] for every candidate that fitted the budget,
@@ -461,6 +477,16 @@ def placement_rank(make, probe, count: int, pitch_gb: float, device, budget_gb: 
             e1.synchronize()
             t.append(e0.elapsed_time(e1))
         out.append((c, min(t)))
+    if retime > 0 and len(out) > retime:           # the best `retime` again, six launches each, median (see placement_search)
+        for i in sorted(range(len(out)), key=lambda k: out[k][1])[:retime]:
+            t = []
+            for _ in range(6):
+                e0.record(stream)
+                probe(out[i][0])
+                e1.record(stream)
+                e1.synchronize()
+                t.append(e0.elapsed_time(e1))
+            out[i] = (out[i][0], sorted(t)[len(t) // 2])
     if stats is not None:
         stats["held_gb"] = stats.get("held_gb", 0.0) + held / (1 << 30)
         stats["budget_gb"] = budget / (1 << 30)

@@ -314,7 +314,7 @@ class SpectralFusion:
         count = int(min(max(T, oversample * T), max(T, budget // per)))
         pitch = pitch_gb
         ranked = eng.placement_rank(lambda: (c0.clone(), r0.clone()), k1, count, pitch, self.device, self.placement_budget_gb, cand_bytes,
-                                    self._placement_stats)
+                                    self._placement_stats, retime=2 * T)
         ranked += [((c, r), float("inf")) for c, r in tiles[:max(0, T - len(ranked))]]      # too little memory for T candidates: the originals
         order = sorted(range(len(ranked)), key=lambda i: ranked[i][1])[:T]
         kept = []

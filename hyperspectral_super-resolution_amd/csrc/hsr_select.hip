@@ -376,7 +376,9 @@ __global__ __launch_bounds__(256) void select_scan_kernel(const SelArgs a, doubl
 // samples that match a channel's pass-1 prefix to a buffer (wave-private LDS staging, one global atomic per 192 keys) so that pass 3
 // reads those instead of the image: the top 11 key bits are sign + exponent + 2 mantissa bits, so on reflectance-like data in [0, 1) a
 // prefix bin holds ~12 % of the samples, not N / 2048, and the per-sample ballot / rank / staging more than doubled pass 2: 1033 us
-// instead of 358 on three 6144 x 6144 planes, 2511 instead of 520 on band-last rows.  (2) a co-resident grid running the six phases of larger images
+// instead of 358 on three 6144 x 6144 planes, 2511 instead of 520 on band-last rows.  (3) MERGED scans: passes 2 and 3 running the previous pass's scan in every workgroup
+// (five launches instead of seven for mid-size images): 38.7 vs 39.6 us at 600 x 600 planes, 51.2 vs 52.2 at 1024 x 1024 - and 71 vs 46 /
+// 91 vs 68 us on band-last rows, where a workgroup repeats the scans of all channels.  (2) a co-resident grid running the six phases of larger images
 // with spinning grid barriers in one launch - the agent-scope fences of five barriers cost more than six launch boundaries:
 // 53 us against 42 at 100 x 100, 90 against 57 at 1024 x 1024.)
 constexpr int kTinyKeys = 32;

@@ -419,9 +419,23 @@ def main(argv=None):
     exchanging = world > 1 or args.force_exchange
     # the library's own RCCL communicator (include/hsr.h hsr_comm_*): ONE for every plan of this run; the step executor issues the
     # per-step collective on it from C.  Under gloo (rehearsal) there is none and the exchange pipeline uses its host transport.
-    comm = eng.Comm(None, device) if exchanging and (args.backend == "nccl" or args.force_exchange) and args.coeff_sync != "local" else None
+    comm, comm_error = None, None
+    if exchanging and (args.backend == "nccl" or args.force_exchange) and args.coeff_sync != "local":
+        try:
+            comm = eng.Comm(None, device)
+        except Exception as e:              # RCCL's C API not bindable / the communicator did not come up: round 3's path (two slots, torch.distributed)
+            comm_error = f"{type(e).__name__}: {e}"
+            sys.stderr.write(f"[bench] rank {rank}: hsr_comm not available ({comm_error}); the exchange goes through torch.distributed\n")
+        if world > 1:                       # one decision for all ranks
+            okc = torch.tensor([1.0 if comm is not None else 0.0], device=device)
+            dist.all_reduce(okc, op=dist.ReduceOp.MIN)
+            if okc.item() < 0.5 and comm is not None:
+                comm.close()
+                comm, comm_error = None, "another rank could not create its communicator"
     exchanging = exchanging and args.coeff_sync != "local"
     want_fused = ntl == 1 and not args.fused_fit and args.pipeline in ("fused", "auto")
+    if exchanging and comm is None and (args.backend == "nccl" or args.force_exchange) and args.pipeline == "auto":
+        want_fused = False                  # no communicator of our own: two-slot pipeline, collective from Python
     if exchanging and args.same_device and args.pipeline == "auto":
         # ranks SHARING a GPU (control-flow rehearsal): a K1 launch of the exchange pipeline that polls for its coefficients holds
         # the whole chip, the other rank's K1 - whose tail has to publish the moments everybody waits for - gets no CU, and only the
@@ -721,6 +735,7 @@ def main(argv=None):
                                          "(no side stream, no events, no reserved CUs); " + str(fused_note)) if fused else
                                         f"one tile deep (two slots, fit on a side stream), {args.reserve_cus} CUs reserved") if pipelined else "off",
                            "exchange_transport": (plan._pipe or {}).get("transport") if pipelined else None,
+                           "hsr_comm_error": comm_error,
                            "mosaic": ({"form": "group pipeline: one kernel per tile, one fit per step" if mosaic_fused else "batched: five launches per step",
                                        "note": mosaic_note, "placement": mosaic_log} if ntl > 1 else None),
                            "fake_collective": ({"us": args.fake_collective_us, "blocks": args.fake_collective_blocks}

@@ -1325,6 +1325,19 @@ __device__ __forceinline__ void glds4_asm(const void* gaddr, uint32_t lds_base) 
 // group's 64 target rows (3 instructions, 24 cache lines) instead of 16 scattered wave loads (512 lines) - within 1 % of
 // this kernel in three alternating fresh processes each; each wave issuing its share of the DMA at a different point of
 // the iteration (wave mod 5) - 3 % slower.  (All in the settled power state: 0.124-0.132 ms exact, 0.120-0.132 ms fast.)
+// Round 4: WAVE PRIORITIES.  With half the bytes per group the two workgroups of a CU no longer hide each other's compute behind
+// the DMA: an iteration is a chain of issue -> sweep -> dot products, and the SIMD's arbiter (oldest wave first) lets a wave of
+// the other workgroup that is merely sweeping or spinning hold up the wave that is on the critical path.  s_setprio per phase -
+// 3 while a wave issues the next group's DMA and flushes the previous rows (HBM is fed first), 1 during the dot products and
+// moments, 0 for the sweep and the waits - measured on one box against the library without it (bench.py --cube u16, 100 steps,
+// fresh processes, two rounds): K1+K2 alone 0.1250 / 0.1272 -> 0.1137 / 0.1152 ms, the fused launch 0.1422 / 0.1419 ->
+// 0.1301 / 0.1332 ms (6.0 - 6.2 TB/s of everything the launch moves), fast arithmetic 0.1441 / 0.1352 -> 0.1363 / 0.1266.
+// Any non-zero level for the dot products gives most of it (1, 2, 3, or graded by the wave's tap count: within the +-2 % of a
+// fresh process); the same levels in the float32 kernel, which waits for HBM and nothing else, change nothing (0.2098 vs
+// 0.2100 ms).  Also tried on the way and dropped: ONE barrier per group (every thread sweeps the chunks its own DMA wrote in
+// front of the top barrier, three flag buffers, two staged slabs) - 5 % slower than two barriers, with and without priorities:
+// the second barrier keeps the eight waves' DMA issue together; band -> wave assignment by SIMD instead of by wave - no effect.
+constexpr int kU16PrioIssue = 3, kU16PrioDots = 1;
 template <int DEG, bool OUTV, bool BATCH, bool FASTU, bool APPLY = false>
 __global__ __launch_bounds__(512, 4) void srf_u16_ring_kernel(const SrfArgs a) {
   constexpr int P = 64, T = 512;
@@ -1468,6 +1481,7 @@ __global__ __launch_bounds__(512, 4) void srf_u16_ring_kernel(const SrfArgs a) {
     __syncthreads();   // group k (every wave's share of the DMA) and the staged planes of group k-1 are visible
     HSR_STAMP(st2);
 
+    __builtin_amdgcn_s_setprio(kU16PrioIssue);
     // group k+1: the next group of this unit, or the first group of the workgroup's next unit.
     // Buffer cur^1 was last read before the barrier above.
     const int g2 = g + cu.slots;
@@ -1492,12 +1506,14 @@ __global__ __launch_bounds__(512, 4) void srf_u16_ring_kernel(const SrfArgs a) {
     }
 
     HSR_STAMP(st3);
+    __builtin_amdgcn_s_setprio(0);
     if (has_nodata) u16_nodata_sweep(reinterpret_cast<const uint4*>(tile), nchunk, npx * B, B, nd2, a.nodata, fl, t);
     // flags of group k complete; also orders the flush reads of the staged slab before the writes below
     lds_barrier();
     HSR_STAMP(st4);
 
     const bool bad = fl[pl] != 0u;
+    __builtin_amdgcn_s_setprio(kU16PrioDots);
 #pragma unroll
     for (int j = 0; j < kBandSlots; ++j) {
       float acc = 0.0f;
@@ -1520,6 +1536,7 @@ __global__ __launch_bounds__(512, 4) void srf_u16_ring_kernel(const SrfArgs a) {
         }
       }
     }
+    __builtin_amdgcn_s_setprio(0);
 #ifdef HSR_PHASE_STAMPS
     {
       HSR_STAMP(st5);

@@ -1106,6 +1106,34 @@ __device__ __forceinline__ void mfma_steps_orb2(const float (&Z)[11], int kh, co
 // ONE slice: the chunked predict103_kernel<2 / 3, false> (nine barriers and a re-staged W per 128-pixel tile) took 0.83-0.87 ms
 // per Mpixel for 65-96 targets, the 96-wide slice kernel 0.51-0.52 ms; (c) slices are as narrow as the target count allows
 // (T = 97: two slices of 64 instead of two of 96).  64-target slices run 16 waves (4 per SIMD) on their 73 KB of W.
+// Wave priorities of the slice and 16-target kernels (r04, after they paid in the uint16 K1): level of a wave during its MFMA chain /
+// outside it (inputs, standardisation, activation, stores).  A/B on one box, ms per Mpixel at T = 16 / 32 / 96 / 285
+// (profiles/r04_k4_ridge.md): none 0.129 / 0.203 / 0.528 / 1.523; REST 1 (shipped): 0.123 / 0.198 / 0.520 / 1.491; REST 3: the same;
+// CHAIN 3 or 1: no change; STAGGER (the four waves of a SIMD at four different levels during the chain, so that they drift apart and
+// one wave's epilogue meets another's chain - either guess of the wave -> SIMD mapping): T = 32 unchanged at 0.200-0.205.
+#ifndef HSR_PRED_PRIO_CHAIN
+#define HSR_PRED_PRIO_CHAIN 0
+#endif
+#ifndef HSR_PRED_PRIO_REST
+#define HSR_PRED_PRIO_REST 1
+#endif
+#ifndef HSR_PRED_PRIO_STAGGER     // 1: chain level = (wave >> 2) & 3, 2: wave & 3 - the waves of a SIMD at DIFFERENT levels drift apart
+#define HSR_PRED_PRIO_STAGGER 0
+#endif
+__device__ __forceinline__ void pred_chain_prio(int wave) {
+  if (HSR_PRED_PRIO_STAGGER == 0) {
+    if (HSR_PRED_PRIO_CHAIN != HSR_PRED_PRIO_REST) __builtin_amdgcn_s_setprio(HSR_PRED_PRIO_CHAIN);
+    return;
+  }
+  const int k = __builtin_amdgcn_readfirstlane(HSR_PRED_PRIO_STAGGER == 1 ? (wave >> 2) & 3 : wave & 3);
+  if (k == 3) __builtin_amdgcn_s_setprio(3);
+  else if (k == 2) __builtin_amdgcn_s_setprio(2);
+  else if (k == 1) __builtin_amdgcn_s_setprio(1);
+  else __builtin_amdgcn_s_setprio(0);
+}
+__device__ __forceinline__ void pred_rest_prio() {
+  if (HSR_PRED_PRIO_STAGGER != 0 || HSR_PRED_PRIO_CHAIN != HSR_PRED_PRIO_REST) __builtin_amdgcn_s_setprio(HSR_PRED_PRIO_REST);
+}
 #ifndef HSR_SLICE_WAVES
 #define HSR_SLICE_WAVES 12
 #endif
@@ -1151,6 +1179,7 @@ __global__ __launch_bounds__(64 * slice_waves(TT), (slice_waves(TT) * slice_wgs(
     pred_load10(a, pc_, xn);
   };
   if ((int64_t)blockIdx.x * kSlicePix < a.npix) load_inputs(blockIdx.x);
+  if (HSR_PRED_PRIO_REST != 0) __builtin_amdgcn_s_setprio(HSR_PRED_PRIO_REST);
   for (int64_t tile = blockIdx.x; tile * kSlicePix < a.npix; tile += gridDim.x) {
     const int64_t p = tile * kSlicePix + wave * 32 + j;
     float z[11];
@@ -1175,7 +1204,9 @@ __global__ __launch_bounds__(64 * slice_waves(TT), (slice_waves(TT) * slice_wgs(
     for (int q = 0; q < TT; ++q)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[q][r] = bv[q][r];
+    pred_chain_prio(wave);
     mfma_steps_orb2<TT>(z, kh, wl, Tp, j, acc);
+    pred_rest_prio();
     if (p < a.npix) {
       int64_t ostride = a.out_stride;
       int tmax = a.T;
@@ -1243,6 +1274,7 @@ __global__ __launch_bounds__(64 * kX16Waves, kX16Wgs) void predict103_x16_kernel
     }
   };
   if ((int64_t)blockIdx.x * kPix < a.npix) load_inputs(blockIdx.x);
+  if (HSR_PRED_PRIO_REST != 0) __builtin_amdgcn_s_setprio(HSR_PRED_PRIO_REST);
   for (int64_t tile = blockIdx.x; tile * kPix < a.npix; tile += gridDim.x) {
     float Z[2][11];                                    // this lane group's permuted copy of the standardised inputs
     bool bad[2] = {false, false};
@@ -1273,6 +1305,7 @@ __global__ __launch_bounds__(64 * kX16Waves, kX16Wgs) void predict103_x16_kernel
       for (int r = 0; r < 4; ++r) acc[h][r] = bias[r];
     const float* wr = wl + g * 16 + i;
     float wc = wr[0], wn = 0.0f;
+    pred_chain_prio(wave);
 #pragma unroll
     for (int s = 0; s < kStepsOrb; ++s) {
       const float b0 = Z[0][kOrb103.rep[s][0]] * Z[0][kOrb103.rep[s][1]] * Z[0][kOrb103.rep[s][2]];
@@ -1283,6 +1316,7 @@ __global__ __launch_bounds__(64 * kX16Waves, kX16Wgs) void predict103_x16_kernel
       wc = wn;
       __builtin_amdgcn_sched_barrier(0);
     }
+    pred_rest_prio();
     int64_t ostride = a.out_stride;
     int tmax = a.T;
     asm volatile("" : "+s"(ostride), "+s"(tmax));      // keep the addressing inside the loop (see predict103_kernel)

@@ -16,6 +16,7 @@
 //                       updates the other rows with 16 x 16 tiles of L on v_mfma_f64_16x16x4_f64.
 // n must be a multiple of 32 (the caller pads with an identity block), n <= 512.
 #include <math.h>
+#include <stdlib.h>
 
 #include "hsr_common.h"
 
@@ -39,6 +40,9 @@ constexpr int kTrailTiles = 5; // trailing-update tiles a wave loads before its 
                                // cycles for the phase against 105 k)
 
 typedef double chol_f64x4 __attribute__((ext_vector_type(4)));
+typedef double chol_f64x2 __attribute__((ext_vector_type(2)));
+constexpr int kDs = kCb + 2;  // LDS row stride of chol_factor_res_kernel: rows start 16-byte aligned, and the 16 rows x 4 k-groups a wave reads for
+                              // one MFMA operand fall on distinct banks (with 33 doubles lanes (col, kk) and (col + 1, kk - 1) share a bank: 4-way)
 
 // 1 / d to the last bit or two: v_rcp_f64 and two Newton steps (a full IEEE division is ~3x the instructions, and the
 // factorisation's column steps are latency chains)
@@ -218,6 +222,326 @@ __global__ __launch_bounds__(1024) void chol_factor_kernel(double* __restrict__ 
   }
 }
 
+// ---- r04: the 32 x 32 diagonal block on ONE wave, four columns per step, rank-4 updates on the matrix cores -------------------------
+// r03 stamps: 47 % of the factorisation in the 31 column steps of a block (600 cycles each: LDS write -> barrier -> read of 16 waves
+// plus a reciprocal chain), and every restructuring that kept the step inside LDS and barriers measured slower.  Here the block
+// never meets a barrier: wave 0 holds its three 16 x 16 tiles (and the three of the inverse) as MFMA accumulators and takes FOUR
+// columns per step:
+//   S    = the 4 x 4 pivot block, read out of the accumulators with v_readlane; every lane runs its LDL^T (unit-lower M, pivots d;
+//          four reciprocal chains instead of 4 x 16 waves of them) and has L_S^-1 = diag(d^-1/2) M^-1 in uniform registers;
+//   Lp   = a L_S^-T for the rows below (a = the four raw columns, which cross from accumulator to operand layout through LDS - the
+//          one transposition of the step; lane (i, k) reads row i's four values and combines them with its column k of L_S^-T);
+//   C   -= Lp Lp^T on the three tiles: one v_mfma_f64_16x16x4 each (rows already finished are masked out of the A operand);
+//   X    = L_S^-1 (rows of the unit-lower inverse E so far): ONE MFMA - the B operand is accumulator register s mod 4 of the E
+//          tile as it stands, and the result lands in the B-operand layout of the next product; X is rows 4 s .. 4 s + 3 of
+//          L_kk^-1 (-> Minv); E -= Lp X on the tiles below.
+// No sqrt or division on the way of a step except the chain of the pivot block itself.
+__device__ __forceinline__ double lane_bcast(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
+// a wave-uniform double into scalar registers (two v_readfirstlane_b32): the step's ten uniform results would otherwise sit in
+// twenty vector registers next to 136 of resident tiles and 48 of accumulators
+__device__ __forceinline__ double uni(double v) {
+  return __hiloint2double(__builtin_amdgcn_readfirstlane(__double2hiint(v)), __builtin_amdgcn_readfirstlane(__double2loint(v)));
+}
+
+struct DiagTiles {
+  chol_f64x4 c00, c10, c11, e00, e10, e11;
+};
+
+// 1 / sqrt(d) to the last bit or two: v_rsq_f64 and two Newton steps (sqrt + reciprocal are ~3x the instructions)
+__device__ __forceinline__ double rsqrt_nr(double d) {
+  double y = __builtin_amdgcn_rsq(d);
+  y = fma(0.5 * y, fma(-(d * y), y, 1.0), y);
+  y = fma(0.5 * y, fma(-(d * y), y, 1.0), y);
+  return y;
+}
+
+template <int S>
+__device__ __forceinline__ void diag_step(DiagTiles& t, double (*D)[kDs], double (*Minv)[kDs], int col, int kk, int kb, int& bad) {
+  constexpr int j0 = 4 * S, Jp = S / 4, q0 = j0 % 16, g0 = S % 4;
+  const chol_f64x4& dt = Jp == 0 ? t.c00 : t.c11;
+  // pivot block, lower triangle: element (a, b) sits in lane (col = q0 + b, kk = a), register g0 of the diagonal tile
+  const double s00 = lane_bcast(dt[g0], q0), s10 = lane_bcast(dt[g0], q0 + 16), s11 = lane_bcast(dt[g0], q0 + 17);
+  const double s20 = lane_bcast(dt[g0], q0 + 32), s21 = lane_bcast(dt[g0], q0 + 33), s22 = lane_bcast(dt[g0], q0 + 34);
+  const double s30 = lane_bcast(dt[g0], q0 + 48), s31 = lane_bcast(dt[g0], q0 + 49), s32 = lane_bcast(dt[g0], q0 + 50),
+               s33 = lane_bcast(dt[g0], q0 + 51);
+  // the four raw columns go to their places in D (step 0: still there from the deposit)
+  if (S > 0 && (col >> 2) == g0) {
+    if (Jp == 0) {
+#pragma unroll
+      for (int g = g0; g < 4; ++g) D[kk + 4 * g][col] = t.c00[g];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) D[16 + kk + 4 * g][col] = t.c10[g];
+    } else {
+#pragma unroll
+      for (int g = g0; g < 4; ++g) D[16 + kk + 4 * g][16 + col] = t.c11[g];
+    }
+  }
+  __builtin_amdgcn_wave_barrier();
+  // lane (i = col, k = kk) reads the four raw values of rows col and 16 + col (16-byte loads: rows of 34 doubles)
+  chol_f64x2 a0l = {0.0, 0.0}, a0h = {0.0, 0.0};
+  if (S <= 3) {
+    a0l = *reinterpret_cast<const chol_f64x2*>(&D[col][j0]);
+    a0h = *reinterpret_cast<const chol_f64x2*>(&D[col][j0 + 2]);
+  }
+  const chol_f64x2 a1l = *reinterpret_cast<const chol_f64x2*>(&D[16 + col][j0]);
+  const chol_f64x2 a1h = *reinterpret_cast<const chol_f64x2*>(&D[16 + col][j0 + 2]);
+  // LDL^T of the pivot block (unit lower M, pivots d), every lane the same
+  const double d0 = s00, r0 = rcp_nr(d0);
+  const double m10 = s10 * r0, m20 = s20 * r0, m30 = s30 * r0;
+  const double d1 = fma(-m10, s10, s11), r1 = rcp_nr(d1);
+  const double u21 = fma(-m20, s10, s21), u31 = fma(-m30, s10, s31);
+  const double m21 = u21 * r1, m31 = u31 * r1;
+  const double d2 = fma(-m21, u21, fma(-m20, s20, s22)), r2 = rcp_nr(d2);
+  const double u32 = fma(-m31, u21, fma(-m30, s20, s32));
+  const double m32 = u32 * r2;
+  const double d3 = fma(-m32, u32, fma(-m31, u31, fma(-m30, s30, s33)));
+  if (!(d0 > 0.0 && d1 > 0.0 && d2 > 0.0 && d3 > 0.0)) {          // wave-uniform, rare
+    const int first = !(d0 > 0.0) ? 1 : (!(d1 > 0.0) ? 2 : (!(d2 > 0.0) ? 3 : 4));
+    bad = min(bad, kb + j0 + first);
+  }
+  const double rsk = rsqrt_nr(kk == 0 ? d0 : (kk == 1 ? d1 : (kk == 2 ? d2 : d3)));   // d_k^-1/2 of the lane's column k
+  // t = a M^-T by forward substitution (all four), the lane keeps t_k: Lp[i][k] = t_k d_k^-1/2
+  double lp0 = 0.0;
+  if (S <= 3) {
+    const double t0 = a0l[0], t1 = fma(-m10, t0, a0l[1]), t2 = fma(-m21, t1, fma(-m20, t0, a0h[0]));
+    const double t3 = fma(-m32, t2, fma(-m31, t1, fma(-m30, t0, a0h[1])));
+    lp0 = rsk * (kk == 0 ? t0 : (kk == 1 ? t1 : (kk == 2 ? t2 : t3)));
+    if (col >= j0 + kk) D[col][j0 + kk] = lp0;
+  }
+  double lp1;
+  {
+    const double t0 = a1l[0], t1 = fma(-m10, t0, a1l[1]), t2 = fma(-m21, t1, fma(-m20, t0, a1h[0]));
+    const double t3 = fma(-m32, t2, fma(-m31, t1, fma(-m30, t0, a1h[1])));
+    lp1 = rsk * (kk == 0 ? t0 : (kk == 1 ? t1 : (kk == 2 ? t2 : t3)));
+    if (16 + col >= j0 + kk) D[16 + col][j0 + kk] = lp1;
+  }
+  const double A0 = col > j0 + 3 ? -lp0 : 0.0;                  // rows that are finished take no part
+  const double A1 = 16 + col > j0 + 3 ? -lp1 : 0.0;
+  if (S <= 2) {
+    t.c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(A0, lp0, t.c00, 0, 0, 0);
+    t.c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(A1, lp0, t.c10, 0, 0, 0);
+  }
+  if (S <= 6) t.c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(A1, lp1, t.c11, 0, 0, 0);
+  // Y = M^-1 E[j0 .. j0 + 3][:]: A operand lane (col = k', kk = a) = (M^-1)[k'][a] (unit lower), rows k' >= 4 zero; X = diag(d^-1/2) Y
+  const double n10 = -m10, n21 = -m21, n32 = -m32;
+  const double n20 = fma(m21, m10, -m20), n31 = fma(m32, m21, -m31);
+  const double n30 = -fma(n32, m20, fma(n31, m10, m30));
+  const int lane = col + 16 * kk;
+  // (built with selects: six v_writelane_b32 through inline assembly - this compiler has no builtin for it - gave an inverse that was
+  // off by 1e-9, the low words of single entries; not understood, not used)
+  double Li = (lane == 0 || lane == 17 || lane == 34 || lane == 51) ? 1.0 : 0.0;
+  Li = lane == 1 ? n10 : Li;
+  Li = lane == 2 ? n20 : Li;
+  Li = lane == 3 ? n30 : Li;
+  Li = lane == 18 ? n21 : Li;
+  Li = lane == 19 ? n31 : Li;
+  Li = lane == 35 ? n32 : Li;
+  const chol_f64x4 zero = {0.0, 0.0, 0.0, 0.0};
+  const chol_f64x4 y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Li, (Jp == 0 ? t.e00 : t.e10)[g0], zero, 0, 0, 0);
+  const double x0 = rsk * y0[0];                                // lane (c, k): X[j0 + k][c]
+  Minv[j0 + kk][col] = x0;                                      // rows j0 .. j0 + 3 of L_kk^-1
+  double x1 = 0.0;
+  if (Jp == 1) {
+    const chol_f64x4 y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Li, t.e11[g0], zero, 0, 0, 0);
+    x1 = rsk * y1[0];
+  }
+  Minv[j0 + kk][16 + col] = x1;
+  if (S <= 2) t.e00 = __builtin_amdgcn_mfma_f64_16x16x4f64(A0, x0, t.e00, 0, 0, 0);
+  if (S <= 6) t.e10 = __builtin_amdgcn_mfma_f64_16x16x4f64(A1, x0, t.e10, 0, 0, 0);
+  if (S >= 4 && S <= 6) t.e11 = __builtin_amdgcn_mfma_f64_16x16x4f64(A1, x1, t.e11, 0, 0, 0);
+}
+
+// Wave 0 of the workgroup: D (lower triangle, upper zero) -> L_kk in D's lower triangle, L_kk^-1 in Minv
+__device__ __forceinline__ void diag_block_wave(double (*D)[kDs], double (*Minv)[kDs], int lane, int kb, int* bad_pivot) {
+  const int col = lane & 15, kk = lane >> 4;
+  DiagTiles t;
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    t.c00[g] = D[kk + 4 * g][col];
+    t.c10[g] = D[16 + kk + 4 * g][col];
+    t.c11[g] = D[16 + kk + 4 * g][16 + col];
+    t.e00[g] = kk + 4 * g == col ? 1.0 : 0.0;
+    t.e10[g] = 0.0;
+    t.e11[g] = t.e00[g];
+  }
+  int bad = 0x7fffffff;
+  diag_step<0>(t, D, Minv, col, kk, kb, bad);
+  diag_step<1>(t, D, Minv, col, kk, kb, bad);
+  diag_step<2>(t, D, Minv, col, kk, kb, bad);
+  diag_step<3>(t, D, Minv, col, kk, kb, bad);
+  diag_step<4>(t, D, Minv, col, kk, kb, bad);
+  diag_step<5>(t, D, Minv, col, kk, kb, bad);
+  diag_step<6>(t, D, Minv, col, kk, kb, bad);
+  diag_step<7>(t, D, Minv, col, kk, kb, bad);
+  if (lane == 0 && bad != 0x7fffffff) atomicMin(bad_pivot, bad);
+}
+
+// ---- r04, n <= 288: the trailing matrix never returns to memory -----------------------------------------------------------------
+// r03 stamps of the kernel above: 30 % in the trailing update (load a tile, 8 MFMAs, store it: all L2 latency) and 8 % loading D and
+// P.  Here the 16 x 16 tiles of the lower triangle behind the first block column - 136 at n = 288 - are dealt out to the waves in
+// column-major order (tile t to wave t mod 8: the tiles still alive at any block step are spread evenly) and live in their owners'
+// registers as MFMA accumulators, NEGATED (N = -C: the update N += P_I P_J^T is the MFMA itself).  When a tile's block column
+// comes up its owner writes it into D / P in LDS.  136 tiles are 72 registers per thread of a 1024-thread workgroup, which the 128
+// registers of such a thread do not have beside the rest of the kernel (100 spilled); 8 waves have 256 each.
+constexpr int kResWaves = 8;
+constexpr int kResThreads = 64 * kResWaves;
+constexpr int kResMaxN = 288;
+constexpr int kResTiles = 17;     // ceil(136 / kResWaves)
+
+__global__ __launch_bounds__(kResThreads) void chol_factor_res_kernel(double* __restrict__ A, int64_t lda, int n, int* info,
+                                                                      double* __restrict__ dinv CHOL_STAMP_PARAM) {
+  extern __shared__ __attribute__((aligned(16))) double chol_lds[];
+  double (*D)[kDs] = reinterpret_cast<double (*)[kDs]>(chol_lds);                      // diagonal block
+  double (*P)[kDs] = reinterpret_cast<double (*)[kDs]>(chol_lds + kCb * kDs);           // panel below, (n - 32) rows
+  __shared__ int bad_pivot;
+  __shared__ __attribute__((aligned(16))) double Minv[kCb][kDs];    // L_kk^-1
+  __shared__ unsigned short res_tile[144];                  // resident tile t: bi | bj << 8
+  const int tid = threadIdx.x, ti = tid >> 5, tj = tid & 31;                            // thread (ti, tj): elements (ti, tj), (ti + 16, tj)
+  const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int col = lane & 15, kk = lane >> 4;
+  const int mt = n >> 4, nres = mt > 2 ? (mt - 2) * (mt - 1) / 2 : 0;
+  if (tid == 0) {
+    *info = 0;
+    bad_pivot = 0x7fffffff;
+  }
+  if (tid < nres) {
+    int t = tid, bj = 2;
+    while (t >= mt - bj) {
+      t -= mt - bj;
+      ++bj;
+    }
+    res_tile[tid] = (unsigned short)((bj + t) | (bj << 8));
+  }
+  __syncthreads();
+  chol_f64x4 creg[kResTiles];
+  int tij[kResTiles];
+#pragma unroll
+  for (int u = 0; u < kResTiles; ++u) {
+    const int t = wave + kResWaves * u;
+    tij[u] = t < nres ? __builtin_amdgcn_readfirstlane((int)res_tile[t]) : -1;
+    creg[u] = chol_f64x4{0.0, 0.0, 0.0, 0.0};
+    if (tij[u] >= 0) {
+      const double* src = A + (int64_t)(16 * (tij[u] & 255) + kk) * lda + 16 * (tij[u] >> 8) + col;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) creg[u][g] = -src[(int64_t)(4 * g) * lda];
+    }
+  }
+  {
+    const int kb = 0;
+    (void)kb;
+    CHOL_STAMP(0);
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int r = ti + 16 * h;
+      D[r][tj] = tj <= r ? A[(int64_t)r * lda + tj] : 0.0;
+    }
+    for (int e = tid; e < (n - kCb) * kCb; e += kResThreads) P[e >> 5][e & 31] = A[(int64_t)(kCb + (e >> 5)) * lda + (e & 31)];
+  }
+  __syncthreads();
+  for (int kb = 0; kb < n; kb += kCb) {
+    const int m = n - kb - kCb;   // rows below the diagonal block
+    CHOL_STAMP(1);
+    if (wave == 0) diag_block_wave(D, Minv, lane, kb, &bad_pivot);
+    __syncthreads();
+    CHOL_STAMP(2);
+    if (tid == 0 && *info == 0 && bad_pivot != 0x7fffffff) *info = bad_pivot;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+      const int r = ti + 16 * h;
+      if (tj <= r) A[(int64_t)(kb + r) * lda + kb + tj] = D[r][tj];
+      dinv[((size_t)(kb / kCb) * kCb + r) * kCb + tj] = Minv[r][tj];
+    }
+    CHOL_STAMP(3);
+    // panel below: X = P L_kk^-T on the float64 matrix cores, one wave per 16 rows and both 16-column halves
+    // (k runs over a lane's PAIRS: lane (col, kk) supplies k = 8 p + 2 kk, 8 p + 2 kk + 1 to MFMAs 2 p, 2 p + 1 of a chain - for both
+    // operands, so the sum is the same - and reads them with one 16-byte load)
+    for (int I = wave; I < (m >> 4); I += kResWaves) {
+      chol_f64x2 av[kCb / 8], b0[kCb / 8], b1[kCb / 8];
+#pragma unroll
+      for (int p = 0; p < kCb / 8; ++p) {
+        av[p] = *reinterpret_cast<const chol_f64x2*>(&P[16 * I + col][8 * p + 2 * kk]);
+        b0[p] = *reinterpret_cast<const chol_f64x2*>(&Minv[col][8 * p + 2 * kk]);
+        b1[p] = *reinterpret_cast<const chol_f64x2*>(&Minv[16 + col][8 * p + 2 * kk]);
+      }
+      chol_f64x4 x0 = {0.0, 0.0, 0.0, 0.0}, x1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int p = 0; p < kCb / 8; ++p) {
+        x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[p][0], b0[p][0], x0, 0, 0, 0);
+        x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[p][0], b1[p][0], x1, 0, 0, 0);
+        x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[p][1], b0[p][1], x0, 0, 0, 0);
+        x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[p][1], b1[p][1], x1, 0, 0, 0);
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        P[16 * I + kk + 4 * g][col] = x0[g];
+        P[16 * I + kk + 4 * g][16 + col] = x1[g];
+      }
+    }
+    __syncthreads();
+    CHOL_STAMP(4);
+    for (int e = tid; e < m * kCb; e += kResThreads) A[(int64_t)(kb + kCb + (e >> 5)) * lda + kb + (e & 31)] = P[e >> 5][e & 31];
+    CHOL_STAMP(5);
+    // trailing update of the resident tiles: N[I][J] += P_I P_J^T.  Lane (col, kk): A operand P[16 I + col][4 s + kk], B operand
+    // P[16 J + col][4 s + kk], accumulator register g = element (row kk + 4 g, column col) of the tile
+    const int k2 = (kb >> 4) + 2;                   // first tile row / column behind this block column
+#pragma unroll
+    for (int u = 0; u < kResTiles; ++u) {
+      const int bi = tij[u] & 255, bj = tij[u] >> 8;
+      if (tij[u] >= 0 && bj >= k2) {                // wave-uniform
+        const chol_f64x2* pa = reinterpret_cast<const chol_f64x2*>(&P[16 * (bi - k2) + col][2 * kk]);
+        const chol_f64x2* pb = reinterpret_cast<const chol_f64x2*>(&P[16 * (bj - k2) + col][2 * kk]);
+        chol_f64x2 va[kCb / 8], vb[kCb / 8];
+#pragma unroll
+        for (int p = 0; p < kCb / 8; ++p) {
+          va[p] = pa[4 * p];
+          vb[p] = pb[4 * p];
+        }
+        chol_f64x4 acc = creg[u];
+#pragma unroll
+        for (int p = 0; p < kCb / 8; ++p) {
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[p][0], vb[p][0], acc, 0, 0, 0);
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[p][1], vb[p][1], acc, 0, 0, 0);
+        }
+        creg[u] = acc;
+      }
+    }
+    __syncthreads();
+    CHOL_STAMP(6);
+    // the next block column leaves the registers for D / P
+    if (m > 0) {
+#ifdef HSR_CHOL_STAMPS
+      {
+        const int kb_next = kb + kCb;
+        const int kb = kb_next;
+        CHOL_STAMP(0);
+      }
+#endif
+#pragma unroll
+      for (int u = 0; u < kResTiles; ++u) {
+        const int bi = tij[u] & 255, bj = tij[u] >> 8;
+        if (tij[u] >= 0 && (bj >> 1) == (k2 >> 1)) {
+          const int c0 = 16 * (bj - k2) + col;
+          if (bi >= k2 + 2) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) P[16 * (bi - k2 - 2) + kk + 4 * g][c0] = -creg[u][g];
+          } else {
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const int r = 16 * (bi - k2) + kk + 4 * g;
+              D[r][c0] = c0 <= r ? -creg[u][g] : 0.0;
+            }
+          }
+        }
+      }
+      if (tj >= 16) D[ti][tj] = 0.0;                // the tile above the diagonal belongs to nobody
+    }
+    __syncthreads();
+  }
+}
+
 // L y = b, then L^T x = y, in place in B - blocked, on the float64 matrix cores.  One workgroup of 1024 threads per slab
 // of 16 right-hand sides; the slab lives in LDS (Y, n x 16) for the whole solve.  Per 32-row block k, forward:
 //     X   = Linv_kk  Y_k                      two 16 x 16 tiles (waves 0, 1), 8 MFMA steps each
@@ -377,7 +701,19 @@ extern "C" int hsr_chol_solve_f64(double* a_dev, int64_t lda, int32_t n, double*
     (void)hipGetLastError();
     configured = lds_f;
   }
-  hipLaunchKernelGGL(chol_factor_kernel, dim3(1), dim3(1024), lds_f, s, a_dev, lda, n, info_dev, work_dev CHOL_STAMP_ARG);
+  static const bool no_res = getenv("HSR_CHOL_NO_RES") != nullptr;     // A/B switch of tools/chol_stamps
+  if (n <= kResMaxN && !no_res) {
+    const size_t lds_r = (size_t)n * kDs * sizeof(double);               // D and P, rows of 34 doubles
+    static thread_local size_t configured_r = 0;
+    if (lds_r > configured_r) {
+      (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_factor_res_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r);
+      (void)hipGetLastError();
+      configured_r = lds_r;
+    }
+    hipLaunchKernelGGL(chol_factor_res_kernel, dim3(1), dim3(kResThreads), lds_r, s, a_dev, lda, n, info_dev, work_dev CHOL_STAMP_ARG);
+  } else {
+    hipLaunchKernelGGL(chol_factor_kernel, dim3(1), dim3(1024), lds_f, s, a_dev, lda, n, info_dev, work_dev CHOL_STAMP_ARG);
+  }
   size_t lds_s = ((size_t)n + kCb) * kYs * sizeof(double);
   const int dinv_in_lds = lds_s + (size_t)n * kCs * sizeof(double) <= 160 * 1024 ? 1 : 0;
   if (dinv_in_lds) lds_s += (size_t)n * kCs * sizeof(double);

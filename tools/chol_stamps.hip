@@ -5,9 +5,12 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <math.h>
 #include <vector>
 #include "../include/hsr.h"
+#ifdef HSR_CHOL_STAMPS
 namespace hsr { extern unsigned long long* g_chol_stamps; }
+#endif
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
 int main(int argc, char** argv) {
   const int n = argc > 1 ? atoi(argv[1]) : 288, T = argc > 2 ? atoi(argv[2]) : 32;
@@ -18,7 +21,9 @@ int main(int argc, char** argv) {
   for (int i = 0; i < n; ++i) for (int j = 0; j <= i; ++j) { double v = 0; for (int k = 0; k < n + 40; ++k) v += M[(size_t)i * (n + 40) + k] * M[(size_t)j * (n + 40) + k]; v = v / n + (i == j ? 0.5 : 0.0); A[(size_t)i * n + j] = A[(size_t)j * n + i] = v; }
   double *dA, *dB, *dW; int* dI; unsigned long long* dS;
   CK(hipMalloc(&dA, A.size() * 8)); CK(hipMalloc(&dB, B.size() * 8)); CK(hipMalloc(&dW, hsr_chol_work_bytes(n))); CK(hipMalloc(&dI, 4)); CK(hipMalloc(&dS, 512 * 8));
+#ifdef HSR_CHOL_STAMPS
   hsr::g_chol_stamps = dS;
+#endif
   const char* nm[6] = {"load D, P -> LDS", "31 column steps", "sqrt, scale, inverse", "panel = P Linv^T (MFMA)", "panel -> global", "trailing update"};
   for (int rep = 0; rep < 3; ++rep) {
     CK(hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dB, B.data(), B.size() * 8, hipMemcpyHostToDevice));
@@ -29,12 +34,46 @@ int main(int argc, char** argv) {
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     unsigned long long h[512]; CK(hipMemcpy(h, dS, sizeof h, hipMemcpyDeviceToHost));
+    if (rep == 0) {   // the factor and the solution against a host Cholesky in long double
+      std::vector<double> Lg((size_t)n * n), Xg((size_t)n * T);
+      CK(hipMemcpy(Lg.data(), dA, Lg.size() * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(Xg.data(), dB, Xg.size() * 8, hipMemcpyDeviceToHost));
+      std::vector<long double> Lh((size_t)n * n, 0.0L);
+      for (int j = 0; j < n; ++j) {
+        long double d = A[(size_t)j * n + j];
+        for (int k = 0; k < j; ++k) d -= Lh[(size_t)j * n + k] * Lh[(size_t)j * n + k];
+        d = sqrtl(d); Lh[(size_t)j * n + j] = d;
+        for (int i = j + 1; i < n; ++i) { long double v = A[(size_t)i * n + j]; for (int k = 0; k < j; ++k) v -= Lh[(size_t)i * n + k] * Lh[(size_t)j * n + k]; Lh[(size_t)i * n + j] = v / d; }
+      }
+      double eL = 0, eX = 0;
+      for (int i = 0; i < n; ++i) for (int j = 0; j <= i; ++j) { double e = fabs(Lg[(size_t)i * n + j] - (double)Lh[(size_t)i * n + j]); if (!(e <= eL)) eL = e; }
+      for (int c = 0; c < T; ++c) {
+        std::vector<long double> y(n);
+        for (int i = 0; i < n; ++i) { long double v = 1.0L; for (int k = 0; k < i; ++k) v -= Lh[(size_t)i * n + k] * y[k]; y[i] = v / Lh[(size_t)i * n + i]; }
+        for (int i = n - 1; i >= 0; --i) { long double v = y[i]; for (int k = i + 1; k < n; ++k) v -= Lh[(size_t)k * n + i] * y[k]; y[i] = v / Lh[(size_t)i * n + i]; }
+        for (int i = 0; i < n; ++i) { double e = fabs(Xg[(size_t)i * T + c] - (double)y[i]) / (fabs((double)y[i]) + 1e-300); if (!(e <= eX)) eX = e; }
+      }
+      int info_h = -1; CK(hipMemcpy(&info_h, dI, 4, hipMemcpyDeviceToHost));
+      printf("check: max |L - L_host| = %.3e, max rel |x - x_host| = %.3e, info = %d\n", eL, eX, info_h);
+    }
     double ph[6] = {0}; double tot = 0;
     for (int b = 0; b < n / 32; ++b) for (int k = 0; k < 6; ++k) { ph[k] += (double)(h[b * 8 + k + 1] - h[b * 8 + k]); }
     for (int k = 0; k < 6; ++k) tot += ph[k];
     printf("rep %d: factor + solve %.1f us (events); factor kernel %.0f cycles over %d block steps\n", rep, ms * 1e3, tot, n / 32);
+#ifndef HSR_CHOL_STAMPS
+    if (rep == 2) {   // plain build: factor and solve timed apart is not possible from here; five more back-to-back runs
+      float best = 1e9f;
+      for (int it = 0; it < 5; ++it) {
+        CK(hipMemcpy(dA, A.data(), A.size() * 8, hipMemcpyHostToDevice)); CK(hipMemcpy(dB, B.data(), B.size() * 8, hipMemcpyHostToDevice));
+        CK(hipEventRecord(e0, 0)); hsr_chol_solve_f64(dA, n, n, dB, T, T, dW, dI, 0); CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
+        float m2; CK(hipEventElapsedTime(&m2, e0, e1)); if (m2 < best) best = m2;
+      }
+      printf("plain build: best factor + solve %.1f us\n", best * 1e3);
+      continue;
+    }
+#endif
     if (rep == 2) {
       for (int k = 0; k < 6; ++k) printf("  %-28s %9.0f cycles  %5.1f %%\n", nm[k], ph[k], 100 * ph[k] / tot);
+      for (int k = 0; k < 6; ++k) { printf("    phase %d per block:", k); for (int b = 0; b < n / 32; ++b) printf(" %llu", h[b * 8 + k + 1] - h[b * 8 + k]); printf("\n"); }
       printf("  per block step (cycles):");
       for (int b = 0; b < n / 32; ++b) printf(" %llu", h[b * 8 + 6] - h[b * 8]);
       printf("\n");

@@ -383,25 +383,26 @@ __device__ __forceinline__ void diag_block_wave(double (*D)[kDs], double (*Minv)
 // r03 stamps of the kernel above: 30 % in the trailing update (load a tile, 8 MFMAs, store it: all L2 latency) and 8 % loading D and
 // P.  Here the 16 x 16 tiles of the lower triangle behind the first block column - 136 at n = 288 - are dealt out to the waves in
 // column-major order (tile t to wave t mod 8: the tiles still alive at any block step are spread evenly) and live in their owners'
-// registers as MFMA accumulators, NEGATED (N = -C: the update N += P_I P_J^T is the MFMA itself).  When a tile's block column
-// comes up its owner writes it into D / P in LDS.  136 tiles are 72 registers per thread of a 1024-thread workgroup, which the 128
+// registers as MFMA accumulators.  When a tile's block column comes up its owner writes it into D / P in LDS.  136 tiles are 72 registers per thread of a 1024-thread workgroup, which the 128
 // registers of such a thread do not have beside the rest of the kernel (100 spilled); 8 waves have 256 each.
 constexpr int kResWaves = 8;
 constexpr int kResThreads = 64 * kResWaves;
 constexpr int kResMaxN = 288;
-constexpr int kResTiles = 17;     // ceil(136 / kResWaves)
+constexpr int kResTiles = 20;     // ceil(136 / 7): wave 0 owns none
 
 __global__ __launch_bounds__(kResThreads) void chol_factor_res_kernel(double* __restrict__ A, int64_t lda, int n, int* info,
                                                                       double* __restrict__ dinv CHOL_STAMP_PARAM) {
   extern __shared__ __attribute__((aligned(16))) double chol_lds[];
-  double (*D)[kDs] = reinterpret_cast<double (*)[kDs]>(chol_lds);                      // diagonal block
-  double (*P)[kDs] = reinterpret_cast<double (*)[kDs]>(chol_lds + kCb * kDs);           // panel below, (n - 32) rows
+  // two (D | P) buffers, block columns alternate: buffer 0 has n rows, buffer 1 n - 32 (the columns only get shorter)
+  typedef double (*Rows)[kDs];
+  Rows buf0 = reinterpret_cast<Rows>(chol_lds), buf1 = reinterpret_cast<Rows>(chol_lds + (size_t)n * kDs);
   __shared__ int bad_pivot;
   __shared__ __attribute__((aligned(16))) double Minv[kCb][kDs];    // L_kk^-1
-  __shared__ unsigned short res_tile[144];                  // resident tile t: bi | bj << 8
+  constexpr int kWorkers = kResWaves - 1, kWorkThreads = 64 * kWorkers;
   const int tid = threadIdx.x, ti = tid >> 5, tj = tid & 31;                            // thread (ti, tj): elements (ti, tj), (ti + 16, tj)
   const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int col = lane & 15, kk = lane >> 4;
+  __shared__ unsigned short res_tile[144];                  // resident tile t: bi | bj << 8
   const int mt = n >> 4, nres = mt > 2 ? (mt - 2) * (mt - 1) / 2 : 0;
   if (tid == 0) {
     *info = 0;
@@ -415,38 +416,43 @@ __global__ __launch_bounds__(kResThreads) void chol_factor_res_kernel(double* __
     }
     res_tile[tid] = (unsigned short)((bj + t) | (bj << 8));
   }
-  __syncthreads();
-  chol_f64x4 creg[kResTiles];
-  int tij[kResTiles];
+  // loads in the order of need (they return in order): the first diagonal block, the first panel (the workers; wave 0 is busy with
+  // the block), then the workers' resident tiles by slot
+  double d_in[2];
 #pragma unroll
-  for (int u = 0; u < kResTiles; ++u) {
-    const int t = wave + kResWaves * u;
-    tij[u] = t < nres ? __builtin_amdgcn_readfirstlane((int)res_tile[t]) : -1;
-    creg[u] = chol_f64x4{0.0, 0.0, 0.0, 0.0};
-    if (tij[u] >= 0) {
-      const double* src = A + (int64_t)(16 * (tij[u] & 255) + kk) * lda + 16 * (tij[u] >> 8) + col;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) creg[u][g] = -src[(int64_t)(4 * g) * lda];
-    }
-  }
+  for (int h = 0; h < 2; ++h) d_in[h] = tj <= ti + 16 * h ? A[(int64_t)(ti + 16 * h) * lda + tj] : 0.0;
   {
     const int kb = 0;
     (void)kb;
     CHOL_STAMP(0);
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-      const int r = ti + 16 * h;
-      D[r][tj] = tj <= r ? A[(int64_t)r * lda + tj] : 0.0;
-    }
-    for (int e = tid; e < (n - kCb) * kCb; e += kResThreads) P[e >> 5][e & 31] = A[(int64_t)(kCb + (e >> 5)) * lda + (e & 31)];
   }
-  __syncthreads();
-  for (int kb = 0; kb < n; kb += kCb) {
-    const int m = n - kb - kCb;   // rows below the diagonal block
-    CHOL_STAMP(1);
-    if (wave == 0) diag_block_wave(D, Minv, lane, kb, &bad_pivot);
-    __syncthreads();
-    CHOL_STAMP(2);
+  // one 16-row tile of the panel times L_kk^-T, both 16-column halves
+  // (k runs over a lane's PAIRS: lane (col, kk) supplies k = 8 p + 2 kk, 8 p + 2 kk + 1 to MFMAs 2 p, 2 p + 1 of a chain - for both
+  // operands, so the sum is the same - and reads them with one 16-byte load)
+  auto panel_tile = [&](Rows P, int I) {
+    chol_f64x2 av[kCb / 8], b0[kCb / 8], b1[kCb / 8];
+#pragma unroll
+    for (int p = 0; p < kCb / 8; ++p) {
+      av[p] = *reinterpret_cast<const chol_f64x2*>(&P[16 * I + col][8 * p + 2 * kk]);
+      b0[p] = *reinterpret_cast<const chol_f64x2*>(&Minv[col][8 * p + 2 * kk]);
+      b1[p] = *reinterpret_cast<const chol_f64x2*>(&Minv[16 + col][8 * p + 2 * kk]);
+    }
+    chol_f64x4 x0 = {0.0, 0.0, 0.0, 0.0}, x1 = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int p = 0; p < kCb / 8; ++p) {
+      x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[p][0], b0[p][0], x0, 0, 0, 0);
+      x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[p][0], b1[p][0], x1, 0, 0, 0);
+      x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[p][1], b0[p][1], x0, 0, 0, 0);
+      x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[p][1], b1[p][1], x1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      P[16 * I + kk + 4 * g][col] = x0[g];
+      P[16 * I + kk + 4 * g][16 + col] = x1[g];
+    }
+  };
+  // what every wave does at the top of block step kb: L_kk and its inverse to memory, then its share of the panel's row tiles
+  auto block_out_and_panel = [&](Rows D, Rows P, int kb, int m) {
     if (tid == 0 && *info == 0 && bad_pivot != 0x7fffffff) *info = bad_pivot;
 #pragma unroll
     for (int h = 0; h < 2; ++h) {
@@ -454,91 +460,151 @@ __global__ __launch_bounds__(kResThreads) void chol_factor_res_kernel(double* __
       if (tj <= r) A[(int64_t)(kb + r) * lda + kb + tj] = D[r][tj];
       dinv[((size_t)(kb / kCb) * kCb + r) * kCb + tj] = Minv[r][tj];
     }
-    CHOL_STAMP(3);
-    // panel below: X = P L_kk^-T on the float64 matrix cores, one wave per 16 rows and both 16-column halves
-    // (k runs over a lane's PAIRS: lane (col, kk) supplies k = 8 p + 2 kk, 8 p + 2 kk + 1 to MFMAs 2 p, 2 p + 1 of a chain - for both
-    // operands, so the sum is the same - and reads them with one 16-byte load)
-    for (int I = wave; I < (m >> 4); I += kResWaves) {
-      chol_f64x2 av[kCb / 8], b0[kCb / 8], b1[kCb / 8];
-#pragma unroll
-      for (int p = 0; p < kCb / 8; ++p) {
-        av[p] = *reinterpret_cast<const chol_f64x2*>(&P[16 * I + col][8 * p + 2 * kk]);
-        b0[p] = *reinterpret_cast<const chol_f64x2*>(&Minv[col][8 * p + 2 * kk]);
-        b1[p] = *reinterpret_cast<const chol_f64x2*>(&Minv[16 + col][8 * p + 2 * kk]);
-      }
-      chol_f64x4 x0 = {0.0, 0.0, 0.0, 0.0}, x1 = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int p = 0; p < kCb / 8; ++p) {
-        x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[p][0], b0[p][0], x0, 0, 0, 0);
-        x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[p][0], b1[p][0], x1, 0, 0, 0);
-        x0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[p][1], b0[p][1], x0, 0, 0, 0);
-        x1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[p][1], b1[p][1], x1, 0, 0, 0);
-      }
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        P[16 * I + kk + 4 * g][col] = x0[g];
-        P[16 * I + kk + 4 * g][16 + col] = x1[g];
-      }
+    for (int I = wave; I < (m >> 4); I += kResWaves) panel_tile(P, I);
+  };
+  if (wave == 0) {
+    // ---- wave 0: the diagonal blocks.  It owns no tile, so that nothing but a block's six accumulator tiles is live in its registers
+    __syncthreads();                                         // (the workers wait for their loads of the first panel here)
+    {
+      const int kb = 0;
+      (void)kb;
+      CHOL_STAMP(5);
     }
-    __syncthreads();
-    CHOL_STAMP(4);
-    for (int e = tid; e < m * kCb; e += kResThreads) A[(int64_t)(kb + kCb + (e >> 5)) * lda + kb + (e & 31)] = P[e >> 5][e & 31];
-    CHOL_STAMP(5);
-    // trailing update of the resident tiles: N[I][J] += P_I P_J^T.  Lane (col, kk): A operand P[16 I + col][4 s + kk], B operand
-    // P[16 J + col][4 s + kk], accumulator register g = element (row kk + 4 g, column col) of the tile
+#pragma unroll
+    for (int h = 0; h < 2; ++h) buf0[ti + 16 * h][tj] = d_in[h];
+    lds_barrier();
+    {
+      const int kb = 0;
+      (void)kb;
+      CHOL_STAMP(6);
+    }
+    diag_block_wave(buf0, Minv, lane, 0, &bad_pivot);
+    {
+      const int kb = 0;
+      (void)kb;
+      CHOL_STAMP(7);
+    }
+    lds_barrier();
+    for (int kb = 0; kb < n; kb += kCb) {
+      const int m = n - kb - kCb;
+      Rows D = ((kb >> 5) & 1) ? buf1 : buf0, Dn = ((kb >> 5) & 1) ? buf0 : buf1;
+      CHOL_STAMP(1);
+      block_out_and_panel(D, D + kCb, kb, m);
+      lds_barrier();
+      CHOL_STAMP(2);
+      if (m == 0) break;
+      Dn[lane >> 2][16 + 4 * (lane & 3) + 0] = 0.0;          // the tile above the next block's diagonal belongs to nobody
+      Dn[lane >> 2][16 + 4 * (lane & 3) + 1] = 0.0;
+      Dn[lane >> 2][16 + 4 * (lane & 3) + 2] = 0.0;
+      Dn[lane >> 2][16 + 4 * (lane & 3) + 3] = 0.0;
+      lds_barrier();
+      CHOL_STAMP(3);
+      diag_block_wave(Dn, Minv, lane, kb + kCb, &bad_pivot);
+      lds_barrier();
+    }
+    return;
+  }
+  // ---- waves 1 .. 7: the panel's loads, the resident tiles
+  const int wt = tid - 64, ww = wave - 1;
+  constexpr int kPanelLoads = ((kResMaxN - kCb) * kCb + kWorkThreads - 1) / kWorkThreads;
+  double p_in[kPanelLoads];
+#pragma unroll
+  for (int i = 0; i < kPanelLoads; ++i) {
+    const int e = wt + i * kWorkThreads;
+    p_in[i] = e < (n - kCb) * kCb ? A[(int64_t)(kCb + (e >> 5)) * lda + (e & 31)] : 0.0;
+  }
+  __syncthreads();                                           // waits for the loads of the first block and panel
+#pragma unroll
+  for (int h = 0; h < 2; ++h) buf0[ti + 16 * h][tj] = d_in[h];
+#pragma unroll
+  for (int i = 0; i < kPanelLoads; ++i) {
+    const int e = wt + i * kWorkThreads;
+    if (e < (n - kCb) * kCb) buf0[kCb + (e >> 5)][e & 31] = p_in[i];
+  }
+  lds_barrier();                                             // wave 0 starts on block 0
+  // the resident tiles: 80 loads per thread, in flight under block 0 and the first panel product.  (Issued BEFORE the panel's loads
+  // they held its way into LDS up - a wait can only name the 63 youngest loads - and so did negating them on arrival: the first
+  // block took 59 k and 38 k cycles instead of 19 k.)
+  chol_f64x4 creg[kResTiles];
+  int tij[kResTiles];
+#pragma unroll
+  for (int u = 0; u < kResTiles; ++u) {
+    const int t = ww + kWorkers * u;
+    tij[u] = t < nres ? __builtin_amdgcn_readfirstlane((int)res_tile[t]) : -1;
+    creg[u] = chol_f64x4{0.0, 0.0, 0.0, 0.0};
+    if (tij[u] >= 0) {
+      const double* src = A + (int64_t)(16 * (tij[u] & 255) + kk) * lda + 16 * (tij[u] >> 8) + col;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) creg[u][g] = src[(int64_t)(4 * g) * lda];   // (no arithmetic on them here: the wave would wait)
+    }
+  }
+  lds_barrier();
+  // Block step kb: D holds L_kk and Minv its inverse, P the raw panel.  (1) L_kk and the inverse go to memory, the panel is
+  // multiplied by L_kk^-T; (2) the three tiles of the NEXT diagonal block are updated and leave the registers for the other buffer;
+  // (3) while wave 0 factors that block, the workers store the panel, update the next panel's tiles and put them beside it, and
+  // update the rest of the trailing matrix.  (Measured and dropped: the three tiles of a diagonal block on ONE worker, which also
+  // multiplies the panel's first two row tiles and so has the next block in LDS when the panel is - phase (2) and its barrier gone -
+  // made that worker's 4.5 k cycles of matrix work the length of phase (1) in every step: 154 us against 134.)
+  for (int kb = 0; kb < n; kb += kCb) {
+    const int m = n - kb - kCb;   // rows below the diagonal block
+    Rows D = ((kb >> 5) & 1) ? buf1 : buf0, P = D + kCb;
+    Rows Dn = ((kb >> 5) & 1) ? buf0 : buf1, Pn = Dn + kCb;
     const int k2 = (kb >> 4) + 2;                   // first tile row / column behind this block column
+    // trailing update of resident tiles: C[I][J] -= P_I P_J^T.  Lane (col, kk): A operand -P[16 I + col][k], B operand
+    // P[16 J + col][k] (k in pairs as above), accumulator register g = element (row kk + 4 g, column col) of the tile.
+    // (Two tiles at a time with alternating chains - so that one wave alone keeps the matrix pipe busy - needs the operands of both:
+    // the kernel went from 244 registers to 256 + scratch and from 134 to 155 us.)
+    auto update = [&](chol_f64x4& acc, int bi, int bj) {
+      const chol_f64x2* pa = reinterpret_cast<const chol_f64x2*>(&P[16 * (bi - k2) + col][2 * kk]);
+      const chol_f64x2* pb = reinterpret_cast<const chol_f64x2*>(&P[16 * (bj - k2) + col][2 * kk]);
+      chol_f64x2 va[kCb / 8], vb[kCb / 8];          // (filled here, not in a helper taking the arrays by reference: that left them in scratch)
+#pragma unroll
+      for (int p = 0; p < kCb / 8; ++p) {
+        va[p] = -pa[4 * p];
+        vb[p] = pb[4 * p];
+      }
+#pragma unroll
+      for (int p = 0; p < kCb / 8; ++p) {
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[p][0], vb[p][0], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[p][1], vb[p][1], acc, 0, 0, 0);
+      }
+    };
+    block_out_and_panel(D, P, kb, m);
+    lds_barrier();
+    if (m == 0) break;
+    // (2) the next diagonal block's tiles
 #pragma unroll
     for (int u = 0; u < kResTiles; ++u) {
       const int bi = tij[u] & 255, bj = tij[u] >> 8;
-      if (tij[u] >= 0 && bj >= k2) {                // wave-uniform
-        const chol_f64x2* pa = reinterpret_cast<const chol_f64x2*>(&P[16 * (bi - k2) + col][2 * kk]);
-        const chol_f64x2* pb = reinterpret_cast<const chol_f64x2*>(&P[16 * (bj - k2) + col][2 * kk]);
-        chol_f64x2 va[kCb / 8], vb[kCb / 8];
+      if (tij[u] >= 0 && (bj >> 1) == (k2 >> 1) && bi < k2 + 2) {   // wave-uniform
+        update(creg[u], bi, bj);
+        const int c0 = 16 * (bj - k2) + col;
 #pragma unroll
-        for (int p = 0; p < kCb / 8; ++p) {
-          va[p] = pa[4 * p];
-          vb[p] = pb[4 * p];
+        for (int g = 0; g < 4; ++g) {
+          const int r = 16 * (bi - k2) + kk + 4 * g;
+          Dn[r][c0] = c0 <= r ? creg[u][g] : 0.0;
         }
-        chol_f64x4 acc = creg[u];
-#pragma unroll
-        for (int p = 0; p < kCb / 8; ++p) {
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[p][0], vb[p][0], acc, 0, 0, 0);
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[p][1], vb[p][1], acc, 0, 0, 0);
-        }
-        creg[u] = acc;
       }
     }
-    __syncthreads();
-    CHOL_STAMP(6);
-    // the next block column leaves the registers for D / P
-    if (m > 0) {
-#ifdef HSR_CHOL_STAMPS
-      {
-        const int kb_next = kb + kCb;
-        const int kb = kb_next;
-        CHOL_STAMP(0);
+    lds_barrier();
+    // (3)
+    for (int e = wt; e < m * kCb; e += kWorkThreads) A[(int64_t)(kb + kCb + (e >> 5)) * lda + kb + (e & 31)] = P[e >> 5][e & 31];
+#pragma unroll
+    for (int u = 0; u < kResTiles; ++u) {
+      const int bi = tij[u] & 255, bj = tij[u] >> 8;
+      if (tij[u] >= 0 && (bj >> 1) == (k2 >> 1) && bi >= k2 + 2) {
+        update(creg[u], bi, bj);
+        const int c0 = 16 * (bj - k2) + col;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) Pn[16 * (bi - k2 - 2) + kk + 4 * g][c0] = creg[u][g];
       }
-#endif
-#pragma unroll
-      for (int u = 0; u < kResTiles; ++u) {
-        const int bi = tij[u] & 255, bj = tij[u] >> 8;
-        if (tij[u] >= 0 && (bj >> 1) == (k2 >> 1)) {
-          const int c0 = 16 * (bj - k2) + col;
-          if (bi >= k2 + 2) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) P[16 * (bi - k2 - 2) + kk + 4 * g][c0] = -creg[u][g];
-          } else {
-#pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              const int r = 16 * (bi - k2) + kk + 4 * g;
-              D[r][c0] = c0 <= r ? -creg[u][g] : 0.0;
-            }
-          }
-        }
-      }
-      if (tj >= 16) D[ti][tj] = 0.0;                // the tile above the diagonal belongs to nobody
     }
-    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < kResTiles; ++u) {
+      const int bi = tij[u] & 255, bj = tij[u] >> 8;
+      if (tij[u] >= 0 && bj >= k2 + 2) update(creg[u], bi, bj);
+    }
+    lds_barrier();
   }
 }
 
@@ -703,7 +769,7 @@ extern "C" int hsr_chol_solve_f64(double* a_dev, int64_t lda, int32_t n, double*
   }
   static const bool no_res = getenv("HSR_CHOL_NO_RES") != nullptr;     // A/B switch of tools/chol_stamps
   if (n <= kResMaxN && !no_res) {
-    const size_t lds_r = (size_t)n * kDs * sizeof(double);               // D and P, rows of 34 doubles
+    const size_t lds_r = (size_t)(2 * n - kCb) * kDs * sizeof(double);   // two (D | P) buffers of n and n - 32 rows of 34 doubles
     static thread_local size_t configured_r = 0;
     if (lds_r > configured_r) {
       (void)hipFuncSetAttribute(reinterpret_cast<const void*>(chol_factor_res_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_r);

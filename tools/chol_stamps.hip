@@ -55,6 +55,26 @@ int main(int argc, char** argv) {
       int info_h = -1; CK(hipMemcpy(&info_h, dI, 4, hipMemcpyDeviceToHost));
       printf("check: max |L - L_host| = %.3e, max rel |x - x_host| = %.3e, info = %d\n", eL, eX, info_h);
     }
+    if (h[4] == 0 && h[1] != 0) {     // chol_factor_res_kernel (n <= 288): stamps 0 (start), then 1, 2, 3 per block step
+      const int nbk = n / 32;
+      printf("rep %d: factor + solve %.1f us (events); resident kernel, cycles per block step:\n", rep, ms * 1e3);
+      if (rep == 2) {
+        printf("  first block (loads, block 0 on wave 0 | panel 0 -> LDS): %llu  (table + first loads %llu, D and P in LDS %llu, block 0 %llu, workers arrive %llu)\n", h[1] - h[0], h[5] - h[0], h[6] - h[5], h[7] - h[6], h[1] - h[7]);
+        const char* rn[3] = {"L_kk, inverse -> memory; panel = P Linv^T", "panel -> memory; next block column updated and out of the registers", "next diagonal block on wave 0 | rest of the trailing update"};
+        for (int k = 0; k < 3; ++k) {
+          unsigned long long sum = 0;
+          printf("  %-90s:", rn[k]);
+          for (int b = 0; b < nbk; ++b) {
+            const unsigned long long a0 = h[b * 8 + 1 + k], a1 = k < 2 ? h[b * 8 + 2 + k] : (b + 1 < nbk ? h[(b + 1) * 8 + 1] : 0);
+            const unsigned long long d = (a0 && a1 > a0) ? a1 - a0 : 0;
+            printf(" %llu", d); sum += d;
+          }
+          printf("  = %llu\n", sum);
+        }
+        printf("  whole kernel up to the last panel: %llu cycles\n", h[(nbk - 1) * 8 + 2] - h[0]);
+      }
+      continue;
+    }
     double ph[6] = {0}; double tot = 0;
     for (int b = 0; b < n / 32; ++b) for (int k = 0; k < 6; ++k) { ph[k] += (double)(h[b * 8 + k + 1] - h[b * 8 + k]); }
     for (int k = 0; k < 6; ++k) tot += ph[k];

@@ -38,8 +38,12 @@ struct SelArgs {
 constexpr int kSelThreads = HSR_SEL_THREADS;      // workgroup of select_hist_kernel
 constexpr int kRowsThreads = HSR_ROWS_THREADS;    // workgroup of select_hist_rows4_kernel
 // resident waves stay the same whatever the workgroup size: the caps below count workgroups of 256 / 512 threads
+#ifndef HSR_SEL_PLANE_WGS
 #define HSR_SEL_PLANE_WGS (1024 * 256 / HSR_SEL_THREADS)
+#endif
+#ifndef HSR_SEL_ROWS4_WGS
 #define HSR_SEL_ROWS4_WGS (1024 * 512 / HSR_ROWS_THREADS)
+#endif
 
 // VEC: band-major planes whose rows start 16-byte aligned (and a 4-byte aligned mask): 4 samples + 4 mask bytes
 // per load, two loads in flight per thread.  The first version walked the plane sample by sample behind a
@@ -63,11 +67,39 @@ __device__ __forceinline__ void hist_pass_planes(const SelArgs& a, int c, int bi
     dedupe_prefixes(pre);
   }
   const int second = PASS > 1 ? second_query(pre) : 0;
+  const uint32_t pre_second = second_prefix(pre, second);
+  const bool more = more_prefixes(pre, second);
   uint32_t* g = PASS == 1 ? a.hist1 + (size_t)c * kHist1
                           : (PASS == 2 ? a.hist2 + (size_t)c * kQ * kBins2 : a.hist3 + (size_t)c * kQ * kBins3);
   __syncthreads();
   const float* x = a.x + (size_t)c * a.cs;
   const int64_t stride = (int64_t)nblk * kSelThreads;
+  // Pass 1 (r04): a thread keeps the bin of its last sample and a count in registers and touches LDS only when the bin changes - images
+  // are smooth, a thread's eight samples of an iteration (two runs of four neighbours) mostly share their top 11 key bits, and the
+  // ballot / shuffle peel of hist_add_wave (~25 instructions per sample, r02) made this the slowest pass: 148 us on three 6144 x 6144
+  // planes against 88 us for pass 3, which is the time of the bytes.  No cross-lane instruction is left; on noise it is one atomic per
+  // sample, as before.  (Measured with it and dropped: the LAST workgroup of a pass running the pass's scan - hist + scan one launch,
+  // four launches instead of seven.  With a __threadfence() per workgroup 1024 x 1024 took 340 us instead of 52; with only a wait for
+  // the workgroup's own atomics and agent-scope loads in the scan 65 us - and 338 against 307 us at 6144 x 6144: the scan's uncached
+  // reads and the tail of the launch cost more than a launch boundary.)
+  uint32_t run_bin = 0u, run_cnt = 0u, run_nan = 0u;
+  const uint32_t run_copy = CP > 1 ? (threadIdx.x & (CP - 1)) * kBins1 : 0u;
+  auto add = [&](float v, bool use) {
+    if (PASS == 1) {
+      if (use) {
+        const uint32_t b = f32_key(v) >> 21;
+        if (b != run_bin) {
+          if (run_cnt) atomicAdd(&h[run_copy + run_bin], run_cnt);
+          run_bin = b;
+          run_cnt = 0u;
+        }
+        ++run_cnt;
+        run_nan += v != v ? 1u : 0u;
+      }
+    } else {
+      hist_sample<PASS, CP>(h, &nanc, pre, second, pre_second, more, g, v, use);
+    }
+  };
   if (VEC) {
     const int64_t n4 = a.npix >> 2;
     const float4* x4 = reinterpret_cast<const float4*>(x);
@@ -87,20 +119,20 @@ __device__ __forceinline__ void hist_pass_planes(const SelArgs& a, int c, int bi
         v1 = ld_stream(x4 + i1);
         mk1 = m4 ? m4[i1] : 0x01010101u;
       }
-      hist_sample<PASS, CP>(h, &nanc, pre, second, g, v0.x, (mk0 & 0x000000ffu) != 0u);
-      hist_sample<PASS, CP>(h, &nanc, pre, second, g, v0.y, (mk0 & 0x0000ff00u) != 0u);
-      hist_sample<PASS, CP>(h, &nanc, pre, second, g, v0.z, (mk0 & 0x00ff0000u) != 0u);
-      hist_sample<PASS, CP>(h, &nanc, pre, second, g, v0.w, (mk0 & 0xff000000u) != 0u);
-      hist_sample<PASS, CP>(h, &nanc, pre, second, g, v1.x, (mk1 & 0x000000ffu) != 0u);
-      hist_sample<PASS, CP>(h, &nanc, pre, second, g, v1.y, (mk1 & 0x0000ff00u) != 0u);
-      hist_sample<PASS, CP>(h, &nanc, pre, second, g, v1.z, (mk1 & 0x00ff0000u) != 0u);
-      hist_sample<PASS, CP>(h, &nanc, pre, second, g, v1.w, (mk1 & 0xff000000u) != 0u);
+      add(v0.x, (mk0 & 0x000000ffu) != 0u);
+      add(v0.y, (mk0 & 0x0000ff00u) != 0u);
+      add(v0.z, (mk0 & 0x00ff0000u) != 0u);
+      add(v0.w, (mk0 & 0xff000000u) != 0u);
+      add(v1.x, (mk1 & 0x000000ffu) != 0u);
+      add(v1.y, (mk1 & 0x0000ff00u) != 0u);
+      add(v1.z, (mk1 & 0x00ff0000u) != 0u);
+      add(v1.w, (mk1 & 0xff000000u) != 0u);
     }
     if (bid == 0 && threadIdx.x < 64) {   // up to 3 tail samples, one wave (ballots need the whole wave)
       const int64_t p = n4 * 4 + threadIdx.x;
       const bool on = p < a.npix;
       const float v = on ? x[p] : 0.0f;
-      hist_sample<PASS, CP>(h, &nanc, pre, second, g, v, on && (!a.mask || a.mask[p] != 0));
+      add(v, on && (!a.mask || a.mask[p] != 0));
     }
   } else {
     const int64_t first = (int64_t)bid * kSelThreads + (threadIdx.x & ~63);
@@ -108,8 +140,12 @@ __device__ __forceinline__ void hist_pass_planes(const SelArgs& a, int c, int bi
       const int64_t p = base + (threadIdx.x & 63);
       const bool on = p < a.npix && (!a.mask || a.mask[p] != 0);
       const float v = on ? ld_stream(x + p * a.ps) : 0.0f;
-      hist_sample<PASS, CP>(h, &nanc, pre, second, g, v, on);
+      add(v, on);
     }
+  }
+  if (PASS == 1) {
+    if (run_cnt) atomicAdd(&h[run_copy + run_bin], run_cnt);
+    if (run_nan) atomicAdd(&nanc, run_nan);
   }
   __syncthreads();
   for (int i = threadIdx.x; i < NBINS; i += kSelThreads) {
@@ -152,16 +188,20 @@ __device__ __forceinline__ void hist_pass_rows4(const SelArgs& a, int bid, int n
 #pragma unroll
   for (int c = 0; c < 4; ++c)
 #pragma unroll
-    for (int q = 0; q < kQ; ++q) pre[c][q] = (PASS > 1 && c < nb) ? pre_s[c][q] : 0u;
+    for (int q = 0; q < kQ; ++q) pre[c][q] = (PASS > 1 && c < nb) ? (uint32_t)__builtin_amdgcn_readfirstlane((int)pre_s[c][q]) : 0u;   // scalar
   if (PASS > 1) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) dedupe_prefixes(pre[c]);
   }
   int second[4];
+  uint32_t pre_second[4];
+  bool more[4];
   uint32_t* gq[4];
 #pragma unroll
   for (int c = 0; c < 4; ++c) {
     second[c] = PASS > 1 ? second_query(pre[c]) : 0;
+    pre_second[c] = second_prefix(pre[c], second[c]);
+    more[c] = more_prefixes(pre[c], second[c]);
     gq[c] = PASS == 1 ? a.hist1 + (size_t)c * kHist1
                       : (PASS == 2 ? a.hist2 + (size_t)c * kQ * kBins2 : a.hist3 + (size_t)c * kQ * kBins3);
   }
@@ -180,12 +220,31 @@ __device__ __forceinline__ void hist_pass_rows4(const SelArgs& a, int bid, int n
       v[u] = ld_stream(rows + pc);
       if (a.mask) on[u] = on[u] && a.mask[pc] != 0;
     }
+    if (PASS == 3) {
+      // pass 3 (r04): a sample matches a 22-bit prefix once in ~16 000, so the wave first asks whether ANY of its 4 x nb samples of this
+      // iteration matches anything (two compares per sample, one ballot) and usually moves on; the compare-and-branch groups of the
+      // counting path ran for every sample and made the pass 155 us for 640 MB
+      bool hit = false;
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          if (c < nb) {
+            const uint32_t key = f32_key(e[c]) >> 10;
+            bool m = key == pre[c][0] || key == pre_second[c];
+            if (more[c]) m = m || key == pre[c][2] || key == pre[c][3];
+            hit = hit || (m && on[u]);
+          }
+      }
+      if (__ballot(hit) == 0) continue;                 // wave-uniform
+    }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #pragma unroll
       for (int c = 0; c < 4; ++c)
-        if (c < nb) hist_sample<PASS>(hall + c * NB, &nanc[c], pre[c], second[c], gq[c], e[c], on[u]);   // c < nb is block-uniform
+        if (c < nb) hist_sample<PASS>(hall + c * NB, &nanc[c], pre[c], second[c], pre_second[c], more[c], gq[c], e[c], on[u]);   // c < nb is block-uniform
     }
   }
   __syncthreads();

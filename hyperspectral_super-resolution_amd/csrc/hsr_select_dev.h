@@ -74,9 +74,12 @@ constexpr int kLdsQ = 2;
 #define HSR_SEL_COPIES 4
 #endif
 constexpr int kPass1Copies = HSR_SEL_COPIES;   // pass-1 histogram copies of select_hist_kernel (planes)
+// r04: the prefixes are wave-uniform, so which of them exist is a SCALAR question: a sample is compared with query 0's prefix, with
+// the second distinct one only if there is one and with a third / fourth only if there are (`more`) - the four compare-and-branch
+// groups per sample of r03 (three of them against parked prefixes that nothing matches) were most of what pass 2 cost over its bytes.
 template <int PASS, int COPIES = 1>
-__device__ __forceinline__ void hist_sample(uint32_t* h, uint32_t* nanc, const uint32_t (&pre)[kQ], int second, uint32_t* g,
-                                            float v, bool use) {
+__device__ __forceinline__ void hist_sample(uint32_t* h, uint32_t* nanc, const uint32_t (&pre)[kQ], int second, uint32_t pre_second,
+                                            bool more, uint32_t* g, float v, bool use) {
   const uint32_t k = f32_key(v);
   if (PASS == 1) {
     hist_add_wave<COPIES>(h, use ? (k >> 21) : kNoBin);
@@ -87,14 +90,24 @@ __device__ __forceinline__ void hist_sample(uint32_t* h, uint32_t* nanc, const u
     const uint32_t bin = PASS == 2 ? ((k >> 10) & 2047u) : (k & 1023u);
     if (use) {
       if (key == pre[0]) atomicAdd(&h[bin], 1u);
+      if (second) {                                   // scalar
+        if (key == pre_second) atomicAdd(&h[NBINS + bin], 1u);
+        if (more) {                                   // scalar, rare: the prev / next ranks of a percentile straddle a bin boundary
 #pragma unroll
-      for (int q = 1; q < kQ; ++q)
-        if (key == pre[q]) {
-          if (q == second) atomicAdd(&h[NBINS + bin], 1u);
-          else atomicAdd(&g[q * NBINS + bin], 1u);
+          for (int q = 2; q < kQ; ++q)
+            if (q != second && key == pre[q]) atomicAdd(&g[q * NBINS + bin], 1u);
         }
+      }
     }
   }
+}
+
+// the second distinct prefix itself and whether a third exists (after dedupe_prefixes; `second` from second_query)
+__device__ __forceinline__ uint32_t second_prefix(const uint32_t (&pre)[kQ], int second) {
+  return second == 1 ? pre[1] : (second == 2 ? pre[2] : (second == 3 ? pre[3] : kNoPrefix));
+}
+__device__ __forceinline__ bool more_prefixes(const uint32_t (&pre)[kQ], int second) {
+  return (second == 1 && (pre[2] != kNoPrefix || pre[3] != kNoPrefix)) || (second == 2 && pre[3] != kNoPrefix);
 }
 
 // first query after 0 whose prefix is its own (after dedupe_prefixes); 0 if there is none

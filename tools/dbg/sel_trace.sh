@@ -11,7 +11,7 @@ sel = [r for r in rows if "select_" in r["Kernel_Name"]]
 # print the last 14 select launches (one percentile_limits call of each flavour near the end)
 seen = collections.OrderedDict()
 for r in sel[-60:]:
-    n = r["Kernel_Name"][:60] + " grid " + r["Grid_Size"]
+    n = r["Kernel_Name"][:60] + " grid " + r["Grid_Size_X"] + "x" + r["Grid_Size_Y"]
     seen.setdefault(n, []).append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3)
 for n, v in seen.items():
     print(f"{n:90s} n={len(v):3d} " + " ".join(f"{x:.1f}" for x in v[-9:]))

@@ -27,7 +27,9 @@ unsigned long long* g_chol_stamps = nullptr;   // [16 blocks][8 phases], device 
 #define CHOL_STAMP_PARAM , unsigned long long* stamps
 #define CHOL_STAMP_ARG , hsr::g_chol_stamps
 #define CHOL_STAMP(k) do { if (tid == 0 && stamps) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); stamps[(kb / kCb) * 8 + (k)] = t_; } } while (0)
+#define CHOL_STAMP_W(k) do { if (tid == 64 && stamps) { unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory"); stamps[(kb / kCb) * 8 + (k)] = t_; } } while (0)
 #else
+#define CHOL_STAMP_W(k)
 #define CHOL_STAMP_PARAM
 #define CHOL_STAMP_ARG
 #define CHOL_STAMP(k)
@@ -539,14 +541,36 @@ __global__ __launch_bounds__(kResThreads) void chol_factor_res_kernel(double* __
     }
   }
   lds_barrier();
+  // Which slots a phase has to visit is asked ONCE per phase, by the lanes: lane u holds slot u's tile, the phase's condition is one
+  // vector compare and a ballot, and every slot's test is one scalar bit test (the slots are registers: static indices only; a
+  // while-loop over the set bits with a switch on the index put all 160 registers into scratch).
+  // Walking all 20 slots with scalar compares - the tile codes live in spilled SGPRs, 15 instructions per slot - cost 1.4 k cycles per
+  // walk, three walks per step; in phase (2), where a worker has one tile or none, that was most of its 3.5 k cycles.
+  const int slot_tile = (lane < kResTiles && ww + kWorkers * lane < nres) ? (int)res_tile[ww + kWorkers * lane] : -1;
+  const int slot_bi = slot_tile & 255, slot_bj = slot_tile >> 8;
+  auto for_slots = [&](unsigned long long mask, auto&& f) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < kResTiles; ++u)
+      if (mask & (1ull << u)) f(creg[u], tij[u]);            // one scalar bit test per slot
+  };
   // Block step kb: D holds L_kk and Minv its inverse, P the raw panel.  (1) L_kk and the inverse go to memory, the panel is
   // multiplied by L_kk^-T; (2) the three tiles of the NEXT diagonal block are updated and leave the registers for the other buffer;
   // (3) while wave 0 factors that block, the workers store the panel, update the next panel's tiles and put them beside it, and
   // update the rest of the trailing matrix.  (Measured and dropped: the three tiles of a diagonal block on ONE worker, which also
   // multiplies the panel's first two row tiles and so has the next block in LDS when the panel is - phase (2) and its barrier gone -
   // made that worker's 4.5 k cycles of matrix work the length of phase (1) in every step: 154 us against 134.)
-  for (int kb = 0; kb < n; kb += kCb) {
-    const int m = n - kb - kCb;   // rows below the diagonal block
+  // (the loop is rotated - phase (1) of step 0 stands in front of it, phase (1) of step k + 1 ends iteration k - so that the resident
+  // tiles can be "touched" once between the first panel product and the first update: the compiler then waits for their loads THERE.
+  // Left to itself it put s_waitcnt vmcnt(2) in front of a tile's first MFMA inside the loop, where in every later step it waits for
+  // nothing but the step's own stores of L_kk and the panel - 3.5 k cycles per step in phase (2), the diagonal tile's 1 k aside.)
+  block_out_and_panel(buf0, buf0 + kCb, 0, n - kCb);
+  lds_barrier();
+#pragma unroll
+  for (int u = 0; u < kResTiles; ++u)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(creg[u][g]));
+  for (int kb = 0; kb < n - kCb; kb += kCb) {
+    const int m = n - kb - kCb;   // rows below the diagonal block (> 0)
     Rows D = ((kb >> 5) & 1) ? buf1 : buf0, P = D + kCb;
     Rows Dn = ((kb >> 5) & 1) ? buf0 : buf1, Pn = Dn + kCb;
     const int k2 = (kb >> 4) + 2;                   // first tile row / column behind this block column
@@ -554,7 +578,7 @@ __global__ __launch_bounds__(kResThreads) void chol_factor_res_kernel(double* __
     // P[16 J + col][k] (k in pairs as above), accumulator register g = element (row kk + 4 g, column col) of the tile.
     // (Two tiles at a time with alternating chains - so that one wave alone keeps the matrix pipe busy - needs the operands of both:
     // the kernel went from 244 registers to 256 + scratch and from 134 to 155 us.)
-    auto update = [&](chol_f64x4& acc, int bi, int bj) {
+    auto update = [&](chol_f64x4& acc, int bi, int bj) __attribute__((always_inline)) {
       const chol_f64x2* pa = reinterpret_cast<const chol_f64x2*>(&P[16 * (bi - k2) + col][2 * kk]);
       const chol_f64x2* pb = reinterpret_cast<const chol_f64x2*>(&P[16 * (bj - k2) + col][2 * kk]);
       chol_f64x2 va[kCb / 8], vb[kCb / 8];          // (filled here, not in a helper taking the arrays by reference: that left them in scratch)
@@ -563,47 +587,44 @@ __global__ __launch_bounds__(kResThreads) void chol_factor_res_kernel(double* __
         va[p] = -pa[4 * p];
         vb[p] = pb[4 * p];
       }
+      // all eight loads before the first MFMA: left alone, the compiler reuses two operand registers and runs load - wait - two MFMAs
+      // four times over (a tile's update 1.5 k cycles, the three tiles of phase (2) 3.5 k)
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int p = 0; p < kCb / 8; ++p) {
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[p][0], vb[p][0], acc, 0, 0, 0);
         acc = __builtin_amdgcn_mfma_f64_16x16x4f64(va[p][1], vb[p][1], acc, 0, 0, 0);
       }
     };
-    block_out_and_panel(D, P, kb, m);
-    lds_barrier();
-    if (m == 0) break;
+    (void)D;
+    CHOL_STAMP_W(4);
     // (2) the next diagonal block's tiles
+    const bool in_col = slot_tile >= 0 && (slot_bj >> 1) == (k2 >> 1);
+    for_slots(__ballot(in_col && slot_bi < k2 + 2), [&](chol_f64x4& acc, int t) __attribute__((always_inline)) {
+      const int bi = t & 255, bj = t >> 8;
+      update(acc, bi, bj);
+      const int c0 = 16 * (bj - k2) + col;
 #pragma unroll
-    for (int u = 0; u < kResTiles; ++u) {
-      const int bi = tij[u] & 255, bj = tij[u] >> 8;
-      if (tij[u] >= 0 && (bj >> 1) == (k2 >> 1) && bi < k2 + 2) {   // wave-uniform
-        update(creg[u], bi, bj);
-        const int c0 = 16 * (bj - k2) + col;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int r = 16 * (bi - k2) + kk + 4 * g;
-          Dn[r][c0] = c0 <= r ? creg[u][g] : 0.0;
-        }
+      for (int g = 0; g < 4; ++g) {
+        const int r = 16 * (bi - k2) + kk + 4 * g;
+        Dn[r][c0] = c0 <= r ? acc[g] : 0.0;
       }
-    }
+    });
+    CHOL_STAMP_W(5);
     lds_barrier();
+    CHOL_STAMP_W(6);
     // (3)
     for (int e = wt; e < m * kCb; e += kWorkThreads) A[(int64_t)(kb + kCb + (e >> 5)) * lda + kb + (e & 31)] = P[e >> 5][e & 31];
+    for_slots(__ballot(in_col && slot_bi >= k2 + 2), [&](chol_f64x4& acc, int t) __attribute__((always_inline)) {
+      const int bi = t & 255, bj = t >> 8;
+      update(acc, bi, bj);
+      const int c0 = 16 * (bj - k2) + col;
 #pragma unroll
-    for (int u = 0; u < kResTiles; ++u) {
-      const int bi = tij[u] & 255, bj = tij[u] >> 8;
-      if (tij[u] >= 0 && (bj >> 1) == (k2 >> 1) && bi >= k2 + 2) {
-        update(creg[u], bi, bj);
-        const int c0 = 16 * (bj - k2) + col;
-#pragma unroll
-        for (int g = 0; g < 4; ++g) Pn[16 * (bi - k2 - 2) + kk + 4 * g][c0] = creg[u][g];
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < kResTiles; ++u) {
-      const int bi = tij[u] & 255, bj = tij[u] >> 8;
-      if (tij[u] >= 0 && bj >= k2 + 2) update(creg[u], bi, bj);
-    }
+      for (int g = 0; g < 4; ++g) Pn[16 * (bi - k2 - 2) + kk + 4 * g][c0] = acc[g];
+    });
+    for_slots(__ballot(slot_tile >= 0 && slot_bj >= k2 + 2), [&](chol_f64x4& acc, int t) __attribute__((always_inline)) { update(acc, t & 255, t >> 8); });
+    lds_barrier();
+    block_out_and_panel(Dn, Pn, kb + kCb, m - kCb);      // (1) of the next step
     lds_barrier();
   }
 }

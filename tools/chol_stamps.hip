@@ -13,6 +13,7 @@ namespace hsr { extern unsigned long long* g_chol_stamps; }
 #endif
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s line %d\n", hipGetErrorString(e_), __LINE__); exit(1);} } while (0)
 int main(int argc, char** argv) {
+  setvbuf(stdout, NULL, _IONBF, 0);
   const int n = argc > 1 ? atoi(argv[1]) : 288, T = argc > 2 ? atoi(argv[2]) : 32;
   std::vector<double> A((size_t)n * n), B((size_t)n * T, 1.0);
   uint32_t s = 7;
@@ -33,7 +34,7 @@ int main(int argc, char** argv) {
     if (hsr_chol_solve_f64(dA, n, n, dB, T, T, dW, dI, 0)) { printf("error %s\n", hsr_last_error()); return 1; }
     CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
-    unsigned long long h[512]; CK(hipMemcpy(h, dS, sizeof h, hipMemcpyDeviceToHost));
+    unsigned long long h[512]; CK(hipMemcpy(h, dS, sizeof h, hipMemcpyDeviceToHost));   // [0, 200) factor blocks, [200, 300) solve
     if (rep == 0) {   // the factor and the solution against a host Cholesky in long double
       std::vector<double> Lg((size_t)n * n), Xg((size_t)n * T);
       CK(hipMemcpy(Lg.data(), dA, Lg.size() * 8, hipMemcpyDeviceToHost)); CK(hipMemcpy(Xg.data(), dB, Xg.size() * 8, hipMemcpyDeviceToHost));
@@ -55,7 +56,7 @@ int main(int argc, char** argv) {
       int info_h = -1; CK(hipMemcpy(&info_h, dI, 4, hipMemcpyDeviceToHost));
       printf("check: max |L - L_host| = %.3e, max rel |x - x_host| = %.3e, info = %d\n", eL, eX, info_h);
     }
-    if (h[4] == 0 && h[1] != 0) {     // chol_factor_res_kernel (n <= 288): stamps 0 (start), then 1, 2, 3 per block step
+    if (h[7] != 0) {     // chol_factor_res_kernel (n <= 288): stamps 0 (start), then 1, 2, 3 per block step
       const int nbk = n / 32;
       printf("rep %d: factor + solve %.1f us (events); resident kernel, cycles per block step:\n", rep, ms * 1e3);
       if (rep == 2) {
@@ -71,6 +72,9 @@ int main(int argc, char** argv) {
           }
           printf("  = %llu\n", sum);
         }
+        printf("  wave 1 (worker 0) in phase 2, per block step: from wave 0's stamp after the panel barrier to its own | its slot loop | its wait at the barrier\n   ");
+        for (int b = 0; b + 1 < nbk; ++b) printf(" %lld|%llu|%llu", (long long)(h[b * 8 + 4] - h[b * 8 + 2]), h[b * 8 + 5] - h[b * 8 + 4], h[b * 8 + 6] - h[b * 8 + 5]);
+        printf("\n");
         printf("  whole kernel up to the last panel: %llu cycles\n", h[(nbk - 1) * 8 + 2] - h[0]);
       }
       continue;

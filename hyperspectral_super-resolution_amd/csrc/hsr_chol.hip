@@ -468,7 +468,7 @@ __global__ __launch_bounds__(kResThreads) void chol_factor_res_kernel(double* __
     // ---- wave 0: the diagonal blocks.  It owns no tile, so that nothing but a block's six accumulator tiles is live in its registers
     __syncthreads();                                         // (the workers wait for their loads of the first panel here)
     {
-      const int kb = 0;
+      const int kb = 23 * kCb;                              // (stamps 189 .. 191: block 0's slots 5, 6 belong to the worker's stamps)
       (void)kb;
       CHOL_STAMP(5);
     }
@@ -476,13 +476,13 @@ __global__ __launch_bounds__(kResThreads) void chol_factor_res_kernel(double* __
     for (int h = 0; h < 2; ++h) buf0[ti + 16 * h][tj] = d_in[h];
     lds_barrier();
     {
-      const int kb = 0;
+      const int kb = 23 * kCb;                              // (stamps 189 .. 191: block 0's slots 5, 6 belong to the worker's stamps)
       (void)kb;
       CHOL_STAMP(6);
     }
     diag_block_wave(buf0, Minv, lane, 0, &bad_pivot);
     {
-      const int kb = 0;
+      const int kb = 23 * kCb;                              // (stamps 189 .. 191: block 0's slots 5, 6 belong to the worker's stamps)
       (void)kb;
       CHOL_STAMP(7);
     }

@@ -56,11 +56,11 @@ int main(int argc, char** argv) {
       int info_h = -1; CK(hipMemcpy(&info_h, dI, 4, hipMemcpyDeviceToHost));
       printf("check: max |L - L_host| = %.3e, max rel |x - x_host| = %.3e, info = %d\n", eL, eX, info_h);
     }
-    if (h[7] != 0) {     // chol_factor_res_kernel (n <= 288): stamps 0 (start), then 1, 2, 3 per block step
+    if (h[191] != 0) {     // chol_factor_res_kernel (n <= 288): stamps 0 (start), then 1, 2, 3 per block step
       const int nbk = n / 32;
       printf("rep %d: factor + solve %.1f us (events); resident kernel, cycles per block step:\n", rep, ms * 1e3);
       if (rep == 2) {
-        printf("  first block (loads, block 0 on wave 0 | panel 0 -> LDS): %llu  (table + first loads %llu, D and P in LDS %llu, block 0 %llu, workers arrive %llu)\n", h[1] - h[0], h[5] - h[0], h[6] - h[5], h[7] - h[6], h[1] - h[7]);
+        printf("  first block (loads, block 0 on wave 0 | panel 0 -> LDS): %llu  (table + first loads %llu, D and P in LDS %llu, block 0 %llu, workers arrive %llu)\n", h[1] - h[0], h[189] - h[0], h[190] - h[189], h[191] - h[190], h[1] - h[191]);
         const char* rn[3] = {"L_kk, inverse -> memory; panel = P Linv^T", "panel -> memory; next block column updated and out of the registers", "next diagonal block on wave 0 | rest of the trailing update"};
         for (int k = 0; k < 3; ++k) {
           unsigned long long sum = 0;

@@ -217,11 +217,12 @@ __global__ __launch_bounds__(256) void bilinear_up_hist_kernel(const float* __re
   }
   __syncthreads();
   const int x = blockIdx.x * 256 + threadIdx.x;
-  const bool on = x < Wf;                     // no early exit: the histogram increments are wave-wide ballots
+  const bool on = x < Wf;
   int x0, x1;
   double tx;
   up_tap(on ? x : Wf - 1, f, Wc, &x0, &x1, &tx);
   const double ux = 1.0 - tx;
+  uint32_t run_bin[kUpMaxVec] = {0u, 0u, 0u, 0u}, run_cnt[kUpMaxVec] = {0u, 0u, 0u, 0u};
   for (int y = ybeg; y < yend; ++y) {
     const int y0 = ry0[y - ybeg], y1 = ry1[y - ybeg];
     const double ty = rty[y - ybeg];
@@ -262,10 +263,26 @@ __global__ __launch_bounds__(256) void bilinear_up_hist_kernel(const float* __re
       st_stream(reinterpret_cast<float4*>(out + p * 4), make_float4(r[0], r[1], r[2], r[3]));
       mask_out[p] = fin ? 1 : 0;
     }
+    // r04: a thread walks DOWN its column, so consecutive samples are vertical neighbours of an interpolated image and nearly always
+    // share their bin: the bin of the last sample and a count stay in registers per band, LDS is touched when the bin changes (as in
+    // pass 1 of select_hist_kernel; the ballot / shuffle peel of hist_add_wave cost ~25 instructions per sample)
+    if (on && fin) {
 #pragma unroll
-    for (int b = 0; b < kUpMaxVec; ++b)
-      if (b < nb) hist_add_wave<1>(uh + b * kBins1, (on && fin) ? (f32_key(r[b]) >> 21) : kNoBin);   // b < nb is launch-uniform
+      for (int b = 0; b < kUpMaxVec; ++b)
+        if (b < nb) {                                   // launch-uniform
+          const uint32_t bin = f32_key(r[b]) >> 21;
+          if (bin != run_bin[b]) {
+            if (run_cnt[b]) atomicAdd(&uh[b * kBins1 + run_bin[b]], run_cnt[b]);
+            run_bin[b] = bin;
+            run_cnt[b] = 0u;
+          }
+          ++run_cnt[b];
+        }
+    }
   }
+#pragma unroll
+  for (int b = 0; b < kUpMaxVec; ++b)
+    if (b < nb && run_cnt[b]) atomicAdd(&uh[b * kBins1 + run_bin[b]], run_cnt[b]);
   __syncthreads();
   for (int i = threadIdx.x; i < nb * kBins1; i += 256)
     if (uh[i]) atomicAdd(&hist1[(size_t)(i / kBins1) * kHist1 + (i % kBins1)], uh[i]);

@@ -110,6 +110,46 @@ __device__ __forceinline__ void up_tap(int i, int f, int n, int* i0, int* i1, do
 constexpr int kUpRows = 8;
 constexpr int kUpMaxVec = 4;   // band-last rows of 4 floats are stored with one 16-byte store
 
+// r04: the rows of a column that share their pair of coarse rows (y0, y1) - six in a row at the driver's 6 x - share `top` and `bot`,
+// the two horizontal interpolations; and when the pair moves on by one row the old `bot` IS the new `top`.  A thread keeps them (per
+// band, float64) while it walks down its column: four 16-byte taps, twelve conversions and eighteen float64 operations per pixel become
+// one tap pair, six conversions and nine operations per SIX pixels.  The same expressions on the same operands: the same bits.
+struct UpRowCache {
+  int y0 = -1, y1 = -1;
+  double top[kUpMaxVec], bot[kUpMaxVec];
+};
+__device__ __forceinline__ void up_rows4(UpRowCache& c, const float* __restrict__ in, int64_t in_ps, int Wc, int x0, int x1, int y0, int y1,
+                                         double ux, double tx, int nb) {
+  y0 = __builtin_amdgcn_readfirstlane(y0);        // the same for the whole workgroup: scalar branches
+  y1 = __builtin_amdgcn_readfirstlane(y1);
+  if (y0 == c.y0 && y1 == c.y1) return;
+  auto row = [&](int y, double (&dst)[kUpMaxVec]) {
+    const float4 q0 = *reinterpret_cast<const float4*>(in + ((int64_t)y * Wc + x0) * in_ps);
+    const float4 q1 = *reinterpret_cast<const float4*>(in + ((int64_t)y * Wc + x1) * in_ps);
+    const float a0[4] = {q0.x, q0.y, q0.z, q0.w}, a1[4] = {q1.x, q1.y, q1.z, q1.w};
+#pragma unroll
+    for (int b = 0; b < kUpMaxVec; ++b)
+      if (b < nb) {
+        const double v0 = a0[b], v1 = a1[b];
+        dst[b] = v0 * ux + v1 * tx;
+      }
+  };
+  if (y0 == c.y1) {
+#pragma unroll
+    for (int b = 0; b < kUpMaxVec; ++b) c.top[b] = c.bot[b];
+  } else {
+    row(y0, c.top);
+  }
+  if (y1 == y0) {
+#pragma unroll
+    for (int b = 0; b < kUpMaxVec; ++b) c.bot[b] = c.top[b];
+  } else {
+    row(y1, c.bot);
+  }
+  c.y0 = y0;
+  c.y1 = y1;
+}
+
 // r03 (rocprofv3 of the reference driver: 260 us for 1024^2 x 3 -> 6144^2 x 4, the largest kernel of the least-squares variant):
 // the ROW taps - a float64 division, a floor and two clamps, ~40 instructions - were recomputed by every thread for every
 // output pixel although they are the same for the whole row: the first kUpRows threads compute them once per workgroup
@@ -139,6 +179,39 @@ __global__ __launch_bounds__(256) void bilinear_up_kernel(const float* __restric
   double tx;
   up_tap(x, f, Wc, &x0, &x1, &tx);
   const double ux = 1.0 - tx;
+  if (!VEC4) {
+    // planes: band by band, so that ONE pair of horizontal interpolations (see UpRowCache) serves the rows that share their coarse rows
+    for (int b = 0; b < nb; ++b) {
+      const float* src = in + (size_t)b * in_bs;
+      int cy0 = -1, cy1 = -1;
+      double top = 0.0, bot = 0.0;
+      for (int y = ybeg; y < yend; ++y) {
+        const int y0 = __builtin_amdgcn_readfirstlane(ry0[y - ybeg]), y1 = __builtin_amdgcn_readfirstlane(ry1[y - ybeg]);
+        const double ty = rty[y - ybeg];
+        const double uy = 1.0 - ty;
+        if (y0 != cy0 || y1 != cy1) {
+          if (y0 == cy1) {
+            top = bot;
+          } else {
+            const double v00 = src[((int64_t)y0 * Wc + x0) * in_ps], v01 = src[((int64_t)y0 * Wc + x1) * in_ps];
+            top = v00 * ux + v01 * tx;
+          }
+          if (y1 == y0) {
+            bot = top;
+          } else {
+            const double v10 = src[((int64_t)y1 * Wc + x0) * in_ps], v11 = src[((int64_t)y1 * Wc + x1) * in_ps];
+            bot = v10 * ux + v11 * tx;
+          }
+          cy0 = y0;
+          cy1 = y1;
+        }
+        const int64_t p = (int64_t)y * Wf + x;
+        st_stream(out + (size_t)b * out_bs + p * out_ps, (float)(top * uy + bot * ty));
+      }
+    }
+    return;
+  }
+  UpRowCache rc;
   for (int y = ybeg; y < yend; ++y) {
     const int y0 = ry0[y - ybeg], y1 = ry1[y - ybeg];
     const double ty = rty[y - ybeg];
@@ -149,18 +222,10 @@ __global__ __launch_bounds__(256) void bilinear_up_kernel(const float* __restric
     if (VEC4) {
       float r[kUpMaxVec] = {0.0f, 0.0f, 0.0f, 0.0f};
       if (IN4) {                                   // in_bs == 1, in_ps == 4, 16-byte aligned: the four taps as whole rows
-        const float4 q00 = *reinterpret_cast<const float4*>(in + i00), q01 = *reinterpret_cast<const float4*>(in + i01);
-        const float4 q10 = *reinterpret_cast<const float4*>(in + i10), q11 = *reinterpret_cast<const float4*>(in + i11);
-        const float a00[4] = {q00.x, q00.y, q00.z, q00.w}, a01[4] = {q01.x, q01.y, q01.z, q01.w};
-        const float a10[4] = {q10.x, q10.y, q10.z, q10.w}, a11[4] = {q11.x, q11.y, q11.z, q11.w};
+        up_rows4(rc, in, in_ps, Wc, x0, x1, y0, y1, ux, tx, nb);
 #pragma unroll
-        for (int b = 0; b < kUpMaxVec; ++b) {
-          if (b < nb) {
-            const double v00 = a00[b], v01 = a01[b], v10 = a10[b], v11 = a11[b];
-            const double top = v00 * ux + v01 * tx, bot = v10 * ux + v11 * tx;
-            r[b] = (float)(top * uy + bot * ty);
-          }
-        }
+        for (int b = 0; b < kUpMaxVec; ++b)
+          if (b < nb) r[b] = (float)(rc.top[b] * uy + rc.bot[b] * ty);
       } else {
 #pragma unroll
         for (int b = 0; b < kUpMaxVec; ++b) {
@@ -222,6 +287,7 @@ __global__ __launch_bounds__(256) void bilinear_up_hist_kernel(const float* __re
   double tx;
   up_tap(on ? x : Wf - 1, f, Wc, &x0, &x1, &tx);
   const double ux = 1.0 - tx;
+  UpRowCache rc;
   uint32_t run_bin[kUpMaxVec] = {0u, 0u, 0u, 0u}, run_cnt[kUpMaxVec] = {0u, 0u, 0u, 0u};
   for (int y = ybeg; y < yend; ++y) {
     const int y0 = ry0[y - ybeg], y1 = ry1[y - ybeg];
@@ -231,18 +297,10 @@ __global__ __launch_bounds__(256) void bilinear_up_hist_kernel(const float* __re
     const int64_t i10 = ((int64_t)y1 * Wc + x0) * in_ps, i11 = ((int64_t)y1 * Wc + x1) * in_ps;
     float r[kUpMaxVec] = {0.0f, 0.0f, 0.0f, 0.0f};
     if (IN4) {
-      const float4 q00 = *reinterpret_cast<const float4*>(in + i00), q01 = *reinterpret_cast<const float4*>(in + i01);
-      const float4 q10 = *reinterpret_cast<const float4*>(in + i10), q11 = *reinterpret_cast<const float4*>(in + i11);
-      const float a00[4] = {q00.x, q00.y, q00.z, q00.w}, a01[4] = {q01.x, q01.y, q01.z, q01.w};
-      const float a10[4] = {q10.x, q10.y, q10.z, q10.w}, a11[4] = {q11.x, q11.y, q11.z, q11.w};
+      up_rows4(rc, in, in_ps, Wc, x0, x1, y0, y1, ux, tx, nb);
 #pragma unroll
-      for (int b = 0; b < kUpMaxVec; ++b) {
-        if (b < nb) {
-          const double v00 = a00[b], v01 = a01[b], v10 = a10[b], v11 = a11[b];
-          const double top = v00 * ux + v01 * tx, bot = v10 * ux + v11 * tx;
-          r[b] = (float)(top * uy + bot * ty);
-        }
-      }
+      for (int b = 0; b < kUpMaxVec; ++b)
+        if (b < nb) r[b] = (float)(rc.top[b] * uy + rc.bot[b] * ty);
     } else {
 #pragma unroll
       for (int b = 0; b < kUpMaxVec; ++b) {

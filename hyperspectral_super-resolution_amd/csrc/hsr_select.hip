@@ -209,17 +209,24 @@ __device__ __forceinline__ void hist_pass_rows4(const SelArgs& a, int bid, int n
   constexpr int U = 4;
   const int64_t stride = (int64_t)nblk * kRowsThreads;
   const int64_t first = (int64_t)bid * kRowsThreads + (threadIdx.x & ~63);
+  auto sweep = [&](auto has_mask) {
   for (int64_t base = first; base < a.npix; base += U * stride) {   // wave-uniform trip count (ballots inside)
     float4 v[U];
     bool on[U];
+    uint32_t mk[U];
+    // all U rows and mask bytes are requested before the first is looked at (r04: `on = on && mask[p] != 0` made the mask byte a
+    // conditional load inside an exec-masked block with its own s_waitcnt vmcnt(0) - four dependent round trips per iteration instead
+    // of one, and the rows kernels ran at 4.3 TB/s where the planes' passes run at 6.4)
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       const int64_t p = base + u * stride + (threadIdx.x & 63);
       on[u] = p < a.npix;
       const int64_t pc = on[u] ? p : 0;
       v[u] = ld_stream(rows + pc);
-      if (a.mask) on[u] = on[u] && a.mask[pc] != 0;
+      mk[u] = decltype(has_mask)::value ? (uint32_t)a.mask[pc] : 1u;   // (the branch on a.mask stands outside the loop)
     }
+#pragma unroll
+    for (int u = 0; u < U; ++u) on[u] = on[u] && mk[u] != 0u;
     if (PASS == 3) {
       // pass 3 (r04): a sample matches a 22-bit prefix once in ~16 000, so the wave first asks whether ANY of its 4 x nb samples of this
       // iteration matches anything (two compares per sample, one ballot) and usually moves on; the compare-and-branch groups of the
@@ -247,6 +254,9 @@ __device__ __forceinline__ void hist_pass_rows4(const SelArgs& a, int bid, int n
         if (c < nb) hist_sample<PASS>(hall + c * NB, &nanc[c], pre[c], second[c], pre_second[c], more[c], gq[c], e[c], on[u]);   // c < nb is block-uniform
     }
   }
+  };
+  if (a.mask) sweep(std::true_type{});
+  else sweep(std::false_type{});
   __syncthreads();
   for (int c = 0; c < nb; ++c) {
     uint32_t* g = PASS == 1 ? a.hist1 + (size_t)c * kHist1

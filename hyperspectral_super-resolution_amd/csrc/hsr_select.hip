@@ -206,7 +206,10 @@ __device__ __forceinline__ void hist_pass_rows4(const SelArgs& a, int bid, int n
                       : (PASS == 2 ? a.hist2 + (size_t)c * kQ * kBins2 : a.hist3 + (size_t)c * kQ * kBins3);
   }
   const float4* rows = reinterpret_cast<const float4*>(a.x);
-  constexpr int U = 4;
+#ifndef HSR_ROWS_U
+#define HSR_ROWS_U 4
+#endif
+  constexpr int U = HSR_ROWS_U;
   const int64_t stride = (int64_t)nblk * kRowsThreads;
   const int64_t first = (int64_t)bid * kRowsThreads + (threadIdx.x & ~63);
   auto sweep = [&](auto has_mask) {

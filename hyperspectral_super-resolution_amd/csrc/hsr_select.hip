@@ -466,14 +466,31 @@ __global__ __launch_bounds__(kSelThreads) void select_tiny_kernel(const SelArgs 
   const float* x = a.x + (size_t)c * a.cs;
   uint32_t key[kTinyKeys];
   uint32_t use = 0u;
+  // sixteen mask bytes and sixteen samples are requested before the first is looked at, twice (r04: `p < npix && mask[p] != 0` ahead
+  // of the sample's load made every one of the 32 a mask load, a wait, a sample load - 32 dependent round trips were most of the 22 us)
+  auto gather = [&](auto has_mask) {
 #pragma unroll
-  for (int i = 0; i < kTinyKeys; ++i) {
-    const int64_t p = (int64_t)i * kSelThreads + t;
-    const bool on = p < a.npix && (!a.mask || a.mask[p] != 0);
-    const float v = on ? x[p * a.ps] : 0.0f;
-    key[i] = f32_key(v);
-    use |= on ? (1u << i) : 0u;
-  }
+    for (int h = 0; h < kTinyKeys; h += 16) {
+      uint32_t mk[16];
+      float val[16];
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int64_t p = (int64_t)(h + i) * kSelThreads + t;
+        const int64_t pc = p < a.npix ? p : 0;
+        mk[i] = decltype(has_mask)::value ? (uint32_t)a.mask[pc] : 1u;
+        val[i] = x[pc * a.ps];
+      }
+#pragma unroll
+      for (int i = 0; i < 16; ++i) {
+        const int64_t p = (int64_t)(h + i) * kSelThreads + t;
+        const bool on = p < a.npix && mk[i] != 0u;
+        key[h + i] = f32_key(on ? val[i] : 0.0f);
+        use |= on ? (1u << (h + i)) : 0u;
+      }
+    }
+  };
+  if (a.mask) gather(std::true_type{});
+  else gather(std::false_type{});
   for (int i = t; i < kBins1; i += kSelThreads) h[i] = 0u;
   if (t == 0) nan_s = 0u;
   __syncthreads();

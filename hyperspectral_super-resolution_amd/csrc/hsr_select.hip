@@ -295,7 +295,10 @@ static void launch_rows4(const SelArgs& a, hipStream_t s) {
     (void)hipGetLastError();
     configured = lds;
   }
-  int64_t gx = (a.npix + kRowsThreads * 4 - 1) / (kRowsThreads * 4);
+  // (r04: above a megapixel a workgroup takes two iterations - half the workgroups, half the flush atomics onto the same global words:
+  // 1448 x 1448 rows 99 -> 83 us, planes 71 -> 58; four or eight iterations, and two below a megapixel, were slower)
+  const int64_t per_wg = (int64_t)kRowsThreads * 4 * (a.npix > (1 << 20) ? 2 : 1);
+  int64_t gx = (a.npix + per_wg - 1) / per_wg;
   if (gx > HSR_SEL_ROWS4_WGS) gx = HSR_SEL_ROWS4_WGS;
   hipLaunchKernelGGL(select_hist_rows4_kernel<PASS>, dim3((unsigned)gx), dim3(kRowsThreads), lds, s, a);
 }
@@ -635,7 +638,8 @@ static int select_setup(SelArgs& a, const float* x_dev, int64_t x_bs, int64_t x_
 static unsigned int* select_spare(const SelArgs& a) { return a.hist3 + hist3_bytes(a.nb) / 4; }       // the 128 spare bytes
 
 static dim3 select_grid(int64_t npix, int nb) {
-  int64_t gx = (npix + kSelThreads * 8 - 1) / (kSelThreads * 8);
+  const int64_t per_wg = (int64_t)kSelThreads * 8 * (npix > (1 << 20) ? 2 : 1);     // see launch_rows4
+  int64_t gx = (npix + per_wg - 1) / per_wg;
   if (gx > HSR_SEL_PLANE_WGS) gx = HSR_SEL_PLANE_WGS;
   return dim3((unsigned)gx, nb);
 }

@@ -1695,6 +1695,86 @@ def test_chol_solve_vs_numpy(torch_gpu):
     assert lib.hsr_chol_solve_f64(_ptr(Abig), n + 7, 40, _ptr(Bbig), T + 2, T, _ptr(cw), _ptr(info), _stream(torch)) == 2   # n % 32 != 0
 
 
+def test_round4_select_runs_upsampler_rows_and_cholesky_sizes(torch_gpu):
+    """Round-4 kernels against independent references.
+    (a) percentile select on SMOOTH images (pass 1 counts runs of equal bins per thread; above a megapixel a workgroup takes two
+        iterations): planes on the 16-byte path and band-last rows, masked stripes, a NaN - np.percentile, bit for bit;
+    (b) the upsamplers that keep their horizontal interpolations while the rows share a coarse pair: factors 1, 2, 3, 6, planes vs the
+        NumPy restatement, and the band-last form / the producer form (mask + pass-1 histogram) carry the planes' bits;
+    (c) the register-resident Cholesky (n <= 288) at every block count, padded leading dimensions, a bad pivot in a late block."""
+    torch = torch_gpu
+    from s2_emit import _engine as eng
+    from s2_emit import _native as nat
+    from s2_emit._engine import _ptr, _stream
+    lib = nat.load()
+    rng = np.random.default_rng(404)
+    # (a)
+    for side in (1100, 640):
+        c = rng.random((3, side // 6 + 2, side // 6 + 2)).astype(np.float32) ** 2
+        up = eng.bilinear_upsample(torch.from_numpy(c).cuda().reshape(3, -1), c.shape[1], c.shape[2], 6).reshape(3, c.shape[1] * 6, c.shape[2] * 6)
+        img = up[:, :side, :side].contiguous().reshape(3, -1)
+        n = side * side
+        mask = np.ones(n, np.uint8)
+        mask.reshape(side, side)[side // 3: side // 3 + 40] = 0          # a masked stripe
+        mask[rng.integers(0, n, n // 50)] = 0
+        md = torch.from_numpy(mask).cuda()
+        x = img.cpu().numpy()
+        for pmin, pmax in ((2, 98), (0.01, 99.99)):
+            got = eng.percentile_limits(img, md, pmin, pmax).cpu().numpy()
+            np.testing.assert_array_equal(got, np.array([np.percentile(p[mask != 0], [pmin, pmax]) for p in x]), err_msg=f"planes {side}")
+            rows = torch.zeros((n, 4), device="cuda")
+            rows[:, :3] = img.t()
+            got = eng.percentile_limits(rows, md, pmin, pmax, "pixmajor", nb=3).cpu().numpy()
+            np.testing.assert_array_equal(got, np.array([np.percentile(p[mask != 0], [pmin, pmax]) for p in x]), err_msg=f"rows {side}")
+        xn = img.clone()
+        xn[1, 12345] = float("nan")
+        got = eng.percentile_limits(xn, md if mask[12345] else None, 2, 98).cpu().numpy()
+        assert np.isnan(got[1]).all() and not np.isnan(got[[0, 2]]).any()
+    # (b)
+    for f_, Hc, Wc in ((6, 9, 11), (1, 7, 5), (2, 33, 40), (3, 12, 70), (6, 37, 50)):
+        coarse = rng.random((3, Hc, Wc)).astype(np.float32)
+        coarse[2, Hc // 2, Wc // 3] = np.nan
+        cd = torch.from_numpy(coarse).cuda()
+        up = eng.bilinear_upsample(cd.reshape(3, -1), Hc, Wc, f_).cpu().numpy().reshape(3, Hc * f_, Wc * f_)
+        refu = onp.bilinear_upsample(coarse, f_)
+        assert np.array_equal(np.isnan(up), np.isnan(refu))
+        np.testing.assert_allclose(up[~np.isnan(refu)], refu[~np.isnan(refu)], rtol=2e-7, atol=1e-7)
+        pm = torch.zeros((Hc * Wc, 4), device="cuda")
+        pm[:, :3] = cd.reshape(3, -1).t()
+        up_pm = eng.bilinear_upsample(pm, Hc, Wc, f_, layout=nat.PIXMAJOR, nb=3)
+        np.testing.assert_array_equal(up_pm[:, :3].t().cpu().numpy().reshape(3, Hc * f_, Wc * f_), up)
+        out, msk, lohi = eng.bilinear_upsample_mask_limits(pm, Hc, Wc, f_, 2.0, 98.0, nb=3)
+        np.testing.assert_array_equal(out[:, :3].t().cpu().numpy().reshape(3, Hc * f_, Wc * f_), up)
+        fin = np.isfinite(up).all(axis=0).reshape(-1)
+        np.testing.assert_array_equal(msk.cpu().numpy() != 0, fin)
+        np.testing.assert_array_equal(lohi.cpu().numpy(), np.array([np.percentile(p.reshape(-1)[fin], [2.0, 98.0]) for p in up]))
+    # (c)
+    for n, T, lda, ldb in ((32, 3, 32, 3), (64, 17, 70, 20), (128, 16, 128, 16), (160, 33, 161, 40), (192, 5, 200, 5), (224, 48, 224, 48),
+                           (256, 32, 300, 32), (288, 285, 288, 285)):
+        M = rng.standard_normal((n, n + 30))
+        A = M @ M.T / n + 0.3 * np.eye(n)
+        Bm = rng.standard_normal((n, T))
+        Ad = torch.zeros((n, lda), dtype=torch.float64, device="cuda")
+        Ad[:, :n] = torch.from_numpy(A).cuda()
+        Bd = torch.zeros((n, ldb), dtype=torch.float64, device="cuda")
+        Bd[:, :T] = torch.from_numpy(Bm).cuda()
+        info = torch.full((1,), -7, dtype=torch.int32, device="cuda")
+        cw = torch.empty(lib.hsr_chol_work_bytes(n) // 8, dtype=torch.float64, device="cuda")
+        nat.check(lib.hsr_chol_solve_f64(_ptr(Ad), lda, n, _ptr(Bd), ldb, T, _ptr(cw), _ptr(info), _stream(torch)))
+        assert int(info.item()) == 0
+        np.testing.assert_allclose(Bd[:, :T].cpu().numpy(), np.linalg.solve(A, Bm), rtol=1e-9, atol=1e-11, err_msg=f"n={n}")
+        np.testing.assert_allclose(np.tril(Ad[:, :n].cpu().numpy()), np.linalg.cholesky(A), rtol=1e-10, atol=1e-12, err_msg=f"n={n}")
+        if ldb > T:
+            assert float(Bd[:, T:].abs().max()) == 0.0
+    Ai = np.eye(288) * 2.0
+    Ai[203, 203] = -1.0                                                    # first non-positive pivot in block 6 (1-based index 204)
+    Aid, Bid = torch.from_numpy(Ai).cuda(), torch.zeros((288, 2), dtype=torch.float64, device="cuda")
+    info = torch.zeros(1, dtype=torch.int32, device="cuda")
+    cw = torch.empty(lib.hsr_chol_work_bytes(288) // 8, dtype=torch.float64, device="cuda")
+    nat.check(lib.hsr_chol_solve_f64(_ptr(Aid), 288, 288, _ptr(Bid), 2, 2, _ptr(cw), _ptr(info), _stream(torch)))
+    assert int(info.item()) == 204
+
+
 def test_fuse_mosaic_equals_one_big_tile(torch_gpu):
     """A global fit over several tiles of different sizes on one GPU (moments added in tile order, one solve, K3 per
     tile) is the fit of the tiles laid end to end."""

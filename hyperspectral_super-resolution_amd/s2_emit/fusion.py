@@ -1133,6 +1133,18 @@ def calibrate_pseudo_to_real_linear(pseudo_stack, real_stack, valid_mask, min_va
     return corrected.reshape(nb, H, W).cpu().numpy(), params
 
 
+_MP_SIDE = {}
+
+
+def _match_pair_side_stream(torch, dev):
+    """One side stream per device for match_pair's 10 m producer chain (created once)."""
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+    st = _MP_SIDE.get(key)
+    if st is None:
+        st = _MP_SIDE[key] = torch.cuda.Stream(device=dev)
+    return st
+
+
 def match_pair(R, emit_w, srf_dict, good_mask, s2_rgb_hi, factor: int = 6, deg: int = 4, use_ot: bool = True,
                n_samples: int = 5000, reg: float = 0.05, numItermax: int = 300, stopThr: float = 1e-6, seed: int = 0,
                src_scale: float = 1.0 / 255.0, rgb_bands=("B4", "B3", "B2"), positive_band: str = "B2",
@@ -1175,6 +1187,18 @@ def match_pair(R, emit_w, srf_dict, good_mask, s2_rgb_hi, factor: int = 6, deg: 
         raise ValueError(f"s2_rgb_hi must be ({H * factor},{W * factor},3) for factor {factor}; got {tuple(s2.shape)}")
     PM = nat.PIXMAJOR
     emit_rgb = eng.srf_integrate(cube, table, layout=PM)                                   # (npix, 4): R,G,B,pad
+    # r04: the 10 m producer chain (upsample -> finite mask -> percentile limits: ~430 us of streaming kernels) needs emit_rgb only, the
+    # 60 m phase below (two launch-bound selects, moments, solve: ~250 us of mostly idle GPU) needs it too and nothing else of it - they
+    # run on two streams and meet at the last apply.  No host synchronisation; the same kernels on the same inputs, the same bits.
+    cur = torch.cuda.current_stream(dev)
+    side = _match_pair_side_stream(torch, dev)
+    ready = torch.cuda.Event()
+    ready.record(cur)
+    with torch.cuda.stream(side):
+        side.wait_event(ready)
+        # the upsampling kernel writes the mask and counts the first radix pass of the select while it holds the values (same bits as
+        # bilinear_upsample + valid_mask + percentile_limits, two reads of the 10 m image fewer)
+        emit_rgb_10, mask10, lohi10 = eng.bilinear_upsample_mask_limits(emit_rgb, H, W, factor, 2, 98, nb=3)
     s2_60 = eng.block_mean(s2.reshape(-1, 3), H, W, factor, src_scale, layout=PM, nb=3)     # (npix, 4)
     pos = list(rgb_bands).index(positive_band)
     valid60 = eng.valid_mask(emit_rgb, pos, s2_60, None, PM, nbx=3, nby=3)
@@ -1191,10 +1215,9 @@ def match_pair(R, emit_w, srf_dict, good_mask, s2_rgb_hi, factor: int = 6, deg: 
         mom = eng.poly_moments(emit_rgb, s2_60, deg, ws, valid60, lohi_x=lohi_e, lohi_y=lohi_s, layout=PM, nb=3)
         coeffs = eng.poly_solve(mom, deg, 200).clone()
     matched60 = eng.poly_apply(emit_rgb, coeffs, valid60, lohi_e, True, PM, nb=3)
-    # upsample -> finite mask -> percentile limits: the upsampling kernel writes the mask and counts the first radix pass of the
-    # select while it holds the values (same bits as bilinear_upsample + valid_mask + percentile_limits, two reads of the
-    # 10 m image fewer)
-    emit_rgb_10, mask10, lohi10 = eng.bilinear_upsample_mask_limits(emit_rgb, H, W, factor, 2, 98, nb=3)
+    cur.wait_stream(side)
+    for t_ in (emit_rgb_10, mask10, lohi10):
+        t_.record_stream(cur)
     matched10 = eng.poly_apply(emit_rgb_10, coeffs, mask10, lohi10, True, PM, nb=3)
     Hh, Wh = H * factor, W * factor
     res = dict(coeffs=coeffs, emit_rgb_matched_60m=matched60[:, :3].reshape(H, W, 3),

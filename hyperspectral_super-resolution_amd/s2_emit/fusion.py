@@ -1136,9 +1136,9 @@ def calibrate_pseudo_to_real_linear(pseudo_stack, real_stack, valid_mask, min_va
 _MP_SIDE = {}
 
 
-def _match_pair_side_stream(torch, dev):
-    """One side stream per device for match_pair's 10 m producer chain (created once)."""
-    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device())
+def _match_pair_side_stream(torch, dev, which: int = 0):
+    """Side streams of match_pair (created once per device): 0 = the 10 m producer chain, 1 = one of the two 60 m selects."""
+    key = (dev.type, dev.index if dev.index is not None else torch.cuda.current_device(), which)
     st = _MP_SIDE.get(key)
     if st is None:
         st = _MP_SIDE[key] = torch.cuda.Stream(device=dev)
@@ -1202,8 +1202,16 @@ def match_pair(R, emit_w, srf_dict, good_mask, s2_rgb_hi, factor: int = 6, deg: 
     s2_60 = eng.block_mean(s2.reshape(-1, 3), H, W, factor, src_scale, layout=PM, nb=3)     # (npix, 4)
     pos = list(rgb_bands).index(positive_band)
     valid60 = eng.valid_mask(emit_rgb, pos, s2_60, None, PM, nbx=3, nby=3)
-    lohi_e = eng.percentile_limits(emit_rgb, valid60, 2, 98, PM, nb=3)
+    # the two 60 m selects are launch-bound (nine launches each for 16 MB): side by side on two streams
+    side2 = _match_pair_side_stream(torch, dev, 1)
+    ready2 = torch.cuda.Event()
+    ready2.record(cur)
+    with torch.cuda.stream(side2):
+        side2.wait_event(ready2)
+        lohi_e = eng.percentile_limits(emit_rgb, valid60, 2, 98, PM, nb=3)
     lohi_s = eng.percentile_limits(s2_60, valid60, 2, 98, PM, nb=3)
+    cur.wait_stream(side2)
+    lohi_e.record_stream(cur)
     s2_n = eng.poly_apply_stretch_only(s2_60, lohi_s, PM, nb=3)
     if use_ot:
         emit_n = eng.poly_apply_stretch_only(emit_rgb, lohi_e, PM, nb=3)

@@ -1110,6 +1110,38 @@ def test_match_pair_reference_driver(torch_gpu, use_ot):
     assert np.array_equal(np.isnan(got["emit_rgb_10m_matched"]), np.isnan(ref["emit_rgb_10m_matched"]))
 
 
+def test_match_pair_two_streams_same_bits_from_any_stream(torch_gpu):
+    """r04: match_pair runs its 10 m producer chain and one of the 60 m selects on side streams.  Called repeatedly, and from inside a
+    non-default current stream with work queued in front of it, it returns the bits of the first call (the event / wait_stream
+    bracket follows the CURRENT stream; nothing waits on the host)."""
+    torch = torch_gpu
+    import s2_emit
+    srf = onp.synthetic_srf()
+    w, good = onp.synthetic_wavelengths()
+    H, W, f = 64, 48, 6
+    R = onp.synthetic_cube(H, W, seed=77)
+    rng = np.random.default_rng(9)
+    ps = onp.pseudo_s2_srf_integral(R, w, srf, good)
+    rgb60 = np.stack([ps["B4"], ps["B3"], ps["B2"]], -1)
+    hi = np.repeat(np.repeat(rgb60, f, 0), f, 1)
+    s2_hi = np.clip((np.clip(hi, 0, None) / 0.45) ** 0.8 * 255 + rng.normal(0, 5, hi.shape), 0, 255).astype(np.uint8)
+    first = s2_emit.match_pair(R, w, srf, good, s2_hi, f, deg=3, use_ot=False)
+    keys = ("coeffs", "emit_rgb_matched_60m", "emit_rgb_10m_matched", "mask10", "valid60")
+    for rep in range(3):
+        again = s2_emit.match_pair(R, w, srf, good, s2_hi, f, deg=3, use_ot=False)
+        for k in keys:
+            np.testing.assert_array_equal(np.asarray(again[k]), np.asarray(first[k]), err_msg=f"default stream, call {rep}: {k}")
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        junk = torch.rand((4096, 4096), device="cuda")
+        for _ in range(20):                              # work in front of the call on this stream
+            junk = junk * 1.0001 + 0.5
+        other = s2_emit.match_pair(R, w, srf, good, s2_hi, f, deg=3, use_ot=False)
+    st.synchronize()
+    for k in keys:
+        np.testing.assert_array_equal(np.asarray(other[k]), np.asarray(first[k]), err_msg=f"side stream: {k}")
+
+
 def test_pipelined_submit_flush_matches_step(torch_gpu):
     """submit()/flush() (one tile in flight on a side stream) must reproduce step() bit for bit, tile by tile."""
     torch = torch_gpu

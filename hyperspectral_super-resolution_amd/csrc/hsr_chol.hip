@@ -260,100 +260,131 @@ __device__ __forceinline__ double rsqrt_nr(double d) {
   return y;
 }
 
+// what step s leaves for its inverse side, which runs INSIDE step s + 1 (the 4 x 4 unit-lower inverse as an MFMA operand, the lane's
+// d^-1/2, the two masked -Lp operands)
+struct DiagPend {
+  double Li, rsk, A0, A1;
+};
+
+// Step S = 0 .. 7 does the Cholesky side of columns 4 S .. 4 S + 3 and, in two places, the inverse side of step S - 1 (S = 8: only
+// that).  One step behind because `x = d^-1/2 y` needs the MFMA that makes y, queued behind the three of the Cholesky side, and the
+// wave waited for it in step order (worth ~40 cycles of a step's ~1 450: 12.0 k -> 11.7 k per block).  Now y of step S - 1 is issued right after step S's pivot block has left the
+// accumulators and completes under step S's reciprocal chain; x, the rows of L_kk^-1 and the two updates of the inverse's tiles follow
+// step S's own three MFMAs and run under the NEXT chain.
 template <int S>
-__device__ __forceinline__ void diag_step(DiagTiles& t, double (*D)[kDs], double (*Minv)[kDs], int col, int kk, int kb, int& bad) {
-  constexpr int j0 = 4 * S, Jp = S / 4, q0 = j0 % 16, g0 = S % 4;
-  const chol_f64x4& dt = Jp == 0 ? t.c00 : t.c11;
-  // pivot block, lower triangle: element (a, b) sits in lane (col = q0 + b, kk = a), register g0 of the diagonal tile
-  const double s00 = lane_bcast(dt[g0], q0), s10 = lane_bcast(dt[g0], q0 + 16), s11 = lane_bcast(dt[g0], q0 + 17);
-  const double s20 = lane_bcast(dt[g0], q0 + 32), s21 = lane_bcast(dt[g0], q0 + 33), s22 = lane_bcast(dt[g0], q0 + 34);
-  const double s30 = lane_bcast(dt[g0], q0 + 48), s31 = lane_bcast(dt[g0], q0 + 49), s32 = lane_bcast(dt[g0], q0 + 50),
-               s33 = lane_bcast(dt[g0], q0 + 51);
-  // the four raw columns go to their places in D (step 0: still there from the deposit)
-  if (S > 0 && (col >> 2) == g0) {
-    if (Jp == 0) {
+__device__ __forceinline__ void diag_step(DiagTiles& t, double (*D)[kDs], double (*Minv)[kDs], int col, int kk, int kb, int& bad,
+                                          DiagPend& pe) {
+  constexpr bool HAS_D = S < 8, HAS_E = S >= 1;
+  constexpr int SD = HAS_D ? S : 7;                              // (constants of a step that is not there are never used)
+  constexpr int j0 = 4 * SD, Jp = SD / 4, q0 = j0 % 16, g0 = SD % 4;
+  constexpr int SE = HAS_E ? S - 1 : 0;
+  constexpr int ej0 = 4 * SE, eJp = SE / 4, eg0 = SE % 4;
+  double s00 = 0, s10 = 0, s11 = 0, s20 = 0, s21 = 0, s22 = 0, s30 = 0, s31 = 0, s32 = 0, s33 = 0;
+  chol_f64x2 a0l = {0.0, 0.0}, a0h = {0.0, 0.0}, a1l = {0.0, 0.0}, a1h = {0.0, 0.0};
+  if (HAS_D) {
+    const chol_f64x4& dt = Jp == 0 ? t.c00 : t.c11;
+    // pivot block, lower triangle: element (a, b) sits in lane (col = q0 + b, kk = a), register g0 of the diagonal tile
+    s00 = lane_bcast(dt[g0], q0), s10 = lane_bcast(dt[g0], q0 + 16), s11 = lane_bcast(dt[g0], q0 + 17);
+    s20 = lane_bcast(dt[g0], q0 + 32), s21 = lane_bcast(dt[g0], q0 + 33), s22 = lane_bcast(dt[g0], q0 + 34);
+    s30 = lane_bcast(dt[g0], q0 + 48), s31 = lane_bcast(dt[g0], q0 + 49), s32 = lane_bcast(dt[g0], q0 + 50);
+    s33 = lane_bcast(dt[g0], q0 + 51);
+    // the four raw columns go to their places in D (step 0: still there from the deposit)
+    if (SD > 0 && (col >> 2) == g0) {
+      if (Jp == 0) {
 #pragma unroll
-      for (int g = g0; g < 4; ++g) D[kk + 4 * g][col] = t.c00[g];
+        for (int g = g0; g < 4; ++g) D[kk + 4 * g][col] = t.c00[g];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) D[16 + kk + 4 * g][col] = t.c10[g];
-    } else {
+        for (int g = 0; g < 4; ++g) D[16 + kk + 4 * g][col] = t.c10[g];
+      } else {
 #pragma unroll
-      for (int g = g0; g < 4; ++g) D[16 + kk + 4 * g][16 + col] = t.c11[g];
+        for (int g = g0; g < 4; ++g) D[16 + kk + 4 * g][16 + col] = t.c11[g];
+      }
     }
+    __builtin_amdgcn_wave_barrier();
+    // lane (i = col, k = kk) reads the four raw values of rows col and 16 + col (16-byte loads: rows of 34 doubles)
+    if (SD <= 3) {
+      a0l = *reinterpret_cast<const chol_f64x2*>(&D[col][j0]);
+      a0h = *reinterpret_cast<const chol_f64x2*>(&D[col][j0 + 2]);
+    }
+    a1l = *reinterpret_cast<const chol_f64x2*>(&D[16 + col][j0]);
+    a1h = *reinterpret_cast<const chol_f64x2*>(&D[16 + col][j0 + 2]);
   }
-  __builtin_amdgcn_wave_barrier();
-  // lane (i = col, k = kk) reads the four raw values of rows col and 16 + col (16-byte loads: rows of 34 doubles)
-  chol_f64x2 a0l = {0.0, 0.0}, a0h = {0.0, 0.0};
-  if (S <= 3) {
-    a0l = *reinterpret_cast<const chol_f64x2*>(&D[col][j0]);
-    a0h = *reinterpret_cast<const chol_f64x2*>(&D[col][j0 + 2]);
-  }
-  const chol_f64x2 a1l = *reinterpret_cast<const chol_f64x2*>(&D[16 + col][j0]);
-  const chol_f64x2 a1h = *reinterpret_cast<const chol_f64x2*>(&D[16 + col][j0 + 2]);
-  // LDL^T of the pivot block (unit lower M, pivots d), every lane the same
-  const double d0 = s00, r0 = rcp_nr(d0);
-  const double m10 = s10 * r0, m20 = s20 * r0, m30 = s30 * r0;
-  const double d1 = fma(-m10, s10, s11), r1 = rcp_nr(d1);
-  const double u21 = fma(-m20, s10, s21), u31 = fma(-m30, s10, s31);
-  const double m21 = u21 * r1, m31 = u31 * r1;
-  const double d2 = fma(-m21, u21, fma(-m20, s20, s22)), r2 = rcp_nr(d2);
-  const double u32 = fma(-m31, u21, fma(-m30, s20, s32));
-  const double m32 = u32 * r2;
-  const double d3 = fma(-m32, u32, fma(-m31, u31, fma(-m30, s30, s33)));
-  if (!(d0 > 0.0 && d1 > 0.0 && d2 > 0.0 && d3 > 0.0)) {          // wave-uniform, rare
-    const int first = !(d0 > 0.0) ? 1 : (!(d1 > 0.0) ? 2 : (!(d2 > 0.0) ? 3 : 4));
-    bad = min(bad, kb + j0 + first);
-  }
-  const double rsk = rsqrt_nr(kk == 0 ? d0 : (kk == 1 ? d1 : (kk == 2 ? d2 : d3)));   // d_k^-1/2 of the lane's column k
-  // t = a M^-T by forward substitution (all four), the lane keeps t_k: Lp[i][k] = t_k d_k^-1/2
-  double lp0 = 0.0;
-  if (S <= 3) {
-    const double t0 = a0l[0], t1 = fma(-m10, t0, a0l[1]), t2 = fma(-m21, t1, fma(-m20, t0, a0h[0]));
-    const double t3 = fma(-m32, t2, fma(-m31, t1, fma(-m30, t0, a0h[1])));
-    lp0 = rsk * (kk == 0 ? t0 : (kk == 1 ? t1 : (kk == 2 ? t2 : t3)));
-    if (col >= j0 + kk) D[col][j0 + kk] = lp0;
-  }
-  double lp1;
-  {
-    const double t0 = a1l[0], t1 = fma(-m10, t0, a1l[1]), t2 = fma(-m21, t1, fma(-m20, t0, a1h[0]));
-    const double t3 = fma(-m32, t2, fma(-m31, t1, fma(-m30, t0, a1h[1])));
-    lp1 = rsk * (kk == 0 ? t0 : (kk == 1 ? t1 : (kk == 2 ? t2 : t3)));
-    if (16 + col >= j0 + kk) D[16 + col][j0 + kk] = lp1;
-  }
-  const double A0 = col > j0 + 3 ? -lp0 : 0.0;                  // rows that are finished take no part
-  const double A1 = 16 + col > j0 + 3 ? -lp1 : 0.0;
-  if (S <= 2) {
-    t.c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(A0, lp0, t.c00, 0, 0, 0);
-    t.c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(A1, lp0, t.c10, 0, 0, 0);
-  }
-  if (S <= 6) t.c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(A1, lp1, t.c11, 0, 0, 0);
-  // Y = M^-1 E[j0 .. j0 + 3][:]: A operand lane (col = k', kk = a) = (M^-1)[k'][a] (unit lower), rows k' >= 4 zero; X = diag(d^-1/2) Y
-  const double n10 = -m10, n21 = -m21, n32 = -m32;
-  const double n20 = fma(m21, m10, -m20), n31 = fma(m32, m21, -m31);
-  const double n30 = -fma(n32, m20, fma(n31, m10, m30));
-  const int lane = col + 16 * kk;
-  // (built with selects: six v_writelane_b32 through inline assembly - this compiler has no builtin for it - gave an inverse that was
-  // off by 1e-9, the low words of single entries; not understood, not used)
-  double Li = (lane == 0 || lane == 17 || lane == 34 || lane == 51) ? 1.0 : 0.0;
-  Li = lane == 1 ? n10 : Li;
-  Li = lane == 2 ? n20 : Li;
-  Li = lane == 3 ? n30 : Li;
-  Li = lane == 18 ? n21 : Li;
-  Li = lane == 19 ? n31 : Li;
-  Li = lane == 35 ? n32 : Li;
+  // inverse side of the previous step, first half: Y = M^-1 E[rows of that step][:] - A operand lane (col = k', kk = a) =
+  // (M^-1)[k'][a] (unit lower), rows k' >= 4 zero; X = diag(d^-1/2) Y
   const chol_f64x4 zero = {0.0, 0.0, 0.0, 0.0};
-  const chol_f64x4 y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(Li, (Jp == 0 ? t.e00 : t.e10)[g0], zero, 0, 0, 0);
-  const double x0 = rsk * y0[0];                                // lane (c, k): X[j0 + k][c]
-  Minv[j0 + kk][col] = x0;                                      // rows j0 .. j0 + 3 of L_kk^-1
-  double x1 = 0.0;
-  if (Jp == 1) {
-    const chol_f64x4 y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(Li, t.e11[g0], zero, 0, 0, 0);
-    x1 = rsk * y1[0];
+  chol_f64x4 y0 = zero, y1 = zero;
+  if (HAS_E) {
+    y0 = __builtin_amdgcn_mfma_f64_16x16x4f64(pe.Li, (eJp == 0 ? t.e00 : t.e10)[eg0], zero, 0, 0, 0);
+    if (eJp == 1) y1 = __builtin_amdgcn_mfma_f64_16x16x4f64(pe.Li, t.e11[eg0], zero, 0, 0, 0);
   }
-  Minv[j0 + kk][16 + col] = x1;
-  if (S <= 2) t.e00 = __builtin_amdgcn_mfma_f64_16x16x4f64(A0, x0, t.e00, 0, 0, 0);
-  if (S <= 6) t.e10 = __builtin_amdgcn_mfma_f64_16x16x4f64(A1, x0, t.e10, 0, 0, 0);
-  if (S >= 4 && S <= 6) t.e11 = __builtin_amdgcn_mfma_f64_16x16x4f64(A1, x1, t.e11, 0, 0, 0);
+  __builtin_amdgcn_sched_barrier(0);
+  DiagPend next = pe;
+  if (HAS_D) {
+    // LDL^T of the pivot block (unit lower M, pivots d), every lane the same
+    const double d0 = s00, r0 = rcp_nr(d0);
+    const double m10 = s10 * r0, m20 = s20 * r0, m30 = s30 * r0;
+    const double d1 = fma(-m10, s10, s11), r1 = rcp_nr(d1);
+    const double u21 = fma(-m20, s10, s21), u31 = fma(-m30, s10, s31);
+    const double m21 = u21 * r1, m31 = u31 * r1;
+    const double d2 = fma(-m21, u21, fma(-m20, s20, s22)), r2 = rcp_nr(d2);
+    const double u32 = fma(-m31, u21, fma(-m30, s20, s32));
+    const double m32 = u32 * r2;
+    const double d3 = fma(-m32, u32, fma(-m31, u31, fma(-m30, s30, s33)));
+    if (!(d0 > 0.0 && d1 > 0.0 && d2 > 0.0 && d3 > 0.0)) {          // wave-uniform, rare
+      const int first = !(d0 > 0.0) ? 1 : (!(d1 > 0.0) ? 2 : (!(d2 > 0.0) ? 3 : 4));
+      bad = min(bad, kb + j0 + first);
+    }
+    const double rsk = rsqrt_nr(kk == 0 ? d0 : (kk == 1 ? d1 : (kk == 2 ? d2 : d3)));   // d_k^-1/2 of the lane's column k
+    // t = a M^-T by forward substitution (all four), the lane keeps t_k: Lp[i][k] = t_k d_k^-1/2
+    double lp0 = 0.0;
+    if (SD <= 3) {
+      const double t0 = a0l[0], t1 = fma(-m10, t0, a0l[1]), t2 = fma(-m21, t1, fma(-m20, t0, a0h[0]));
+      const double t3 = fma(-m32, t2, fma(-m31, t1, fma(-m30, t0, a0h[1])));
+      lp0 = rsk * (kk == 0 ? t0 : (kk == 1 ? t1 : (kk == 2 ? t2 : t3)));
+      if (col >= j0 + kk) D[col][j0 + kk] = lp0;
+    }
+    double lp1;
+    {
+      const double t0 = a1l[0], t1 = fma(-m10, t0, a1l[1]), t2 = fma(-m21, t1, fma(-m20, t0, a1h[0]));
+      const double t3 = fma(-m32, t2, fma(-m31, t1, fma(-m30, t0, a1h[1])));
+      lp1 = rsk * (kk == 0 ? t0 : (kk == 1 ? t1 : (kk == 2 ? t2 : t3)));
+      if (16 + col >= j0 + kk) D[16 + col][j0 + kk] = lp1;
+    }
+    const double A0 = col > j0 + 3 ? -lp0 : 0.0;                  // rows that are finished take no part
+    const double A1 = 16 + col > j0 + 3 ? -lp1 : 0.0;
+    if (SD <= 2) {
+      t.c00 = __builtin_amdgcn_mfma_f64_16x16x4f64(A0, lp0, t.c00, 0, 0, 0);
+      t.c10 = __builtin_amdgcn_mfma_f64_16x16x4f64(A1, lp0, t.c10, 0, 0, 0);
+    }
+    if (SD <= 6) t.c11 = __builtin_amdgcn_mfma_f64_16x16x4f64(A1, lp1, t.c11, 0, 0, 0);
+    // the 4 x 4 unit-lower inverse as the operand of the NEXT step's first MFMA
+    const double n10 = -m10, n21 = -m21, n32 = -m32;
+    const double n20 = fma(m21, m10, -m20), n31 = fma(m32, m21, -m31);
+    const double n30 = -fma(n32, m20, fma(n31, m10, m30));
+    const int lane = col + 16 * kk;
+    // (built with selects: six v_writelane_b32 through inline assembly - this compiler has no builtin for it - gave an inverse that was
+    // off by 1e-9, the low words of single entries; not understood, not used)
+    double Li = (lane == 0 || lane == 17 || lane == 34 || lane == 51) ? 1.0 : 0.0;
+    Li = lane == 1 ? n10 : Li;
+    Li = lane == 2 ? n20 : Li;
+    Li = lane == 3 ? n30 : Li;
+    Li = lane == 18 ? n21 : Li;
+    Li = lane == 19 ? n31 : Li;
+    Li = lane == 35 ? n32 : Li;
+    next = DiagPend{Li, rsk, A0, A1};
+  }
+  __builtin_amdgcn_sched_barrier(0);
+  if (HAS_E) {
+    // inverse side of the previous step, second half
+    const double x0 = pe.rsk * y0[0];                             // lane (c, k): X[ej0 + k][c]
+    Minv[ej0 + kk][col] = x0;                                     // rows ej0 .. ej0 + 3 of L_kk^-1
+    const double x1 = eJp == 1 ? pe.rsk * y1[0] : 0.0;
+    Minv[ej0 + kk][16 + col] = x1;
+    if (SE <= 2) t.e00 = __builtin_amdgcn_mfma_f64_16x16x4f64(pe.A0, x0, t.e00, 0, 0, 0);
+    if (SE <= 6) t.e10 = __builtin_amdgcn_mfma_f64_16x16x4f64(pe.A1, x0, t.e10, 0, 0, 0);
+    if (SE >= 4 && SE <= 6) t.e11 = __builtin_amdgcn_mfma_f64_16x16x4f64(pe.A1, x1, t.e11, 0, 0, 0);
+  }
+  pe = next;
 }
 
 // Wave 0 of the workgroup: D (lower triangle, upper zero) -> L_kk in D's lower triangle, L_kk^-1 in Minv
@@ -370,14 +401,16 @@ __device__ __forceinline__ void diag_block_wave(double (*D)[kDs], double (*Minv)
     t.e11[g] = t.e00[g];
   }
   int bad = 0x7fffffff;
-  diag_step<0>(t, D, Minv, col, kk, kb, bad);
-  diag_step<1>(t, D, Minv, col, kk, kb, bad);
-  diag_step<2>(t, D, Minv, col, kk, kb, bad);
-  diag_step<3>(t, D, Minv, col, kk, kb, bad);
-  diag_step<4>(t, D, Minv, col, kk, kb, bad);
-  diag_step<5>(t, D, Minv, col, kk, kb, bad);
-  diag_step<6>(t, D, Minv, col, kk, kb, bad);
-  diag_step<7>(t, D, Minv, col, kk, kb, bad);
+  DiagPend pe{0.0, 0.0, 0.0, 0.0};
+  diag_step<0>(t, D, Minv, col, kk, kb, bad, pe);
+  diag_step<1>(t, D, Minv, col, kk, kb, bad, pe);
+  diag_step<2>(t, D, Minv, col, kk, kb, bad, pe);
+  diag_step<3>(t, D, Minv, col, kk, kb, bad, pe);
+  diag_step<4>(t, D, Minv, col, kk, kb, bad, pe);
+  diag_step<5>(t, D, Minv, col, kk, kb, bad, pe);
+  diag_step<6>(t, D, Minv, col, kk, kb, bad, pe);
+  diag_step<7>(t, D, Minv, col, kk, kb, bad, pe);
+  diag_step<8>(t, D, Minv, col, kk, kb, bad, pe);           // the inverse side of step 7
   if (lane == 0 && bad != 0x7fffffff) atomicMin(bad_pivot, bad);
 }
 

@@ -303,38 +303,33 @@ static void launch_rows4(const SelArgs& a, hipStream_t s) {
   hipLaunchKernelGGL(select_hist_rows4_kernel<PASS>, dim3((unsigned)gx), dim3(kRowsThreads), lds, s, a);
 }
 
-// Locate, for one histogram of `nbins` (multiple of 256) bins, the bin holding 0-based rank r:
-// returns bin and the rank remaining inside it.  The first 256 threads of the workgroup cooperate (`act`); every thread of the
-// workgroup must call it (barriers).
-__device__ void block_locate(const uint32_t* hist, int nbins, uint32_t r, uint32_t* scratch /*[256]*/,
-                             uint32_t* out_bin, uint32_t* out_rem, bool act) {
-  const int per = nbins / 256;
-  const int t = act ? threadIdx.x : 0;
-  const int lane = threadIdx.x & 63;
-  uint32_t local = 0;
-  if (act)
-    for (int i = 0; i < per; ++i) local += hist[t * per + i];
-  // inclusive scan over the 256 per-thread sums: inside each of the four waves by shuffles, then the three wave totals (r04: the
-  // 16-barrier Hillis-Steele scan through LDS was most of a scan kernel's ~4 us and of the one-workgroup select's 28 us)
-  uint32_t v = local;
+// The four rank queries side by side (r04): wave q of the workgroup's first four locates query q in ITS histogram - a lane sums
+// nbins / 64 consecutive bins, one shuffle scan over the 64 sums, the lane that holds the rank walks its bins.  One barrier for all four;
+// block_locate (256 threads and two barriers per query, the queries one after another) was 8 barriers per scan and 24 in the
+// one-workgroup select.  Every thread of the workgroup must call it; the workgroup has at least 256 threads.
+__device__ __forceinline__ void locate4(const uint32_t* h0, const uint32_t* h1, const uint32_t* h2, const uint32_t* h3, int nbins,
+                                        const uint32_t* ranks, uint32_t* out_bin, uint32_t* out_rem) {
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if (w < kQ) {                                                // wave-uniform
+    const uint32_t* h = w == 0 ? h0 : (w == 1 ? h1 : (w == 2 ? h2 : h3));
+    const uint32_t r = ranks[w];
+    const int per = nbins / 64;
+    const uint32_t* mine = h + lane * per;
+    uint32_t local = 0;
+    for (int i = 0; i < per; ++i) local += mine[i];
+    uint32_t v = local;
 #pragma unroll
-  for (int off = 1; off < 64; off <<= 1) {
-    const uint32_t n = __shfl_up(v, off, 64);
-    if (lane >= off) v += n;
-  }
-  if (act && lane == 63) scratch[t >> 6] = v;
-  __syncthreads();
-  if (act) {
-    uint32_t base = 0;
-    for (int w = 0; w < (t >> 6); ++w) base += scratch[w];
-    const uint32_t incl = v + base;
-    uint32_t before = incl - local;
-    if (r >= before && r < incl) {  // exactly one thread
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t n = __shfl_up(v, off, 64);
+      if (lane >= off) v += n;
+    }
+    uint32_t before = v - local;
+    if (r >= before && r < v) {                                // exactly one lane (r is below the histogram's total)
       for (int i = 0; i < per; ++i) {
-        const uint32_t cnt = hist[t * per + i];
+        const uint32_t cnt = mine[i];
         if (r < before + cnt) {
-          *out_bin = (uint32_t)(t * per + i);
-          *out_rem = r - before;
+          out_bin[w] = (uint32_t)(lane * per + i);
+          out_rem[w] = r - before;
           break;
         }
         before += cnt;
@@ -360,12 +355,13 @@ __device__ __forceinline__ void scan_pass(const SelArgs& a, int c, double qlo, d
     if (act) {
       uint32_t local = 0;
       for (int i = threadIdx.x; i < kBins1; i += 256) local += a.hist1[(size_t)c * kHist1 + i];
-      L.scratch[threadIdx.x] = local;
+#pragma unroll
+      for (int off = 32; off >= 1; off >>= 1) local += __shfl_xor(local, off, 64);
+      if ((threadIdx.x & 63) == 0) L.scratch[threadIdx.x >> 6] = local;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
-      uint32_t n = 0;
-      for (int i = 0; i < 256; ++i) n += L.scratch[i];
+      const uint32_t n = L.scratch[0] + L.scratch[1] + L.scratch[2] + L.scratch[3];
       L.total = n;
       st->n = n;
       st->nan_count = a.hist1[(size_t)c * kHist1 + kBins1];
@@ -395,13 +391,13 @@ __device__ __forceinline__ void scan_pass(const SelArgs& a, int c, double qlo, d
     }
     __syncthreads();
     if (L.total == 0) return;
-    for (int q = 0; q < kQ; ++q) {
-      block_locate(a.hist1 + (size_t)c * kHist1, kBins1, L.ranks[q], L.scratch, &L.bins[q], &L.rems[q], act);
-      if (threadIdx.x == 0) {
-        st->prefix[q] = L.bins[q];
-        st->rem[q] = L.rems[q];
+    {
+      const uint32_t* h1 = a.hist1 + (size_t)c * kHist1;
+      locate4(h1, h1, h1, h1, kBins1, L.ranks, L.bins, L.rems);
+      if (threadIdx.x < kQ) {
+        st->prefix[threadIdx.x] = L.bins[threadIdx.x];
+        st->rem[threadIdx.x] = L.rems[threadIdx.x];
       }
-      __syncthreads();
     }
   } else {
     if (st->n == 0) {
@@ -411,11 +407,17 @@ __device__ __forceinline__ void scan_pass(const SelArgs& a, int c, double qlo, d
     constexpr int NBINS = PASS == 2 ? kBins2 : kBins3;
     constexpr int SHIFT = PASS == 2 ? 11 : 10;
     const uint32_t* hist = PASS == 2 ? a.hist2 + (size_t)c * kQ * kBins2 : a.hist3 + (size_t)c * kQ * kBins3;
-    for (int q = 0; q < kQ; ++q) {
-      int src = q;                                   // the first query of the run of equal prefixes: the one that was histogrammed
-      while (src > 0 && st->prefix[src - 1] == st->prefix[q]) --src;
-      block_locate(hist + (size_t)src * NBINS, NBINS, st->rem[q], L.scratch, &L.bins[q], &L.rems[q], act);
+    {
+      const uint32_t* hq[kQ];
+#pragma unroll
+      for (int q = 0; q < kQ; ++q) {
+        int src = q;                                 // the first query of the run of equal prefixes: the one that was histogrammed
+        while (src > 0 && st->prefix[src - 1] == st->prefix[q]) --src;
+        hq[q] = hist + (size_t)src * NBINS;
+      }
+      if (threadIdx.x < kQ) L.ranks[threadIdx.x] = st->rem[threadIdx.x];
       __syncthreads();
+      locate4(hq[0], hq[1], hq[2], hq[3], NBINS, L.ranks, L.bins, L.rems);
     }
     if (threadIdx.x == 0) {
       for (int q = 0; q < kQ; ++q) {
@@ -547,14 +549,12 @@ __global__ __launch_bounds__(kSelThreads) void select_tiny_kernel(const SelArgs 
     if (t == 0) lohi[2 * c] = lohi[2 * c + 1] = __longlong_as_double(0x7ff8000000000000LL);
     return;
   }
-  for (int q = 0; q < kQ; ++q) {
-    block_locate(h, kBins1, L.ranks[q], L.scratch, &L.bins[q], &L.rems[q], act);
-    if (t == 0) {
-      pre[q] = L.bins[q];
-      rem[q] = L.rems[q];
-    }
-    __syncthreads();
+  locate4(h, h, h, h, kBins1, L.ranks, L.bins, L.rems);
+  if (t < kQ) {
+    pre[t] = L.bins[t];
+    rem[t] = L.rems[t];
   }
+  __syncthreads();
   // passes 2 and 3: one histogram per query (no sharing of equal prefixes: LDS has room)
 #pragma unroll
   for (int pass = 2; pass <= 3; ++pass) {
@@ -574,15 +574,11 @@ __global__ __launch_bounds__(kSelThreads) void select_tiny_kernel(const SelArgs 
         if (kk == p3) atomicAdd(&h[3 * nbins + bin], 1u);
       }
     __syncthreads();
-    for (int q = 0; q < kQ; ++q) {
-      block_locate(h + q * nbins, nbins, rem[q], L.scratch, &L.bins[q], &L.rems[q], act);
-      __syncthreads();
+    locate4(h, h + nbins, h + 2 * nbins, h + 3 * nbins, nbins, rem, L.bins, L.rems);
+    if (t < kQ) {
+      pre[t] = (pre[t] << (pass == 2 ? 11 : 10)) | L.bins[t];
+      rem[t] = L.rems[t];
     }
-    if (t == 0)
-      for (int q = 0; q < kQ; ++q) {
-        pre[q] = (pre[q] << (pass == 2 ? 11 : 10)) | L.bins[q];
-        rem[q] = L.rems[q];
-      }
     __syncthreads();
   }
   if (t == 0) {

@@ -69,6 +69,7 @@ __device__ __forceinline__ void hist_pass_planes(const SelArgs& a, int c, int bi
   const int second = PASS > 1 ? second_query(pre) : 0;
   const uint32_t pre_second = second_prefix(pre, second);
   const bool more = more_prefixes(pre, second);
+  const PrefixRaw praw = prefix_raw<(PASS > 1 ? PASS : 2)>(pre, pre_second);
   uint32_t* g = PASS == 1 ? a.hist1 + (size_t)c * kHist1
                           : (PASS == 2 ? a.hist2 + (size_t)c * kQ * kBins2 : a.hist3 + (size_t)c * kQ * kBins3);
   __syncthreads();
@@ -97,7 +98,7 @@ __device__ __forceinline__ void hist_pass_planes(const SelArgs& a, int c, int bi
         run_nan += v != v ? 1u : 0u;
       }
     } else {
-      hist_sample<PASS, CP>(h, &nanc, pre, second, pre_second, more, g, v, use);
+      hist_sample<PASS, CP>(h, &nanc, pre, second, praw, more, g, v, use);
     }
   };
   if (VEC) {
@@ -195,6 +196,7 @@ __device__ __forceinline__ void hist_pass_rows4(const SelArgs& a, int bid, int n
   }
   int second[4];
   uint32_t pre_second[4];
+  PrefixRaw praw[4];
   bool more[4];
   uint32_t* gq[4];
 #pragma unroll
@@ -202,6 +204,7 @@ __device__ __forceinline__ void hist_pass_rows4(const SelArgs& a, int bid, int n
     second[c] = PASS > 1 ? second_query(pre[c]) : 0;
     pre_second[c] = second_prefix(pre[c], second[c]);
     more[c] = more_prefixes(pre[c], second[c]);
+    praw[c] = prefix_raw<(PASS > 1 ? PASS : 2)>(pre[c], pre_second[c]);
     gq[c] = PASS == 1 ? a.hist1 + (size_t)c * kHist1
                       : (PASS == 2 ? a.hist2 + (size_t)c * kQ * kBins2 : a.hist3 + (size_t)c * kQ * kBins3);
   }
@@ -241,9 +244,12 @@ __device__ __forceinline__ void hist_pass_rows4(const SelArgs& a, int bid, int n
 #pragma unroll
         for (int c = 0; c < 4; ++c)
           if (c < nb) {
-            const uint32_t key = f32_key(e[c]) >> 10;
-            bool m = key == pre[c][0] || key == pre_second[c];
-            if (more[c]) m = m || key == pre[c][2] || key == pre[c][3];
+            const uint32_t hi = __float_as_uint(e[c]) >> 10;
+            bool m = hi == praw[c].r0 || (second[c] && hi == praw[c].rs);
+            if (more[c]) {
+              const uint32_t key = f32_key(e[c]) >> 10;
+              m = m || key == pre[c][2] || key == pre[c][3];
+            }
             hit = hit || (m && on[u]);
           }
       }
@@ -254,7 +260,7 @@ __device__ __forceinline__ void hist_pass_rows4(const SelArgs& a, int bid, int n
       const float e[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
 #pragma unroll
       for (int c = 0; c < 4; ++c)
-        if (c < nb) hist_sample<PASS>(hall + c * NB, &nanc[c], pre[c], second[c], pre_second[c], more[c], gq[c], e[c], on[u]);   // c < nb is block-uniform
+        if (c < nb) hist_sample<PASS>(hall + c * NB, &nanc[c], pre[c], second[c], praw[c], more[c], gq[c], e[c], on[u]);   // c < nb is block-uniform
     }
   }
   };

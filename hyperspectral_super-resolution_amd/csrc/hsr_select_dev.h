@@ -77,22 +77,42 @@ constexpr int kPass1Copies = HSR_SEL_COPIES;   // pass-1 histogram copies of sel
 // r04: the prefixes are wave-uniform, so which of them exist is a SCALAR question: a sample is compared with query 0's prefix, with
 // the second distinct one only if there is one and with a third / fourth only if there are (`more`) - the four compare-and-branch
 // groups per sample of r03 (three of them against parked prefixes that nothing matches) were most of what pass 2 cost over its bytes.
+// r04: a prefix also fixes the SIGN class of the samples that can match it (the key's top bit), so the match is tested on the raw
+// float bits - (bits >> s) == raw prefix, one shift and one compare - and only a matching sample's bin needs the key's lower bits,
+// (bits >> s') ^ flip.  The key transform (four instructions per sample and channel) is gone from passes 2 and 3.
+struct PrefixRaw {
+  uint32_t r0, f0;   // query 0: raw prefix, xor mask of the bin (0 for the positive class, ~0 for the negative)
+  uint32_t rs, fs;   // the second distinct prefix (valid if `second`)
+};
+template <int PASS>
+__device__ __forceinline__ PrefixRaw prefix_raw(const uint32_t (&pre)[kQ], uint32_t pre_second) {
+  constexpr uint32_t top = PASS == 2 ? 0x400u : 0x200000u, all = PASS == 2 ? 0x7ffu : 0x3fffffu;
+  auto raw = [&](uint32_t p) { return (p & top) ? (p & (top - 1u)) : (~p & all); };
+  auto flip = [&](uint32_t p) { return (p & top) ? 0u : 0xffffffffu; };
+  return PrefixRaw{raw(pre[0]), flip(pre[0]), raw(pre_second), flip(pre_second)};
+}
+
 template <int PASS, int COPIES = 1>
-__device__ __forceinline__ void hist_sample(uint32_t* h, uint32_t* nanc, const uint32_t (&pre)[kQ], int second, uint32_t pre_second,
+__device__ __forceinline__ void hist_sample(uint32_t* h, uint32_t* nanc, const uint32_t (&pre)[kQ], int second, const PrefixRaw& pr,
                                             bool more, uint32_t* g, float v, bool use) {
-  const uint32_t k = f32_key(v);
   if (PASS == 1) {
+    const uint32_t k = f32_key(v);
     hist_add_wave<COPIES>(h, use ? (k >> 21) : kNoBin);
     if (use && v != v) atomicAdd(nanc, 1u);
   } else {
     constexpr int NBINS = PASS == 2 ? kBins2 : kBins3;
-    const uint32_t key = PASS == 2 ? (k >> 21) : (k >> 10);
-    const uint32_t bin = PASS == 2 ? ((k >> 10) & 2047u) : (k & 1023u);
+    const uint32_t bits = __float_as_uint(v);
+    const uint32_t hi = PASS == 2 ? (bits >> 21) : (bits >> 10);              // the raw image of the prefix
+    const uint32_t lo = PASS == 2 ? (bits >> 10) : bits;                        // the bin's bits, before the class's flip
+    constexpr uint32_t bmask = PASS == 2 ? 2047u : 1023u;
     if (use) {
-      if (key == pre[0]) atomicAdd(&h[bin], 1u);
+      if (hi == pr.r0) atomicAdd(&h[(lo ^ pr.f0) & bmask], 1u);
       if (second) {                                   // scalar
-        if (key == pre_second) atomicAdd(&h[NBINS + bin], 1u);
+        if (hi == pr.rs) atomicAdd(&h[NBINS + ((lo ^ pr.fs) & bmask)], 1u);
         if (more) {                                   // scalar, rare: the prev / next ranks of a percentile straddle a bin boundary
+          const uint32_t k = f32_key(v);
+          const uint32_t key = PASS == 2 ? (k >> 21) : (k >> 10);
+          const uint32_t bin = PASS == 2 ? ((k >> 10) & 2047u) : (k & 1023u);
 #pragma unroll
           for (int q = 2; q < kQ; ++q)
             if (q != second && key == pre[q]) atomicAdd(&g[q * NBINS + bin], 1u);

@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void bilinear_up_hist_kernel(const float* __re
   up_tap(on ? x : Wf - 1, f, Wc, &x0, &x1, &tx);
   const double ux = 1.0 - tx;
   UpRowCache rc;
-  uint32_t run_bin[kUpMaxVec] = {0u, 0u, 0u, 0u}, run_cnt[kUpMaxVec] = {0u, 0u, 0u, 0u};
+  uint32_t run_bin[kUpMaxVec] = {~0u, ~0u, ~0u, ~0u}, run_cnt[kUpMaxVec] = {0u, 0u, 0u, 0u};
   for (int y = ybeg; y < yend; ++y) {
     const int y0 = ry0[y - ybeg], y1 = ry1[y - ybeg];
     const double ty = rty[y - ybeg];
@@ -328,9 +328,9 @@ __global__ __launch_bounds__(256) void bilinear_up_hist_kernel(const float* __re
 #pragma unroll
       for (int b = 0; b < kUpMaxVec; ++b)
         if (b < nb) {                                   // launch-uniform
-          const uint32_t bin = f32_key(r[b]) >> 21;
+          const uint32_t bin = __float_as_uint(r[b]) >> 21;          // raw top bits; the key's bin is formed at the flush
           if (bin != run_bin[b]) {
-            if (run_cnt[b]) atomicAdd(&uh[b * kBins1 + run_bin[b]], run_cnt[b]);
+            if (run_cnt[b]) atomicAdd(&uh[b * kBins1 + (run_bin[b] ^ ((run_bin[b] & 0x400u) ? 0x7ffu : 0x400u))], run_cnt[b]);
             run_bin[b] = bin;
             run_cnt[b] = 0u;
           }
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void bilinear_up_hist_kernel(const float* __re
   }
 #pragma unroll
   for (int b = 0; b < kUpMaxVec; ++b)
-    if (b < nb && run_cnt[b]) atomicAdd(&uh[b * kBins1 + run_bin[b]], run_cnt[b]);
+    if (b < nb && run_cnt[b]) atomicAdd(&uh[b * kBins1 + (run_bin[b] ^ ((run_bin[b] & 0x400u) ? 0x7ffu : 0x400u))], run_cnt[b]);
   __syncthreads();
   for (int i = threadIdx.x; i < nb * kBins1; i += 256)
     if (uh[i]) atomicAdd(&hist1[(size_t)(i / kBins1) * kHist1 + (i % kBins1)], uh[i]);

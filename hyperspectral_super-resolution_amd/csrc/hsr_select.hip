@@ -83,14 +83,17 @@ __device__ __forceinline__ void hist_pass_planes(const SelArgs& a, int c, int bi
   // four launches instead of seven.  With a __threadfence() per workgroup 1024 x 1024 took 340 us instead of 52; with only a wait for
   // the workgroup's own atomics and agent-scope loads in the scan 65 us - and 338 against 307 us at 6144 x 6144: the scan's uncached
   // reads and the tail of the launch cost more than a launch boundary.)
-  uint32_t run_bin = 0u, run_cnt = 0u, run_nan = 0u;
+  // (runs are compared on the raw top 11 bits; the key's bin, raw ^ 0x400 for the positive class and raw ^ 0x7ff for the negative, is
+  // formed when a run is flushed)
+  uint32_t run_bin = 0xffffffffu, run_cnt = 0u, run_nan = 0u;
   const uint32_t run_copy = CP > 1 ? (threadIdx.x & (CP - 1)) * kBins1 : 0u;
+  auto bin_of = [](uint32_t raw) { return raw ^ ((raw & 0x400u) ? 0x7ffu : 0x400u); };
   auto add = [&](float v, bool use) {
     if (PASS == 1) {
       if (use) {
-        const uint32_t b = f32_key(v) >> 21;
+        const uint32_t b = __float_as_uint(v) >> 21;
         if (b != run_bin) {
-          if (run_cnt) atomicAdd(&h[run_copy + run_bin], run_cnt);
+          if (run_cnt) atomicAdd(&h[run_copy + bin_of(run_bin)], run_cnt);
           run_bin = b;
           run_cnt = 0u;
         }
@@ -145,7 +148,7 @@ __device__ __forceinline__ void hist_pass_planes(const SelArgs& a, int c, int bi
     }
   }
   if (PASS == 1) {
-    if (run_cnt) atomicAdd(&h[run_copy + run_bin], run_cnt);
+    if (run_cnt) atomicAdd(&h[run_copy + bin_of(run_bin)], run_cnt);
     if (run_nan) atomicAdd(&nanc, run_nan);
   }
   __syncthreads();
